@@ -1,0 +1,105 @@
+"""ctypes binding of libacr_hip.so (C ABI: include/acr_hip.h).
+
+The HIP library is the product: there is no CPU or eager-PyTorch fallback.  If the shared object is
+missing, or a call returns a negative status, this module raises -- loudly -- instead of degrading.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C acr_wsss_amd/csrc``.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libacr_hip.so")
+
+ACR_F32, ACR_BF16 = 0, 1
+GETAM_FUNCS = {"grad": 0, "cam_grad": 1, "grad_s": 2, "cam_grad_s": 3}
+
+c_void_p, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                                  ctypes.c_float, ctypes.c_size_t)
+
+
+class AttnDesc(ctypes.Structure):
+    """struct acr_attn_desc (include/acr_hip.h)."""
+    _fields_ = [("B", c_int32), ("H", c_int32), ("T", c_int32), ("head_dim", c_int32),
+                ("dtype", c_int32), ("scale", c_float),
+                ("qkv_sb", c_int64), ("qkv_st", c_int64), ("qkv_sh", c_int64),
+                ("o_sb", c_int64), ("o_st", c_int64), ("o_sh", c_int64)]
+
+
+_P = ctypes.POINTER(AttnDesc)
+# name -> (restype, argtypes); must list every symbol include/acr_hip.h declares (tests check this)
+SIGNATURES = {
+    "acr_version": (c_int32, []),
+    "acr_last_error": (ctypes.c_char_p, []),
+    "acr_attn_fwd": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "acr_attn_bwd": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "acr_attn_probs": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "acr_attn_dprobs": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "acr_consistency_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),
+    "acr_consistency_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                      c_void_p, c_void_p]),
+    "acr_consistency_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                      c_void_p, c_void_p, c_int64, c_void_p]),
+    "acr_getam_row_accum": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                      c_void_p, c_void_p]),
+    "acr_aff_refine": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "acr_patch_cam": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                c_void_p, c_void_p]),
+    "acr_bilinear_resize": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int32,
+                                      c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+}
+
+_lib = None
+
+
+class AcrHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libacr_hip.so (once).  Raises AcrHipError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AcrHipError(
+                "libacr_hip.so not found at %s -- the HIP extension is the product path and there is no "
+                "fallback.  Build it: python -c 'import __graft_entry__ as g; g.build()'" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        if lib.acr_version() != 1:
+            raise AcrHipError("libacr_hip.so ABI version %d != 1" % lib.acr_version())
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise AcrHipError("%s failed (%d): %s" % (what, rc, load().acr_last_error().decode()))
+
+
+def stream_ptr():
+    """Raw hipStream_t of torch's current stream (kernels are enqueued there; graph-capturable)."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return ACR_F32
+    if dt == torch.bfloat16:
+        return ACR_BF16
+    raise AcrHipError("unsupported dtype %s (fp32 and bf16 are built)" % dt)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise AcrHipError("acr_wsss_amd ops run on the GPU only (got a %s tensor); there is no CPU path"
+                              % t.device)

@@ -1,0 +1,313 @@
+"""Encoder of the ACR model: ResNetV2 stem (hybrid patch embedding) + ViT whose attention runs in HIP.
+
+Module / parameter names reproduce the reference's state-dict layout exactly (315 tensors for hybrid-base,
+tests/golden/state_dict_layout.json) so reference checkpoints load with ``strict=True``:
+  models/resnetv2.py:171-216,250-383   Bottleneck / ResNetStage / ResNetV2 (layers=(3,4,9), preact=False, 'same' stem)
+  models/layers/std_conv.py:40-65      StdConv2dSame (weight standardisation + TF SAME padding)
+  models/layers/norm_act.py:69-85      GroupNormAct
+  models/vision_transformer_hybrid.py:67-106   HybridEmbed
+  models/vision_transformer.py:148-233,262-504 Mlp / Attention / Block / VisionTransformer.forward_flex
+
+Convolutions, GroupNorm/LayerNorm and the MLP GEMMs stay on stock PyTorch-ROCm ops (MIOpen / hipBLASLt) as
+SURVEY 7 scopes them; the attention core -- softmax(q k^T) v with the head-mean side output the ACR loss
+consumes, and its backward -- is ``ops.attention_core`` (hand-written gfx950 kernels, include/acr_hip.h).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------------
+# ResNetV2 pieces
+# ------------------------------------------------------------------------------------------------
+def _same_pad(n, k, s):
+    return max((math.ceil(n / s) - 1) * s + (k - 1) + 1 - n, 0)
+
+
+def pad_same(x, k, s, value=0.0):
+    ph, pw = _same_pad(x.shape[-2], k, s), _same_pad(x.shape[-1], k, s)
+    if ph > 0 or pw > 0:
+        x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2], value=value)
+    return x
+
+
+class StdConv2dSame(nn.Conv2d):
+    """Weight-standardised conv, TF 'SAME' padding (asymmetric: the odd pixel goes right/bottom)."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, eps=1e-5):
+        static = stride == 1 and (kernel_size - 1) % 2 == 0
+        super().__init__(cin, cout, kernel_size, stride=stride, padding=(kernel_size - 1) // 2 if static else 0, bias=False)
+        self.dynamic_pad = not static
+        self.eps = eps
+
+    def standardized_weight(self):
+        std, mean = torch.std_mean(self.weight, dim=[1, 2, 3], keepdim=True, unbiased=False)
+        return (self.weight - mean) / (std + self.eps)
+
+    def forward(self, x):
+        if self.dynamic_pad:
+            x = pad_same(x, self.kernel_size[0], self.stride[0])
+        return F.conv2d(x, self.standardized_weight(), None, self.stride, self.padding)
+
+
+class GroupNormAct(nn.GroupNorm):
+    def __init__(self, channels, apply_act=True):
+        super().__init__(32, channels, eps=1e-5)
+        self.apply_act = apply_act
+
+    def forward(self, x):
+        x = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+        return F.relu(x) if self.apply_act else x
+
+
+class MaxPool2dSame(nn.Module):
+    def forward(self, x):
+        return F.max_pool2d(pad_same(x, 3, 2, value=-float("inf")), 3, 2)
+
+
+class DownsampleConv(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv = StdConv2dSame(cin, cout, 1, stride=stride)
+        self.norm = GroupNormAct(cout, apply_act=False)
+
+    def forward(self, x):
+        return self.norm(self.conv(x))
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, cin, cout, stride, downsample):
+        super().__init__()
+        mid = cout // 4
+        self.downsample = DownsampleConv(cin, cout, stride) if downsample else None
+        self.conv1 = StdConv2dSame(cin, mid, 1)
+        self.norm1 = GroupNormAct(mid)
+        self.conv2 = StdConv2dSame(mid, mid, 3, stride=stride)
+        self.norm2 = GroupNormAct(mid)
+        self.conv3 = StdConv2dSame(mid, cout, 1)
+        self.norm3 = GroupNormAct(cout, apply_act=False)
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        x = self.norm1(self.conv1(x))
+        x = self.norm2(self.conv2(x))
+        x = self.norm3(self.conv3(x))
+        return F.relu(x + shortcut)
+
+
+class ResNetStage(nn.Module):
+    def __init__(self, cin, cout, stride, depth):
+        super().__init__()
+        self.blocks = nn.Sequential(*[Bottleneck(cin if i == 0 else cout, cout, stride if i == 0 else 1, i == 0)
+                                      for i in range(depth)])
+
+    def forward(self, x):
+        return self.blocks(x)
+
+
+class ResNetV2(nn.Module):
+    """Non-preact ResNetV2 feature extractor, layers (3,4,9), channels (256,512,1024), output stride 16."""
+
+    def __init__(self, layers=(3, 4, 9), channels=(256, 512, 1024), in_chans=3, stem_chs=64):
+        super().__init__()
+        self.stem = nn.Sequential(OrderedDict([
+            ("conv", StdConv2dSame(in_chans, stem_chs, 7, stride=2)),
+            ("norm", GroupNormAct(stem_chs)),
+            ("pool", MaxPool2dSame())]))
+        stages, prev = [], stem_chs
+        for i, (d, c) in enumerate(zip(layers, channels)):
+            stages.append(ResNetStage(prev, c, 1 if i == 0 else 2, d))
+            prev = c
+        self.stages = nn.Sequential(*stages)
+        self.num_features = prev
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x, taps=None):
+        x = self.stem(x)
+        for i, st in enumerate(self.stages):
+            x = st(x)
+            if taps is not None and i < 2:
+                taps[str(i + 1)] = x           # DPT/vit.py:426-431 forward hooks "1", "2"
+        return x
+
+
+class HybridEmbed(nn.Module):
+    def __init__(self, backbone, embed_dim):
+        super().__init__()
+        self.backbone = backbone
+        self.proj = nn.Conv2d(backbone.num_features, embed_dim, kernel_size=1, stride=1)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, patch, in_chans, embed_dim):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch, stride=patch)
+
+
+# ------------------------------------------------------------------------------------------------
+# ViT
+# ------------------------------------------------------------------------------------------------
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class Attention(nn.Module):
+    """models/vision_transformer.py:167-214 with the (B,H,T,T) softmax never written to HBM.
+
+    ``get_attn()`` / ``get_attn_gradients()`` keep working for code that reaches into the blocks
+    (DPT/ACR.py:108-111,182-184): the per-head maps are recomputed on demand from the saved q, k, row
+    log-sum-exp (resp. dO, v) by the HIP kernels instead of being retained after every forward."""
+
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        assert dim % num_heads == 0 and dim // num_heads == ops.HEAD_DIM, "HIP attention is built for head_dim 64"
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+        self._saved = None          # (qkv, lse2, heads) of the last forward
+        self._saved_do = None       # dO of the last backward
+        self._override = {}
+
+    def forward(self, x, stack=None, layer=0):
+        self._override = {}
+        qkv = self.qkv(x)                                           # packed (B, T, 3*H*64): no permute copy
+        o, _ = ops.attention_core(qkv, self.num_heads, stack, layer, self)
+        return self.proj(o)
+
+    # -- reference state API (vision_transformer.py:186-196) --
+    def get_attn(self):
+        if "attn" in self._override:
+            return self._override["attn"]
+        if self._saved is None:
+            return None
+        qkv, lse2, heads = self._saved
+        return ops.attn_probs(qkv.detach(), lse2, heads)
+
+    def save_attn(self, attn):
+        self._override["attn"] = attn
+
+    def get_attn_gradients(self):
+        if "grad" in self._override:
+            return self._override["grad"]
+        if self._saved is None or self._saved_do is None:
+            return None
+        qkv, _, heads = self._saved
+        return ops.attn_dprobs(qkv.detach(), self._saved_do, heads)
+
+    def save_attn_gradients(self, g):
+        self._override["grad"] = g
+
+    def saved_for_getam(self):
+        """(qkv, dO, lse2, heads) of the last forward/backward, for the fused GETAM row kernel."""
+        if self._saved is None or self._saved_do is None:
+            return None
+        qkv, lse2, heads = self._saved
+        return qkv.detach(), self._saved_do, lse2, heads
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = Attention(dim, num_heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x, stack=None, layer=0):
+        x = x + self.attn(self.norm1(x), stack, layer)
+        return x + self.mlp(self.norm2(x))
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, embed_dim=768, depth=12, num_heads=12, hybrid=True, patch=16, img_size=384,
+                 num_classes=1000, distilled=False, in_chans=3):
+        super().__init__()
+        self.embed_dim, self.depth, self.num_heads = embed_dim, depth, num_heads
+        self.num_tokens = 2 if distilled else 1
+        self.start_index = self.num_tokens
+        self.patch_size = [16, 16]
+        if hybrid:
+            self.patch_embed = HybridEmbed(ResNetV2(in_chans=in_chans), embed_dim)
+        else:
+            self.patch_embed = PatchEmbed(patch, in_chans, embed_dim)
+        n_patches = (img_size // 16) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.bkg_token = nn.Parameter(torch.zeros(1, 1, embed_dim))          # vision_transformer.py:307 (unused)
+        self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim)) if distilled else None
+        self.pos_embed = nn.Parameter(torch.zeros(1, n_patches + self.num_tokens, embed_dim))
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.head = nn.Linear(embed_dim, num_classes)                        # in the layout, never used by ACR
+        self.head_dist = nn.Linear(embed_dim, num_classes) if distilled else None
+        self._init_weights()
+
+    def _init_weights(self):
+        for t in (self.pos_embed, self.cls_token, self.bkg_token):
+            nn.init.trunc_normal_(t, std=0.02)
+        if self.dist_token is not None:
+            nn.init.trunc_normal_(self.dist_token, std=0.02)
+        for name, m in self.named_modules():
+            if name.startswith("patch_embed.backbone"):
+                continue
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Conv2d):
+                fan_in = m.weight[0].numel()
+                nn.init.trunc_normal_(m.weight, std=math.sqrt(1.0 / fan_in) / 0.87962566103423978)
+                nn.init.zeros_(m.bias)
+
+    def _resize_pos_embed(self, posemb, gs_h, gs_w):
+        tok, grid = posemb[:, :self.start_index], posemb[0, self.start_index:]
+        gs_old = int(math.sqrt(grid.shape[0]))
+        if gs_old == gs_h and gs_old == gs_w:
+            return posemb
+        grid = grid.reshape(1, gs_old, gs_old, -1).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, size=(gs_h, gs_w), mode="bilinear")
+        grid = grid.permute(0, 2, 3, 1).reshape(1, gs_h * gs_w, -1)
+        return torch.cat([tok, grid], dim=1)
+
+    def forward_flex(self, x, stack=None, taps=None, truncate_at=None):
+        """models/vision_transformer.py:449-486.  ``stack`` (ops.MeanStack) receives the head-mean maps,
+        ``taps`` the DPT activations dict; ``truncate_at`` = k detaches the tokens entering block k so a
+        later backward stops there (GETAM only needs gradients of blocks >= start_layer)."""
+        b, c, h, w = x.shape
+        pos = self._resize_pos_embed(self.pos_embed, h // self.patch_size[1], w // self.patch_size[0])
+        if isinstance(self.patch_embed, HybridEmbed):
+            x = self.patch_embed.backbone(x, taps)
+        res_features = x
+        x = self.patch_embed.proj(x).flatten(2).transpose(1, 2)
+        toks = [self.cls_token.expand(b, -1, -1)]
+        if self.dist_token is not None:
+            toks.append(self.dist_token.expand(b, -1, -1))
+        x = torch.cat(toks + [x], dim=1) + pos
+        for i, blk in enumerate(self.blocks):
+            if truncate_at is not None and i == truncate_at:
+                x = x.detach()
+            x = blk(x, stack, i)
+            if taps is not None:
+                if i == self.tap3:
+                    taps["3"] = x
+                if i == self.tap4:
+                    taps["4"] = x
+        return self.norm(x) if truncate_at is None else None, res_features
+
+    tap3, tap4 = 8, 11

@@ -1,0 +1,70 @@
+// Shared device/host helpers for libacr_hip.so (gfx950 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/acr_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define ACR_LOG2E 1.4426950408889634f
+
+// ---- host side error plumbing (thread-local message, never throws) ---------------------------
+void acr_set_error(const char* fmt, ...);
+#define ACR_CHECK_ARG(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            acr_set_error(__VA_ARGS__);     \
+            return ACR_ERR_INVALID;         \
+        }                                   \
+    } while (0)
+int acr_check_launch(const char* what);
+
+// ---- XCD-aware block remap --------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap the
+// linear block id so that each XCD walks one contiguous chunk of the work list: neighbouring
+// tiles (same batch/head -> same K/V panels) then hit the same 4 MiB L2.  Bijective for any n.
+__device__ __forceinline__ int acr_xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// C/D fragment row of a 32x32 MFMA accumulator register (dtype independent on gfx950):
+// element `reg` of lane l sits at row krow(reg, l>>5), column l&31.
+__device__ __forceinline__ int acr_krow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// ---- dtype-generic 4-element loads / stores (fp32 math everywhere) ---------------------------
+template <typename T>
+__device__ __forceinline__ f32x4 acr_load4(const T* p);
+template <>
+__device__ __forceinline__ f32x4 acr_load4<float>(const float* p) {
+    return *reinterpret_cast<const f32x4*>(p);
+}
+template <>
+__device__ __forceinline__ f32x4 acr_load4<__bf16>(const __bf16* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ void acr_store1(T* p, float v);
+template <>
+__device__ __forceinline__ void acr_store1<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void acr_store1<__bf16>(__bf16* p, float v) { *p = (__bf16)v; }
+template <typename T>
+__device__ __forceinline__ void acr_store4(T* p, f32x4 v);
+template <>
+__device__ __forceinline__ void acr_store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <>
+__device__ __forceinline__ void acr_store4<__bf16>(__bf16* p, f32x4 v) {
+    bf16x4 r = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = r;
+}
+template <typename T>
+__device__ __forceinline__ float acr_load1(const T* p) { return (float)*p; }

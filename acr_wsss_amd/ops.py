@@ -1,0 +1,242 @@
+"""torch.autograd wrappers around the C ABI (include/acr_hip.h).
+
+These are the only places where the Python host surface meets the HIP library.  Tensors are torch
+allocations (device memory + stream plumbing); all arithmetic of the hot path happens in the kernels.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+HEAD_DIM = 64
+
+
+def _desc(B, H, T, dtype, packed_qkv=True):
+    """Descriptor for q/k/v aliasing slices of the packed qkv Linear output (B,T,3,H,64) and o / do in
+    the reference's (B,T,H*64) activation layout (models/vision_transformer.py:200-201,211)."""
+    D = H * HEAD_DIM
+    d = L.AttnDesc()
+    d.B, d.H, d.T, d.head_dim = B, H, T, HEAD_DIM
+    d.dtype = L.dtype_code(dtype)
+    d.scale = HEAD_DIM ** -0.5
+    d.qkv_sb, d.qkv_st, d.qkv_sh = T * 3 * D, 3 * D, HEAD_DIM
+    d.o_sb, d.o_st, d.o_sh = T * D, D, HEAD_DIM
+    return d
+
+
+def _qkv_ptrs(qkv, H):
+    esz = qkv.element_size()
+    base = qkv.data_ptr()
+    D = H * HEAD_DIM
+    return (L.c_void_p(base), L.c_void_p(base + D * esz), L.c_void_p(base + 2 * D * esz))
+
+
+class MeanStack:
+    """Owner of the (B, L, T, T) fp32 head-mean stack of one forward pass (DPT/ACR.py:107-112).
+
+    Each attention layer's kernel writes its slice in place (strided output), so the reference's 12
+    ``mean(dim=1)`` kernels and the ``torch.stack`` copy never happen.  Not a tensor on purpose: autograd
+    must not see the buffer as an input of the per-layer Functions."""
+
+    def __init__(self, B, Lyr, T, device):
+        self.buf = torch.empty((B, Lyr, T, T), dtype=torch.float32, device=device)
+        self.n_layers = Lyr
+
+
+class AttnCoreFn(Function):
+    """o = softmax(q k^T d^-0.5) v  (+ head-mean side output), packed qkv in, (B,T,D) out."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, stack, layer, owner):
+        L.require_gpu(qkv)
+        if not qkv.is_contiguous():
+            qkv = qkv.contiguous()
+        B, T, D3 = qkv.shape
+        D = heads * HEAD_DIM
+        assert D3 == 3 * D, "qkv last dim %d != 3*heads*64" % D3
+        lib = L.load()
+        d = _desc(B, heads, T, qkv.dtype)
+        o = torch.empty((B, T, D), dtype=qkv.dtype, device=qkv.device)
+        lse2 = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device)
+        pm = None
+        if stack is not None:
+            pm = stack.buf[:, layer]
+        qp, kp, vp = _qkv_ptrs(qkv, heads)
+        L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm),
+                                 stack.buf.stride(0) if stack is not None else 0, L.stream_ptr()), "acr_attn_fwd")
+        ctx.save_for_backward(qkv, o, lse2)
+        ctx.heads = heads
+        ctx.owner = owner
+        if owner is not None:
+            owner._saved = (qkv, lse2, heads)
+            owner._saved_do = None
+        if pm is None:
+            return o, None
+        return o, pm
+
+    @staticmethod
+    def backward(ctx, d_o, g_pm):
+        qkv, o, lse2 = ctx.saved_tensors
+        heads = ctx.heads
+        B, T, _ = qkv.shape
+        lib = L.load()
+        if d_o is None:
+            d_o = torch.zeros_like(o)
+        if not d_o.is_contiguous():
+            d_o = d_o.contiguous()
+        if d_o.dtype != qkv.dtype:
+            d_o = d_o.to(qkv.dtype)
+        gm_sb = 0
+        if g_pm is not None:
+            if g_pm.dtype != torch.float32 or g_pm.stride(2) != 1 or g_pm.stride(1) != T:
+                g_pm = g_pm.float().contiguous()
+            gm_sb = g_pm.stride(0)
+        d = _desc(B, heads, T, qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device)
+        qp, kp, vp = _qkv_ptrs(qkv, heads)
+        dqp, dkp, dvp = _qkv_ptrs(dqkv, heads)
+        L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(g_pm), gm_sb,
+                                 dqp, dkp, dvp, L.ptr(delta), L.stream_ptr()), "acr_attn_bwd")
+        if ctx.owner is not None:
+            ctx.owner._saved_do = d_o
+        return dqkv, None, None, None, None
+
+
+class StackAliasFn(Function):
+    """Expose MeanStack.buf as the autograd-visible (B,L,T,T) tensor without copying: forward returns the
+    buffer the per-layer kernels already wrote, backward hands each layer its strided slice of the
+    incoming gradient (what torch.stack's backward does with 12 copies in the reference)."""
+
+    @staticmethod
+    def forward(ctx, stack, *pms):
+        ctx.n = len(pms)
+        return stack.buf
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(g[:, l] for l in range(ctx.n))
+
+
+def attention_core(qkv, heads, stack=None, layer=0, owner=None):
+    return AttnCoreFn.apply(qkv, heads, stack, layer, owner)
+
+
+def attn_probs(qkv, lse2, heads):
+    """Per-head P (B,H,T,T) fp32 recomputed from q, k, lse2 (Attention.get_attn compatibility)."""
+    B, T, _ = qkv.shape
+    lib = L.load()
+    out = torch.empty((B, heads, T, T), dtype=torch.float32, device=qkv.device)
+    qp, kp, _ = _qkv_ptrs(qkv, heads)
+    L.check(lib.acr_attn_probs(_desc(B, heads, T, qkv.dtype), qp, kp, L.ptr(lse2), L.ptr(out), L.stream_ptr()),
+            "acr_attn_probs")
+    return out
+
+
+def attn_dprobs(qkv, d_o, heads):
+    """Per-head dO V^T (B,H,T,T) fp32 (Attention.get_attn_gradients compatibility)."""
+    B, T, _ = qkv.shape
+    lib = L.load()
+    out = torch.empty((B, heads, T, T), dtype=torch.float32, device=qkv.device)
+    _, _, vp = _qkv_ptrs(qkv, heads)
+    L.check(lib.acr_attn_dprobs(_desc(B, heads, T, qkv.dtype), L.ptr(d_o), vp, L.ptr(out), L.stream_ptr()),
+            "acr_attn_dprobs")
+    return out
+
+
+def getam_row_accum(qkv, d_o, lse2, heads, batch, func, cam_row):
+    B, T, _ = qkv.shape
+    lib = L.load()
+    qp, kp, vp = _qkv_ptrs(qkv, heads)
+    L.check(lib.acr_getam_row_accum(_desc(B, heads, T, qkv.dtype), qp, kp, vp, L.ptr(d_o), L.ptr(lse2), batch,
+                                    L.GETAM_FUNCS[func], L.ptr(cam_row), L.stream_ptr()), "acr_getam_row_accum")
+
+
+class ConsistencyFn(Function):
+    """(cls_align, aff_align) of train_acr.py:143-161 on one (2B,L,T,T) stack holding view 1 in [:B] and
+    view 2 in [B:] (both views run as one 2B batch; GroupNorm/LayerNorm are per-sample so this is exact)."""
+
+    @staticmethod
+    def forward(ctx, a, p):
+        L.require_gpu(a)
+        assert a.dtype == torch.float32 and a.dim() == 4 and a.shape[0] % 2 == 0
+        B2, Ly, T, T2 = a.shape
+        B = B2 // 2
+        assert T == T2 == p * p + 1, "attention map side %d != p*p+1 (p=%d)" % (T, p)
+        assert a.stride(3) == 1 and a.stride(2) == T and a.stride(1) == T * T, "maps must be dense per sample"
+        lib = L.load()
+        ws = torch.empty(lib.acr_consistency_ws_floats(B, Ly, T), dtype=torch.float32, device=a.device)
+        out = torch.empty(2, dtype=torch.float32, device=a.device)
+        L.check(lib.acr_consistency_fwd(L.ptr(a[:B]), L.ptr(a[B:]), a.stride(0), B, Ly, T, p, L.ptr(ws), L.ptr(out),
+                                        L.stream_ptr()), "acr_consistency_fwd")
+        ctx.save_for_backward(a)
+        ctx.p = p
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (a,) = ctx.saved_tensors
+        B2, Ly, T, _ = a.shape
+        B = B2 // 2
+        lib = L.load()
+        gout = gout.contiguous().float()
+        g = torch.empty((B2, Ly, T, T), dtype=torch.float32, device=a.device)
+        L.check(lib.acr_consistency_bwd(L.ptr(a[:B]), L.ptr(a[B:]), a.stride(0), B, Ly, T, ctx.p, L.ptr(gout),
+                                        L.ptr(g[:B]), L.ptr(g[B:]), g.stride(0), L.stream_ptr()), "acr_consistency_bwd")
+        return g, None
+
+
+def consistency(a, p, a2=None):
+    """Returns (cls_align, aff_align).  ``a`` is the (2B,L,T,T) two-view stack; if ``a2`` is given, ``a`` and
+    ``a2`` are separate (B,L,T,T) stacks (reference-style call) and are concatenated first."""
+    if a2 is not None:
+        a = torch.cat([a, a2], dim=0)
+    out = ConsistencyFn.apply(a, p)
+    return out[0], out[1]
+
+
+def patch_cam(x, weight, bias):
+    """relu(x @ weight.T + bias) for patch tokens x (N, D) -> (N, C) fp32 (DPT/ACR.py:133-134)."""
+    L.require_gpu(x, weight, bias)
+    N, D = x.shape
+    C = weight.shape[0]
+    assert x.stride(1) == 1 and weight.is_contiguous() and bias.is_contiguous()
+    weight, bias = weight.to(x.dtype), bias.to(x.dtype)
+    out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    L.check(L.load().acr_patch_cam(L.ptr(x), x.stride(0), L.ptr(weight), L.ptr(bias), N, D, C, L.dtype_code(x.dtype),
+                                   L.ptr(out), L.stream_ptr()), "acr_patch_cam")
+    return out
+
+
+def bilinear_resize(src, out_hw, align_corners, chan_mul=None, hflip=False, out=None, channels_last=False):
+    """Resize (C,ih,iw) [or (ih,iw,C) when channels_last] fp32 to (C,oh,ow), optional per-channel multiply and
+    horizontal flip; accumulates into ``out`` when given (infer_cam.py:157-160,187,195-196,201,208)."""
+    L.require_gpu(src)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    if channels_last:
+        ih, iw, C = src.shape
+        sc, sp = 1, C
+    else:
+        C, ih, iw = src.shape
+        sc, sp = ih * iw, 1
+    oh, ow = out_hw
+    acc = out is not None
+    if out is None:
+        out = torch.empty((C, oh, ow), dtype=torch.float32, device=src.device)
+    assert out.shape == (C, oh, ow) and out.is_contiguous()
+    if chan_mul is not None:
+        chan_mul = chan_mul.to(device=src.device, dtype=torch.float32).contiguous()
+    L.check(L.load().acr_bilinear_resize(L.ptr(src), sc, sp, C, ih, iw, L.ptr(out), oh, ow, int(align_corners),
+                                         L.ptr(chan_mul), int(hflip), int(acc), L.stream_ptr()), "acr_bilinear_resize")
+    return out
+
+
+def aff_refine(stack_b, cams):
+    """patch_aff @ cam for one sample: stack_b (L,T,T) fp32 head-mean maps, cams (n, T-1) -> (n, T-1)."""
+    L.require_gpu(stack_b, cams)
+    Ly, T, _ = stack_b.shape
+    assert stack_b.is_contiguous() and cams.is_contiguous() and cams.shape[1] == T - 1
+    out = torch.empty_like(cams)
+    L.check(L.load().acr_aff_refine(L.ptr(stack_b), Ly, T, L.ptr(cams), cams.shape[0], L.ptr(out), L.stream_ptr()),
+            "acr_aff_refine")
+    return out

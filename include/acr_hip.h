@@ -1,0 +1,131 @@
+/*
+ * acr_hip.h -- C ABI of libacr_hip.so, the MI355X (gfx950) implementation of the ACR_WSSS hot path.
+ *
+ * The reference (OpenNLPLab/ACR_WSSS) has no FFI layer: its hot path is stock PyTorch ops called from
+ * Python.  This header is the boundary the replacement defines underneath the reference's Python
+ * surface.  Each entry point names the reference code it replaces (file:line under
+ * the reference root).  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - plain C, no torch types; device pointers are raw `void*` / `float*` owned by the caller
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); no hidden synchronisation,
+ *     no allocation, no global mutable state -> safe to capture into a hipGraph, re-entrant
+ *   - returns 0 on success, a negative acr_status on failure; acr_last_error() gives a
+ *     thread-local message for the last failure on the calling thread
+ *   - tensors are row-major; "stride" arguments are in ELEMENTS of the tensor's dtype
+ */
+#ifndef ACR_HIP_H
+#define ACR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACR_ABI_VERSION 1
+
+typedef enum acr_status {
+    ACR_OK = 0,
+    ACR_ERR_INVALID = -1,      /* bad argument (null pointer, unsupported head_dim, ...) */
+    ACR_ERR_LAUNCH = -2,       /* hipLaunch / hipGetLastError failure */
+    ACR_ERR_UNSUPPORTED = -3   /* dtype / shape not built into this library */
+} acr_status;
+
+typedef enum acr_dtype { ACR_F32 = 0, ACR_BF16 = 1 } acr_dtype;
+
+typedef enum acr_getam_func {   /* DPT/ACR.py:189-205 */
+    ACR_GETAM_GRAD = 0, ACR_GETAM_CAM_GRAD = 1, ACR_GETAM_GRAD_S = 2, ACR_GETAM_CAM_GRAD_S = 3
+} acr_getam_func;
+
+/* Geometry of one multi-head attention problem.  q, k, v share one stride triple so that they can
+ * alias slices of the packed output of the qkv Linear, (B, T, 3, H, d): sb = 3*H*d*T, st = 3*H*d,
+ * sh = d (no permute copy, models/vision_transformer.py:200-201).  o / do use (o_sb, o_st, o_sh);
+ * for the reference's (B, T, H*d) activation layout: o_sb = T*H*d, o_st = H*d, o_sh = d
+ * (the transpose(1,2).reshape of vision_transformer.py:211 is folded into the store).
+ * head_dim must be 64 (every ViT the reference's backbone_dict reaches: tiny/small/base/large). */
+typedef struct acr_attn_desc {
+    int32_t B, H, T, head_dim;
+    int32_t dtype;              /* acr_dtype of q/k/v/o/do/dq/dk/dv */
+    float   scale;              /* head_dim^-0.5, vision_transformer.py:173 */
+    int64_t qkv_sb, qkv_st, qkv_sh;
+    int64_t o_sb, o_st, o_sh;
+} acr_attn_desc;
+
+int         acr_version(void);
+const char* acr_last_error(void);
+
+/* ---- attention (models/vision_transformer.py:198-214 `Attention.forward`, minus the two Linears) ----
+ * O = softmax(q k^T * scale) v without materialising P.  lse2 (B,H,T) fp32 receives the row
+ * log-sum-exp in base-2 units of the scaled logits: P[b,h,i,j] = exp2(s2 - lse2), s2 = q.k*scale*log2(e).
+ * If pmean != NULL it receives mean_h P (B,T,T) fp32 with batch stride pmean_sb and row stride T:
+ * the per-layer slice of the (B,L,T,T) stack DPT/ACR.py:107-112 builds with 12 mean kernels + stack. */
+int acr_attn_fwd(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
+                 void* o, float* lse2, float* pmean, int64_t pmean_sb, void* stream);
+
+/* Backward of acr_attn_fwd.  gmean (nullable) is dLoss/d(mean_h P), (B,T,T) fp32, batch stride
+ * gmean_sb, row stride T (what autograd delivers to the `torch.mean(attn, dim=1)` node of
+ * DPT/ACR.py:109).  dP_h = dO_h V_h^T + gmean/H.  delta_ws: caller-owned (B,H,T) fp32 scratch.
+ * dq/dk/dv use the q/k/v strides (they may alias slices of one packed (B,T,3,H,d) buffer). */
+int acr_attn_bwd(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
+                 const void* o, const void* d_o, const float* lse2,
+                 const float* gmean, int64_t gmean_sb,
+                 void* dq, void* dk, void* dv, float* delta_ws, void* stream);
+
+/* Materialise per-head maps for API compatibility with `Attention.get_attn()` /
+ * `get_attn_gradients()` (vision_transformer.py:186-196): probs -> P (B,H,T,T) fp32 contiguous,
+ * dprobs -> dO V^T (B,H,T,T) fp32 contiguous.  Not used by the fused training / GETAM paths. */
+int acr_attn_probs(const acr_attn_desc* desc, const void* q, const void* k, const float* lse2,
+                   float* probs, void* stream);
+int acr_attn_dprobs(const acr_attn_desc* desc, const void* d_o, const void* v,
+                    float* dprobs, void* stream);
+
+/* ---- attention-consistency regulariser (train_acr.py:143-161, inline in train()) ----
+ * a1, a2: (B,L,T,T) fp32 head-mean stacks of view 1 / view 2 (T = p*p + 1), batch stride a_sb each
+ * (so both may live in one (2B,L,T,T) buffer).  With pi(i*p+j) = i*p+(p-1-j):
+ *   out[0] = mean_{b,l,c}   |a1[b,l,0,1+c]   - a2[b,l,0,1+pi(c)]|          (cls_align_loss, :160)
+ *   out[1] = mean_{b,l,r,c} |a1[b,l,1+r,1+c] - a2[b,l,1+pi(r),1+pi(c)]|    (aff_align_loss, :161)
+ * equal to the reference's 3*p in-place block flips (:151-158) followed by two F.l1_loss.
+ * partial_ws: caller-owned fp32 scratch of acr_consistency_ws_floats(B,L,T) floats.  Deterministic
+ * (fixed-order two-stage reduction, no float atomics). */
+size_t acr_consistency_ws_floats(int32_t B, int32_t L, int32_t T);
+int acr_consistency_fwd(const float* a1, const float* a2, int64_t a_sb, int32_t B, int32_t L,
+                        int32_t T, int32_t p, float* partial_ws, float* out2, void* stream);
+/* gout2: device pointer to the two upstream gradients (d/d out[0], d/d out[1]).  Writes
+ * g1, g2 (same geometry as a1, a2; every element written, zeros where the loss does not look). */
+int acr_consistency_bwd(const float* a1, const float* a2, int64_t a_sb, int32_t B, int32_t L,
+                        int32_t T, int32_t p, const float* gout2, float* g1, float* g2,
+                        int64_t g_sb, void* stream);
+
+/* ---- GETAM (DPT/ACR.py:177-215 `ACR.getam`) ----
+ * Adds one layer's contribution to cam_row (T fp32, caller zero-initialised):
+ *   cam_row[j] += f_h( dP_h[batch,0,j], P_h[batch,0,j] ),  dP_h = dO_h V_h^T (row 0 only)
+ * for `func` in acr_getam_func.  Only row 0 of the layer-summed map is consumed by the reference
+ * (:213), so nothing else is computed.  The final relu and the [1:] / [2:] slice are the caller's. */
+int acr_getam_row_accum(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
+                        const void* d_o, const float* lse2, int32_t batch, int32_t func,
+                        float* cam_row, void* stream);
+
+/* Affinity refinement (infer_cam.py:164-165,183-184): out[c][r] = sum_l sum_k a[l][1+r][1+k] cam[c][k]
+ * for one sample's (L,T,T) head-mean stack `a`, n_cam row vectors cam (n_cam, T-1) -> out (n_cam, T-1). */
+int acr_aff_refine(const float* a, int32_t L, int32_t T, const float* cam, int32_t n_cam,
+                   float* out, void* stream);
+
+/* ---- CAM read-outs ----
+ * Patch-token -> class activation (DPT/ACR.py:133-134): out[n][c] = relu(x[n,:] . w[c,:] + bias[c]),
+ * x (N, D) with row stride x_st, w (C, D) contiguous, out (N, C) contiguous; dtype of x/w/bias. */
+int acr_patch_cam(const void* x, int64_t x_st, const void* w, const void* bias, int32_t N, int32_t D,
+                  int32_t C, int32_t dtype, float* out, void* stream);
+/* Bilinear resize of a (C, ih, iw) fp32 map given as src[(y*iw + x)*src_sp + c*src_sc] to (C, oh, ow)
+ * contiguous, torch semantics (infer_cam.py:157 align_corners=0; :187 align_corners=1), then optional
+ * per-channel multiply (label mask, :158; chan_mul nullable) and horizontal flip (:159-160,195-196).
+ * If accumulate != 0 the result is added to dst (sum over flips/scales, :201,208). */
+int acr_bilinear_resize(const float* src, int64_t src_sc, int64_t src_sp, int32_t C, int32_t ih,
+                        int32_t iw, float* dst, int32_t oh, int32_t ow, int32_t align_corners,
+                        const float* chan_mul, int32_t hflip, int32_t accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACR_HIP_H */

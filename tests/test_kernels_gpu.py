@@ -1,0 +1,178 @@
+"""Kernel-level parity on the GPU: every C-ABI entry point against plain torch math (fp64 on device) on
+seeded inputs, incl. ragged sizes (T not a multiple of any tile), the maximum T of the inference config and
+the edge cases the path has (p = 1 -> T = 2, masked tails, no head-mean gradient)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _ref_attn(qkv, H, want_grad=False):
+    B, T, _ = qkv.shape
+    q, k, v = qkv.double().reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    P = ((q @ k.transpose(-2, -1)) * 64 ** -0.5).softmax(-1)
+    o = (P @ v).transpose(1, 2).reshape(B, T, H * 64)
+    return o, P
+
+
+def _flip_perm(p, dev):
+    return torch.arange(p * p, device=dev).reshape(p, p).flip(1).reshape(-1)
+
+
+@pytest.mark.parametrize("B,L,p", [(1, 1, 1), (2, 3, 4), (1, 12, 14), (2, 2, 28), (1, 2, 37)])
+def test_consistency(B, L, p):
+    from acr_wsss_amd import ops
+    dev = _dev()
+    T = p * p + 1
+    g = torch.Generator(device="cpu").manual_seed(p * 7 + B)
+    a = torch.rand(2 * B, L, T, T, generator=g).to(dev)
+    a[0, 0, 1:, 1:] = a[B, 0, 1:, 1:][_flip_perm(p, dev)][:, _flip_perm(p, dev)]   # exact zeros in d -> sign 0
+    a.requires_grad_(True)
+    cls, aff = ops.consistency(a, p)
+    w = torch.tensor([1.7, -0.6], device=dev)
+    (cls * w[0] + aff * w[1]).backward()
+    ad = a.detach().double().requires_grad_(True)
+    pi = _flip_perm(p, dev)
+    a1, a2 = ad[:B], ad[B:]
+    rc = (a1[:, :, 0, 1:] - a2[:, :, 0, 1:][:, :, pi]).abs().mean()
+    ra = (a1[:, :, 1:, 1:] - a2[:, :, 1:, 1:][:, :, pi][:, :, :, pi]).abs().mean()
+    (rc * w[0].double() + ra * w[1].double()).backward()
+    assert abs(float(cls) - float(rc)) <= 2e-6 * abs(float(rc)) + 1e-9
+    assert abs(float(aff) - float(ra)) <= 2e-6 * abs(float(ra)) + 1e-9
+    torch.testing.assert_close(a.grad.double(), ad.grad, rtol=1e-5, atol=1e-12)
+    # in-place-flip form of the reference (train_acr.py:151-158) gives the same numbers
+    b2 = a.detach()[B:].clone()
+    c2, f2 = b2[:, :, 0, 1:].unsqueeze(2), b2[:, :, 1:, 1:]
+    for i in range(p):
+        c2[:, :, :, i * p:i * p + p] = c2[:, :, :, i * p:i * p + p].flip(3)
+    for i in range(p):
+        f2[:, :, i * p:i * p + p, :] = f2[:, :, i * p:i * p + p, :].flip(2)
+    for i in range(p):
+        f2[:, :, :, i * p:i * p + p] = f2[:, :, :, i * p:i * p + p].flip(3)
+    ref_aff = torch.nn.functional.l1_loss(a.detach()[:B, :, 1:, 1:], f2)
+    assert abs(float(aff) - float(ref_aff)) <= 5e-6 * abs(float(ref_aff)) + 1e-9
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 2, 1), (1, 17, 12), (2, 197, 3), (1, 785, 12), (1, 1025, 2)])
+@pytest.mark.parametrize("with_g", [True, False])
+def test_attention_f32(B, T, H, with_g):
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(T * 3 + H)
+    qkv = (1.5 * torch.randn(B, T, 3 * H * 64, generator=g)).to(dev).requires_grad_(True)
+    Ly = 2
+    stack = ops.MeanStack(B, Ly, T, dev)
+    stack.buf.fill_(float("nan"))
+    o, pm = ops.attention_core(qkv, H, stack, 1, None)
+    d_o = torch.randn(B, T, H * 64, generator=g).to(dev)
+    gpm = torch.randn(B, T, T, generator=g).to(dev) if with_g else None
+    loss = (o * d_o).sum() + ((pm * gpm).sum() if with_g else 0.0)
+    loss.backward()
+
+    qd = qkv.detach().double().requires_grad_(True)
+    o_ref, P = _ref_attn(qd, H)
+    pm_ref = P.mean(1)
+    loss_ref = (o_ref * d_o.double()).sum() + ((pm_ref * gpm.double()).sum() if with_g else 0.0)
+    loss_ref.backward()
+    torch.testing.assert_close(o.double(), o_ref, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(pm.double(), pm_ref, rtol=1e-4, atol=1e-7)
+    assert torch.isnan(stack.buf[:, 0]).all()            # the other layer's slice is untouched
+    scale = qd.grad.abs().max()
+    assert (qkv.grad.double() - qd.grad).abs().max() <= 3e-5 * scale, (qkv.grad.double() - qd.grad).abs().max() / scale
+
+
+def test_attention_bf16_io():
+    """bf16 tensors through the fp32-MFMA kernels (bf16 I/O, fp32 math)."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    B, T, H = 2, 197, 3
+    g = torch.Generator(device="cpu").manual_seed(5)
+    qkv = torch.randn(B, T, 3 * H * 64, generator=g).to(dev).bfloat16().requires_grad_(True)
+    stack = ops.MeanStack(B, 1, T, dev)
+    o, pm = ops.attention_core(qkv, H, stack, 0, None)
+    d_o = torch.randn(B, T, H * 64, generator=g).to(dev).bfloat16()
+    (o.float() * d_o.float()).sum().backward()
+    qd = qkv.detach().double().requires_grad_(True)
+    o_ref, P = _ref_attn(qd, H)
+    (o_ref * d_o.double()).sum().backward()
+    torch.testing.assert_close(o.double(), o_ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(pm.double(), P.mean(1), rtol=1e-3, atol=1e-6)
+    scale = qd.grad.abs().max()
+    assert (qkv.grad.double() - qd.grad).abs().max() <= 2e-2 * scale
+
+
+def test_probs_dprobs_getam_row():
+    from acr_wsss_amd import ops
+    dev = _dev()
+    B, T, H = 2, 145, 12
+    g = torch.Generator(device="cpu").manual_seed(11)
+    qkv = torch.randn(B, T, 3 * H * 64, generator=g).to(dev).requires_grad_(True)
+    o, _ = ops.attention_core(qkv, H, None, 0, None)
+    d_o = torch.randn(B, T, H * 64, generator=g).to(dev)
+    lse2 = o.grad_fn.saved_tensors[2]
+    P = ops.attn_probs(qkv.detach(), lse2, H)
+    dP = ops.attn_dprobs(qkv.detach(), d_o, H)
+    _, P_ref = _ref_attn(qkv.detach(), H)
+    v = qkv.detach().double().reshape(B, T, 3, H, 64)[:, :, 2].permute(0, 2, 1, 3)
+    dP_ref = d_o.double().reshape(B, T, H, 64).permute(0, 2, 1, 3) @ v.transpose(-2, -1)
+    torch.testing.assert_close(P.double(), P_ref, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(dP.double(), dP_ref, rtol=1e-4, atol=1e-4)
+    for func in ("grad", "cam_grad", "grad_s", "cam_grad_s"):
+        for batch in (0, 1):
+            row = torch.zeros(T, device=dev)
+            ops.getam_row_accum(qkv.detach(), d_o, lse2, H, batch, func, row)
+            ops.getam_row_accum(qkv.detach(), d_o, lse2, H, batch, func, row)      # accumulates
+            gr, cm = dP_ref[batch], P_ref[batch]
+            mg = gr.clamp(min=0).mean(0)
+            mcg = (gr * cm).clamp(min=0).mean(0)
+            ref = {"grad": mg, "cam_grad": mcg, "grad_s": mg * mg, "cam_grad_s": mcg * mg}[func][0] * 2
+            torch.testing.assert_close(row.double(), ref, rtol=1e-4, atol=1e-6 * float(ref.abs().max()))
+
+
+def test_cam_readouts():
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    N, D, C = 36, 768, 20
+    x = torch.randn(1 + N, D, generator=g).to(dev)
+    w = (torch.randn(C, D, generator=g) * D ** -0.5).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    pc = ops.patch_cam(x[1:], w, bias)
+    torch.testing.assert_close(pc, F.relu(F.linear(x[1:], w, bias)), rtol=1e-4, atol=1e-5)
+    lab = torch.zeros(C, device=dev)
+    lab[[3, 11]] = 1.0
+    for (oh, ow) in ((75, 61), (6, 6), (5, 13), (1, 1)):
+        ref = F.interpolate(pc.t().reshape(1, C, 6, 6), (oh, ow), mode="bilinear", align_corners=False)[0]
+        got = ops.bilinear_resize(pc, (oh, ow), False, chan_mul=lab, hflip=True, channels_last=False) if False else \
+            ops.bilinear_resize(pc.reshape(6, 6, C), (oh, ow), False, chan_mul=lab, hflip=True, channels_last=True)
+        torch.testing.assert_close(got, (ref * lab.view(C, 1, 1)).flip(-1), rtol=1e-5, atol=1e-6)
+        src = torch.rand(2, 6, 6, generator=g).to(dev)
+        ref = F.interpolate(src[None], (oh, ow), mode="bilinear", align_corners=True)[0]
+        acc = torch.ones(2, oh, ow, device=dev)
+        ops.bilinear_resize(src, (oh, ow), True, out=acc)
+        torch.testing.assert_close(acc, ref + 1.0, rtol=1e-5, atol=1e-6)
+    Ly, T = 12, 37
+    a = torch.rand(Ly, T, T, generator=g).to(dev)
+    cams = torch.rand(11, T - 1, generator=g).to(dev)
+    out = ops.aff_refine(a, cams)
+    ref = (a[:, 1:, 1:].sum(0).double() @ cams.double().t()).t()
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_errors_are_loud():
+    from acr_wsss_amd import _lib, ops
+    with pytest.raises(_lib.AcrHipError):
+        ops.attention_core(torch.randn(1, 5, 192), 1, None, 0, None)          # CPU tensor: no fallback
+    dev = _dev()
+    with pytest.raises(_lib.AcrHipError):
+        ops.attention_core(torch.randn(1, 5, 192, device=dev).half(), 1, None, 0, None)
+    lib = _lib.load()
+    rc = lib.acr_consistency_fwd(None, None, 0, 1, 1, 5, 2, None, None, None)
+    assert rc < 0 and b"null" in lib.acr_last_error()
