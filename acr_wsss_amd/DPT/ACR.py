@@ -1,0 +1,153 @@
+"""ACR model surface -- drop-in for the reference's ``DPT/ACR.py`` (BaseModel :25-37, DPT :40-143, ACR :147-215).
+
+Same constructor, same methods, same state-dict layout; what changes is underneath:
+  * both views of ``forward_mirror`` run as ONE 2B batch (exact: every norm is per-sample), and the
+    (B,L,T,T) head-mean stack is written slice-by-slice by the attention kernels -- no (B,H,T,T) softmax
+    in HBM, no 12 mean kernels, no stack copy (DPT/ACR.py:107-112);
+  * ``getam`` reads row 0 of dO V^T / P straight from the saved q,k,v,dO with one small kernel per layer
+    instead of materialising two (B,H,T,T) tensors per block (:181-206);
+  * there is no CPU fallback: tensors must live on an MI355X and libacr_hip.so must be built.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..backbone import VisionTransformer
+
+# backbone name -> VisionTransformer kwargs, DPT scratch in_shape   (DPT/vit.py:548-632, DPT/blocks.py:26-83)
+_BACKBONES = {
+    "vitb_rn50_384": (dict(embed_dim=768, depth=12, num_heads=12, hybrid=True), [256, 512, 768, 768], (8, 11)),
+    "vitb16_384": (dict(embed_dim=768, depth=12, num_heads=12, hybrid=False), [96, 192, 384, 768], (8, 11)),
+    "deitb16_384": (dict(embed_dim=768, depth=12, num_heads=12, hybrid=False), [96, 192, 384, 768], (8, 11)),
+    "deitb16_distil_384": (dict(embed_dim=768, depth=12, num_heads=12, hybrid=False, distilled=True),
+                           [96, 192, 384, 768], (8, 11)),
+    "vitl16_384": (dict(embed_dim=1024, depth=24, num_heads=16, hybrid=False), [256, 512, 1024, 1024], (17, 23)),
+    # BASELINE config 1 (plumbing): ViT-tiny/16 @224 assembled from the same parts
+    "vit_tiny16_224": (dict(embed_dim=192, depth=12, num_heads=3, hybrid=False, img_size=224), [48, 96, 192, 192], (8, 11)),
+}
+
+
+class AttnPair(list):
+    """[attn1, attn2] as the reference returns them, plus ``.stacked``: the (2B,L,T,T) tensor both are
+    halves of, so the fused loss can skip the slice/concat round trip."""
+    stacked = None
+
+
+class BaseModel(nn.Module):
+    def load(self, path):
+        parameters = torch.load(path, map_location=torch.device("cpu"))
+        if "optimizer" in parameters:
+            parameters = parameters["model"]
+        self.load_state_dict(parameters)
+
+
+class DPT(BaseModel):
+    def __init__(self, features=256, backbone="vitb_rn50_384", readout="ignore", channels_last=False, use_bn=False,
+                 enable_attention_hooks=False, use_pretrain=True, use_attention=False, seg=False):
+        super().__init__()
+        if backbone not in _BACKBONES:
+            print(f"Backbone '{backbone}' not implemented")
+            assert False
+        if seg:
+            raise NotImplementedError("seg=True (DPT decoder) is outside the ACR hot path (SURVEY 2 #6)")
+        self.channels_last = channels_last
+        self.attention = use_attention
+        vit_kw, scratch_in, (tap3, tap4) = _BACKBONES[backbone]
+        # NB use_pretrain: the reference downloads ImageNet weights here (models/helpers.py:177).  There is
+        # no network in this build: weights are random-initialised and a checkpoint is loaded via `path`.
+        vit = VisionTransformer(**vit_kw)
+        vit.tap3, vit.tap4 = tap3, tap4
+        self.pretrained = nn.Module()
+        self.pretrained.model = vit
+        self.pretrained.activations = {}
+        self.scratch = nn.Module()                     # created, never used in the ACR forward (blocks.py:97-147)
+        for i, cin in enumerate(scratch_in):
+            setattr(self.scratch, "layer%d_rn" % (i + 1), nn.Conv2d(cin, features, 3, 1, 1, bias=False))
+        self.cls_head = nn.Linear(vit.embed_dim, self.num_class)
+        self.use_gap = True
+        self.truncate_at = None                        # GETAM: stop the backward at this block (None = full)
+
+    # -- encoder pass shared by forward_cls / forward_cam --
+    def _encode(self, x):
+        vit = self.pretrained.model
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        b, _, h, w = x.shape
+        T = (h // 16) * (w // 16) + vit.num_tokens
+        stack = ops.MeanStack(b, vit.depth, T, x.device)
+        taps = self.pretrained.activations
+        taps.clear()
+        vit.forward_flex(x, stack=stack, taps=taps, truncate_at=self.truncate_at)
+        return taps["4"], stack
+
+    def _stack_tensor(self, stack):
+        """(B,L,T,T) autograd view of the head-mean buffer the attention kernels filled."""
+        vit = self.pretrained.model
+        pms = [blk.attn.last_pm for blk in vit.blocks]
+        if any(pm is None for pm in pms) or not any(pm.requires_grad for pm in pms):
+            return stack.buf
+        return ops.StackAliasFn.apply(stack, *pms)
+
+    def forward_cls(self, x):
+        layer_4, stack = self._encode(x)
+        nt = self.pretrained.model.num_tokens
+        x_cls = self.cls_head(layer_4[:, 0, :])
+        x_patch_cls = self.cls_head(layer_4[:, nt:, :].mean(dim=1))
+        return x_cls, x_patch_cls, self._stack_tensor(stack), None
+
+    def forward_cam(self, x):
+        layer_4, stack = self._encode(x)
+        nt = self.pretrained.model.num_tokens
+        x_patch = layer_4[:, nt:, :]
+        x_cls = self.cls_head(layer_4[:, 0, :])
+        x_patch_cls = self.cls_head(x_patch.mean(dim=1))
+        if x_patch.requires_grad and torch.is_grad_enabled():
+            x_patch_cam = F.relu(self.cls_head(x_patch))
+        else:                                           # inference read-out: HIP kernel (K5)
+            B, N, D = x_patch.shape
+            xp = x_patch.reshape(B * N, D) if x_patch.is_contiguous() else x_patch.contiguous().reshape(B * N, D)
+            x_patch_cam = ops.patch_cam(xp, self.cls_head.weight.detach(), self.cls_head.bias.detach())
+            x_patch_cam = x_patch_cam.reshape(B, N, -1)
+        return x_cls, x_patch_cls, self._stack_tensor(stack), x_patch_cam
+
+
+class ACR(DPT):
+    def __init__(self, num_classes, backbone_name, path=None, **kwargs):
+        self.num_class = num_classes
+        kwargs["use_bn"] = True
+        backbone_dict = {"vitb_hybrid": "vitb_rn50_384", "vitb": "vitb16_384", "deit": "deitb16_384",
+                         "deit_distilled": "deitb16_distil_384", "vitl": "vitl16_384", "vit_tiny": "vit_tiny16_224"}
+        cur_backbone = backbone_dict[backbone_name]
+        self.cur_backbone = cur_backbone
+        super().__init__(backbone=cur_backbone, **kwargs)
+        if path is not None:
+            self.load(path)
+
+    def forward_mirror(self, x1, x2):
+        """DPT/ACR.py:170-174.  One 2B pass instead of two sequential B passes."""
+        b = x1.shape[0]
+        x_cls, x_p_cls, attn, _ = self.forward_cls(torch.cat([x1, x2], dim=0))
+        pair = AttnPair([attn[:b], attn[b:]])
+        pair.stacked = attn
+        return [x_cls[:b], x_cls[b:], x_p_cls[:b], x_p_cls[b:], None, None], pair
+
+    def getam(self, batch, start_layer=0, func="grad"):
+        """DPT/ACR.py:177-215.  Returns (cls_cam (1,N), attn_list, cam_list) like the reference; cam_list holds
+        the per-layer row-0 vectors (1,T) -- the only part of the reference's (1,T,T) maps that is consumed."""
+        vit = self.pretrained.model
+        rows, attn_list = [], []
+        for i, blk in enumerate(vit.blocks):
+            attn_list.append(blk.attn.last_pm)
+            if i < start_layer:
+                continue
+            saved = blk.attn.saved_for_getam()
+            if saved is None:
+                raise RuntimeError("getam(): block %d has no saved forward/backward (call forward_cam + backward first)" % i)
+            qkv, d_o, lse2, heads = saved
+            row = torch.zeros(qkv.shape[1], dtype=torch.float32, device=qkv.device)
+            ops.getam_row_accum(qkv, d_o, lse2, heads, batch, func, row)
+            rows.append(row.unsqueeze(0))
+        cams = torch.stack(rows).sum(dim=0)
+        skip = 2 if self.cur_backbone == "deitb16_distil_384" else 1
+        return torch.relu(cams[:, skip:]), attn_list, rows

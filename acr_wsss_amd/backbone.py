@@ -182,11 +182,12 @@ class Attention(nn.Module):
         self._saved = None          # (qkv, lse2, heads) of the last forward
         self._saved_do = None       # dO of the last backward
         self._override = {}
+        self.last_pm = None         # (B,T,T) head-mean map of the last forward (slice of the MeanStack)
 
     def forward(self, x, stack=None, layer=0):
         self._override = {}
         qkv = self.qkv(x)                                           # packed (B, T, 3*H*64): no permute copy
-        o, _ = ops.attention_core(qkv, self.num_heads, stack, layer, self)
+        o, self.last_pm = ops.attention_core(qkv, self.num_heads, stack, layer, self)
         return self.proj(o)
 
     # -- reference state API (vision_transformer.py:186-196) --
@@ -301,7 +302,8 @@ class VisionTransformer(nn.Module):
         x = torch.cat(toks + [x], dim=1) + pos
         for i, blk in enumerate(self.blocks):
             if truncate_at is not None and i == truncate_at:
-                x = x.detach()
+                x = x.detach().requires_grad_(True)
+                self.trunc_input = x
             x = blk(x, stack, i)
             if taps is not None:
                 if i == self.tap3:

@@ -1,0 +1,76 @@
+"""Training-step pieces of train_acr.py / train_acr_coco.py on the HIP path.
+
+  acr_loss       <- the inline loss block train_acr.py:140-168 (COCO twin train_acr_coco.py:137-165)
+  PolyOptimizer  <- tool/torchutils.py:10-31 (including its positional-argument quirk)
+  train_step     <- train_acr.py:135-174 (one iteration, minus data loading and logging)
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def acr_loss(cls_list, attn_list, label, p, alpha):
+    """loss = MLSM(x1,y) + MLSM(x2,y) + alpha*cls_align + alpha*aff_align   (train_acr.py:160-168).
+
+    ``attn_list`` is what ``ACR.forward_mirror`` returned (``[attn1, attn2]``; the fused two-view stack is
+    taken from its ``.stacked`` attribute when present) or the (2B,L,T,T) stack itself.  The reference's
+    3*p in-place block flips + two F.l1_loss are one HIP kernel each way (include/acr_hip.h
+    acr_consistency_fwd/bwd); the view-2 maps are NOT mutated.  Returns (loss, dict of the four terms)."""
+    stacked = getattr(attn_list, "stacked", None)
+    if stacked is None and torch.is_tensor(attn_list):
+        stacked = attn_list
+    if stacked is not None:
+        cls_align, aff_align = ops.consistency(stacked, p)
+    else:
+        cls_align, aff_align = ops.consistency(attn_list[0], p, attn_list[1])
+    x1, x2 = cls_list[0], cls_list[1]
+    cls_loss_1 = F.multilabel_soft_margin_loss(x1.float(), label)
+    cls_loss_2 = F.multilabel_soft_margin_loss(x2.float(), label)
+    loss = cls_loss_1 + cls_loss_2 + cls_align * alpha + aff_align * alpha
+    return loss, dict(cls_loss_1=cls_loss_1, cls_loss_2=cls_loss_2, cls_align=cls_align, aff_align=aff_align, loss=loss)
+
+
+class PolyOptimizer(torch.optim.SGD):
+    """SGD with lr = lr0 * (1 - step/max_step)^0.9  (tool/torchutils.py:10-31).
+
+    Quirk kept on purpose: the reference calls ``SGD.__init__(params, lr, weight_decay)``, so its
+    ``weight_decay`` argument lands in SGD's *momentum* slot -- effective momentum = wt_dec (5e-4), effective
+    weight decay = 0; ``momentum=0.9`` is only the exponent of the poly schedule."""
+
+    def __init__(self, params, lr, weight_decay, max_step, momentum=0.9, **sgd_kwargs):
+        super().__init__(params, lr, weight_decay, **sgd_kwargs)
+        self.global_step = 0
+        self.max_step = max_step
+        self.momentum = momentum
+        self._initial_lr = [group["lr"] for group in self.param_groups]
+        self.lr_scale = 1
+
+    def step(self, closure=None):
+        if self.global_step < self.max_step:
+            lr_mult = (1 - self.global_step / self.max_step) ** self.momentum
+            for i in range(len(self.param_groups)):
+                self.param_groups[i]["lr"] = self._initial_lr[i] * lr_mult * self.lr_scale
+        super().step(closure)
+        self.global_step += 1
+
+
+def train_step(model, optimizer, img, label, alpha, grad_sync=None, amp_dtype=None):
+    """One iteration of train_acr.py:127-174: view 2 = h-flip, forward_mirror, ACR loss, backward, SGD step.
+
+    ``grad_sync`` (acr_wsss_amd.dp.GradSync) all-reduces gradients over RCCL while backward is still running;
+    the reference wraps the model in DDP but calls ``model.module.forward_mirror`` so its reducer never fires
+     -- this implements the intended data-parallel semantics.  Returns (loss tensor, terms)."""
+    p = img.shape[2] // 16
+    img2 = img.flip(-1)                                   # RandomHorizontalFlip(p=1), train_acr.py:135
+    optimizer.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+        cls_list, attn_list = model.forward_mirror(img, img2)
+    loss, terms = acr_loss(cls_list, attn_list, label, p, alpha)
+    if grad_sync is not None:
+        grad_sync.prepare()
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync.finish()
+    optimizer.step()
+    return loss, terms

@@ -1,0 +1,165 @@
+"""CPU-side checks (no GPU): the C ABI library loads and exports every symbol include/acr_hip.h declares, the
+product's module tree reproduces the reference state-dict layout, host logic (PolyOptimizer, sharding, seeds)
+matches the oracle, the product refuses to run without a GPU, and the data-parallel gradient exchange is
+correct on a 2-rank gloo group."""
+import json
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT, load_golden
+from oracle import acr_oracle as O
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from acr_wsss_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "acr_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(acr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(built.SIGNATURES.keys()), declared ^ set(built.SIGNATURES.keys())
+    lib = built.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.acr_version() == 1
+    assert lib.acr_consistency_ws_floats(16, 12, 785) > 0          # host-only helper, no GPU touched
+
+
+def test_state_dict_layout_matches_reference():
+    from acr_wsss_amd.DPT.ACR import ACR
+    for backbone, fn in (("vitb_hybrid", "state_dict_layout.json"), ("vit_tiny", "state_dict_layout_tiny.json")):
+        with open(os.path.join(GOLDEN, fn)) as f:
+            layout = json.load(f)
+        model = ACR(num_classes=20, backbone_name=backbone, use_pretrain=False)
+        sd = model.state_dict()
+        if backbone == "vit_tiny":                        # the assembled tiny oracle has no scratch convs
+            sd = {k: v for k, v in sd.items() if not k.startswith("scratch.")}
+        assert list(sd.keys()) == list(layout.keys())
+        for k, v in sd.items():
+            assert list(v.shape) == layout[k], k
+
+
+def test_no_cpu_fallback(built):
+    from acr_wsss_amd import ops
+    from acr_wsss_amd.DPT.ACR import ACR
+    with pytest.raises(built.AcrHipError):
+        ops.consistency(torch.rand(2, 1, 5, 5), 2)
+    model = ACR(num_classes=20, backbone_name="vit_tiny", use_pretrain=False)
+    with pytest.raises(built.AcrHipError):
+        model.forward_cls(torch.randn(1, 3, 32, 32))
+
+
+def test_poly_optimizer_quirk_matches_oracle_and_golden():
+    from acr_wsss_amd.train import PolyOptimizer
+    fx = load_golden("train_hybrid_64_b2")
+    w0 = torch.randn(7, 5)
+    p = torch.nn.Parameter(w0.clone())
+    opt = PolyOptimizer([p], lr=0.05, weight_decay=5e-4, max_step=100)
+    assert opt.param_groups[0]["momentum"] == 5e-4 and opt.param_groups[0]["weight_decay"] == 0
+    ref, bufs = [w0.clone()], [None]
+    g = torch.Generator().manual_seed(0)
+    for step in range(3):
+        grad = torch.randn(7, 5, generator=g)
+        p.grad = grad.clone()
+        opt.step()
+        lr = O.poly_sgd_step([torch.nn.Parameter(ref[0])], [grad], bufs, step, 100, 0.05, 5e-4)
+        ref[0] = ref[0]
+        assert abs(opt.param_groups[0]["lr"] - lr) < 1e-12
+        torch.testing.assert_close(p.detach(), ref[0], rtol=1e-6, atol=1e-7)
+    # golden: cls_head.bias after one reference step from the recipe weights
+    from recipe import recipe_tensor
+    b0 = recipe_tensor("cls_head.bias", (20,))
+    q = torch.nn.Parameter(b0.clone())
+    q.grad = torch.from_numpy(fx["grad:cls_head.bias"])
+    o2 = PolyOptimizer([q], lr=0.05, weight_decay=5e-4, max_step=100)
+    o2.step()
+    np.testing.assert_allclose(q.detach().numpy(), fx["after_step:cls_head.bias"], rtol=1e-6, atol=1e-7)
+
+
+def test_seed_argmax_matches_oracle():
+    from acr_wsss_amd.infer_cam import seeds_from_cam_dict
+    rng = np.random.default_rng(1)
+    cam = {3: rng.random((9, 7)).astype(np.float32), 11: rng.random((9, 7)).astype(np.float32)}
+    for t in (0.0, 0.2, 0.4, 0.99):
+        np.testing.assert_array_equal(seeds_from_cam_dict(cam, t), O.seeds_from_cam_dict(cam, t))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from acr_wsss_amd.dp import GradSync, broadcast_parameters
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # different init per rank: broadcast must fix it
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 3))
+    unused = torch.nn.Parameter(torch.ones(5))           # like the reference's 9 never-used tensors
+    net.register_parameter("unused", unused)
+    broadcast_parameters(net, 0)
+    sync = GradSync(net.parameters(), bucket_mb=0.0003)  # tiny buckets -> several collectives
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    xs, ys = x[rank::world], y[rank::world]              # shard the global batch by rank
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        loss = ((net(xs) - ys) ** 2).mean()
+        sync.prepare()
+        loss.backward()
+        sync.finish()
+        opt.step()
+    out[rank] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    if rank == 0:
+        out["nbuckets"] = len(sync.buckets)
+    dist.destroy_process_group()
+
+
+def test_grad_sync_two_ranks_gloo():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out["nbuckets"] >= 3
+    torch.testing.assert_close(out[0], out[1], rtol=0, atol=0)          # replicas stay identical
+    # single-process reference on the full batch with rank 0's initial weights
+    torch.manual_seed(100)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 3))
+    net.register_parameter("unused", torch.nn.Parameter(torch.ones(5)))
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        # mean over ranks of per-rank means == global mean (equal shard sizes)
+        ((net(x) - y) ** 2).mean().backward()
+        opt.step()
+    ref = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    torch.testing.assert_close(out[0], ref, rtol=1e-5, atol=1e-6)
+
+
+def test_infer_list_sharding():
+    """rank r takes items r::world; the union over ranks is the list, no overlaps."""
+    n, world = 11, 4
+    seen = []
+    for r in range(world):
+        seen += list(range(r, n, world))
+    assert sorted(seen) == list(range(n))
