@@ -12,7 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libacr_hip.so")
 
-ACR_F32, ACR_BF16 = 0, 1
+ACR_F32, ACR_BF16, ACR_BF16_F32MATH = 0, 1, 2
+BF16_F32MATH = False      # True: bf16 tensors take the exact-fp32 MFMA kernels (reference for the bf16-MFMA ones)
 GETAM_FUNCS = {"grad": 0, "cam_grad": 1, "grad_s": 2, "cam_grad_s": 3}
 
 c_void_p, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
@@ -94,7 +95,7 @@ def dtype_code(dt):
     if dt == torch.float32:
         return ACR_F32
     if dt == torch.bfloat16:
-        return ACR_BF16
+        return ACR_BF16_F32MATH if BF16_F32MATH else ACR_BF16
     raise AcrHipError("unsupported dtype %s (fp32 and bf16 are built)" % dt)
 
 

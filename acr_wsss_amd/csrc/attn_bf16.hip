@@ -1,0 +1,532 @@
+// Attention kernels on the gfx950 bf16 MFMA (v_mfma_f32_32x32x16_bf16): the training-throughput precision.
+//
+// Same kernel set and the same fragment algebra as attn_f32.hip (read its header first); what changes:
+//   * operands are 8 x bf16 per lane (k = 8*(l>>5) + j), fp32 accumulate; 4 MFMAs per 32x32x64 product
+//     instead of 32, so VALU (softmax) and LDS traffic matter and tiles are 64 keys / 64 queries per step;
+//   * rowop reads its LDS operand with ds_read_b128 (row pitch 144 B: 16 consecutive rows hit 16 distinct
+//     16-byte slots -> conflict-free for every ds_read_b128 lane group);
+//   * accop ("accumulator tile is the next MFMA's operand"): P / dS leave the accumulator as bf16x8 fragments
+//     whose k-slot j of lane-half h is row 16s + 8(j>>2) + 4h + (j&3) of the tile, so the other operand
+//     (V, K, Q or dO rows -- contraction index = row, i.e. k-strided in memory) is fetched with the hardware
+//     transpose read ds_read_b64_tr_b16 from the SAME row-major LDS image (2-way conflict at pitch 144 B:
+//     measured irrelevant next to the softmax VALU work);
+//   * the softmax scale rides in the exp2 argument: p = exp2(fma(s, scale*log2e, -m)) -- q is not re-rounded;
+//   * P and dS are rounded to bf16 for the second-stage products (standard flash-attention numerics), row
+//     sums / log-sum-exp / delta / the head-mean output stay fp32.
+// The fp32-accumulated head-mean map (B,T,T) and lse2 have the same meaning as on the fp32 path.
+#include "acr_common.h"
+
+typedef __bf16 bf16_t;
+#define BP 72                       // LDS row pitch in bf16 elements (144 B)
+#define GP 68                       // LDS row pitch of the staged fp32 G tile (floats)
+
+struct AttnGeomB {
+    int B, H, T;
+    float scale;
+    int64_t sb, st, sh;
+    int64_t osb, ost, osh;
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int ROWS, int NTHREADS>
+__device__ __forceinline__ void stage_tile_bf(bf16_t* lds, const bf16_t* g, int64_t st, int row0, int Tn, int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS * 8 / NTHREADS; ++i) {
+        const int slot = tid + i * NTHREADS;
+        const int row = slot >> 3, c8 = slot & 7;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row0 + row < Tn) v = *reinterpret_cast<const bf16x8*>(g + (int64_t)(row0 + row) * st + c8 * 8);
+        *reinterpret_cast<bf16x8*>(lds + row * BP + c8 * 8) = v;
+    }
+}
+
+// lane (r, h) owns row (row0 + r), k-slots 16s + 8h + j  (s = 0..3, j = 0..7)
+__device__ __forceinline__ void load_rows_bf(bf16x8 (&reg)[4], const bf16_t* g, int64_t st, int row0, int Tn, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const bool ok = row0 + r < Tn;
+    const bf16_t* p = g + (int64_t)(row0 + r) * st + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) v = *reinterpret_cast<const bf16x8*>(p + 16 * s);
+        reg[s] = v;
+    }
+}
+__device__ __forceinline__ void load_rows_lds_bf(bf16x8 (&reg)[4], const bf16_t* tile, int lane) {
+    const bf16_t* p = tile + (lane & 31) * BP + 8 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) reg[s] = *reinterpret_cast<const bf16x8*>(p + 16 * s);
+}
+
+// acc[reg] += sum_d tile[krow(reg,h)][d] * Y[l&31][d]
+__device__ __forceinline__ void mma_rowop_bf(f32x16& acc, const bf16_t* tile, const bf16x8 (&y)[4], int lane) {
+    const bf16_t* ap = tile + (lane & 31) * BP + 8 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 16 * s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, y[s], acc, 0, 0, 0);
+    }
+}
+
+// Fragment of X^T for k-step s of a 32-row tile: element j = X[16s + 8(j>>2) + 4h + (j&3)][32*blk + (l&31)]
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int s, int blk, int lane) {
+    const int i = lane & 15, h = lane >> 5;
+    const bf16_t* a0 = tile + (16 * s + 4 * h + (i >> 2)) * BP + 32 * blk + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+    typedef __attribute__((address_space(3))) bf16x4* lds_p;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + 8 * BP));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+template <int S>
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& z) {
+    bf16x8 r = {(bf16_t)z[8 * S + 0], (bf16_t)z[8 * S + 1], (bf16_t)z[8 * S + 2], (bf16_t)z[8 * S + 3],
+                (bf16_t)z[8 * S + 4], (bf16_t)z[8 * S + 5], (bf16_t)z[8 * S + 6], (bf16_t)z[8 * S + 7]};
+    return r;
+}
+// z (lane index = output row) x tile (rows = contraction, cols 32*blk.. = output column)
+__device__ __forceinline__ void mma_accop_a_bf(f32x16& acc, const f32x16& z, const bf16_t* tile, int blk, int lane) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag<0>(z), tr_frag(tile, 0, blk, lane), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag<1>(z), tr_frag(tile, 1, blk, lane), acc, 0, 0, 0);
+}
+// tile columns 32*blk.. = output row, z (lane index = output column)
+__device__ __forceinline__ void mma_accop_b_bf(f32x16& acc, const f32x16& z, const bf16_t* tile, int blk, int lane) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tile, 0, blk, lane), acc_frag<0>(z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tile, 1, blk, lane), acc_frag<1>(z), acc, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: 2 waves x 32 query rows, 64 keys per step
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void attn_fwd_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
+                                                            const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                            bf16_t* __restrict__ o, float* __restrict__ lse2) {
+    __shared__ __attribute__((aligned(16))) bf16_t kt[64 * BP];
+    __shared__ __attribute__((aligned(16))) bf16_t vt[64 * BP];
+    const int nqt = (g.T + 63) >> 6;
+    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = id % nqt; id /= nqt;
+    const int h = id % g.H;
+    const int b = id / g.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int q0 = qt * 64 + wave * 32;
+    const int64_t base = (int64_t)b * g.sb + (int64_t)h * g.sh;
+    const float c = g.scale * ACR_LOG2E;
+    bf16x8 qreg[4];
+    load_rows_bf(qreg, q + base, g.st, q0, g.T, lane);
+    float m = -INFINITY, l = 0.f;
+    f32x16 o0 = {0}, o1 = {0};
+    for (int k0 = 0; k0 < g.T; k0 += 64) {
+        __syncthreads();
+        stage_tile_bf<64, 128>(kt, k + base, g.st, k0, g.T, tid);
+        stage_tile_bf<64, 128>(vt, v + base, g.st, k0, g.T, tid);
+        __syncthreads();
+        f32x16 s0 = {0}, s1 = {0};
+        mma_rowop_bf(s0, kt, qreg, lane);                  // s[reg] = q.k (raw) [key = k0 + 32*kb + krow][query = r]
+        mma_rowop_bf(s1, kt + 32 * BP, qreg, lane);
+        if (k0 + 64 > g.T) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                if (k0 + acr_krow(reg, hh) >= g.T) s0[reg] = -INFINITY;
+                if (k0 + 32 + acr_krow(reg, hh) >= g.T) s1[reg] = -INFINITY;
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) mx = fmaxf(mx, fmaxf(s0[reg], s1[reg]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx * c);
+        const float alpha = fast_exp2(m - mn);
+        float rs = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            s0[reg] = fast_exp2(fmaf(s0[reg], c, -mn));
+            s1[reg] = fast_exp2(fmaf(s1[reg], c, -mn));
+            rs += s0[reg] + s1[reg];
+        }
+        rs += __shfl_xor(rs, 32);
+        l = l * alpha + rs;
+        m = mn;
+        o0 *= alpha; o1 *= alpha;
+        mma_accop_b_bf(o0, s0, vt, 0, lane);               // o[reg] = O^T[d = 32*blk + krow][query = r]
+        mma_accop_b_bf(o1, s0, vt, 1, lane);
+        mma_accop_b_bf(o0, s1, vt + 32 * BP, 0, lane);
+        mma_accop_b_bf(o1, s1, vt + 32 * BP, 1, lane);
+    }
+    if (q0 + r < g.T) {
+        const float inv = 1.f / l;
+        bf16_t* ob = o + (int64_t)b * g.osb + (int64_t)(q0 + r) * g.ost + (int64_t)h * g.osh;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            f32x4 a = {o0[4 * grp] * inv, o0[4 * grp + 1] * inv, o0[4 * grp + 2] * inv, o0[4 * grp + 3] * inv};
+            f32x4 cc = {o1[4 * grp] * inv, o1[4 * grp + 1] * inv, o1[4 * grp + 2] * inv, o1[4 * grp + 3] * inv};
+            acr_store4<bf16_t>(ob + 8 * grp + 4 * hh, a);
+            acr_store4<bf16_t>(ob + 32 + 8 * grp + 4 * hh, cc);
+        }
+        if (hh == 0) lse2[((int64_t)b * g.H + h) * g.T + q0 + r] = m + log2f(l);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 64x64 tiles of P / dO V^T (PMEAN over heads, PROBS / DPROBS per head); 4 waves as 2 x 2
+// ---------------------------------------------------------------------------------------------
+enum { TQKB_PMEAN = 0, TQKB_PROBS = 1, TQKB_DPROBS = 2 };
+
+template <int MODE>
+__global__ __launch_bounds__(256) void attn_tile_qk_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ xq,
+                                                                const bf16_t* __restrict__ xk,
+                                                                const float* __restrict__ lse2,
+                                                                float* __restrict__ out, int64_t out_sb) {
+    __shared__ __attribute__((aligned(16))) bf16_t qs[64 * BP];
+    __shared__ __attribute__((aligned(16))) bf16_t ks[64 * BP];
+    const int nt = (g.T + 63) >> 6;
+    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int kti = id % nt; id /= nt;
+    const int qti = id % nt; id /= nt;
+    int b, hsel;
+    if (MODE == TQKB_PMEAN) { b = id; hsel = 0; } else { hsel = id % g.H; b = id / g.H; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wq = wave >> 1, wk = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int q0 = qti * 64, k0 = kti * 64;
+    const bool is_q = (MODE != TQKB_DPROBS);
+    const float c = g.scale * ACR_LOG2E;
+    f32x16 acc = {0};
+    const int h_lo = (MODE == TQKB_PMEAN) ? 0 : hsel, h_hi = (MODE == TQKB_PMEAN) ? g.H : hsel + 1;
+    for (int h = h_lo; h < h_hi; ++h) {
+        const bf16_t* qb = is_q ? xq + (int64_t)b * g.sb + (int64_t)h * g.sh : xq + (int64_t)b * g.osb + (int64_t)h * g.osh;
+        const int64_t qst = is_q ? g.st : g.ost;
+        const bf16_t* kb = xk + (int64_t)b * g.sb + (int64_t)h * g.sh;
+        __syncthreads();
+        stage_tile_bf<64, 256>(qs, qb, qst, q0, g.T, tid);
+        stage_tile_bf<64, 256>(ks, kb, g.st, k0, g.T, tid);
+        __syncthreads();
+        bf16x8 kreg[4];
+        load_rows_lds_bf(kreg, ks + wk * 32 * BP, lane);
+        f32x16 s = {0};
+        mma_rowop_bf(s, qs + wq * 32 * BP, kreg, lane);    // s[reg] = X[query = krow][key = r]
+        if (MODE == TQKB_DPROBS) {
+            acc = s;
+        } else {
+            const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int qq = q0 + wq * 32 + acr_krow(reg, hh);
+                const float lv = (qq < g.T) ? lrow[qq] : 0.f;
+                acc[reg] += fast_exp2(fmaf(s[reg], c, -lv));
+            }
+        }
+    }
+    const int key = k0 + wk * 32 + r;
+    if (key < g.T) {
+        float* ob = (MODE == TQKB_PMEAN) ? out + (int64_t)b * out_sb : out + ((int64_t)b * g.H + hsel) * (int64_t)g.T * g.T;
+        const float mul = (MODE == TQKB_PMEAN) ? 1.f / (float)g.H : 1.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int qq = q0 + wq * 32 + acr_krow(reg, hh);
+            if (qq < g.T) ob[(int64_t)qq * g.T + key] = acc[reg] * mul;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// delta[b,h,i] = rowsum(dO*O) + (1/H) sum_j P_h[i,j] G[b,i,j]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void attn_delta_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
+                                                              const bf16_t* __restrict__ k, const bf16_t* __restrict__ o,
+                                                              const bf16_t* __restrict__ d_o,
+                                                              const float* __restrict__ lse2,
+                                                              const float* __restrict__ gm, int64_t gm_sb,
+                                                              float* __restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) bf16_t qs[64 * BP];
+    __shared__ float dsh[64];
+    const int nqt = (g.T + 63) >> 6;
+    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = id % nqt; id /= nqt;
+    const int h = id % g.H;
+    const int b = id / g.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int q0 = qt * 64 + wave * 32;
+    const int64_t base = (int64_t)b * g.sb + (int64_t)h * g.sh;
+    const int64_t obase = (int64_t)b * g.osb + (int64_t)h * g.osh;
+    const float c = g.scale * ACR_LOG2E;
+    float part = 0.f;
+    if (q0 + r < g.T) {
+        const bf16_t* op = o + obase + (int64_t)(q0 + r) * g.ost + 32 * hh;
+        const bf16_t* dp = d_o + obase + (int64_t)(q0 + r) * g.ost + 32 * hh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(op + 8 * i);
+            const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(dp + 8 * i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part = fmaf((float)a[e], (float)d8[e], part);
+        }
+    }
+    part += __shfl_xor(part, 32);
+    if (hh == 0) dsh[wave * 32 + r] = part;
+    float rho[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) rho[reg] = 0.f;
+    if (gm != nullptr) {
+        stage_tile_bf<64, 128>(qs, q + base, g.st, qt * 64, g.T, tid);
+        float l2r[16];
+        const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int qq = q0 + acr_krow(reg, hh);
+            l2r[reg] = (qq < g.T) ? lrow[qq] : 0.f;
+        }
+        __syncthreads();
+        const float* grow = gm + (int64_t)b * gm_sb;
+        for (int k0 = 0; k0 < g.T; k0 += 32) {
+            bf16x8 kreg[4];
+            load_rows_bf(kreg, k + base, g.st, k0, g.T, lane);
+            f32x16 s = {0};
+            mma_rowop_bf(s, qs + wave * 32 * BP, kreg, lane);   // S raw [query = krow][key = k0 + r]
+            const int key = k0 + r;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int qq = q0 + acr_krow(reg, hh);
+                if (qq < g.T && key < g.T)
+                    rho[reg] = fmaf(fast_exp2(fmaf(s[reg], c, -l2r[reg])), grow[(int64_t)qq * g.T + key], rho[reg]);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) rho[reg] += __shfl_xor(rho[reg], off);
+        }
+    }
+    __syncthreads();
+    if (r == 0) {
+        const float invH = 1.f / (float)g.H;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int kr = acr_krow(reg, hh);
+            if (q0 + kr < g.T) delta[((int64_t)b * g.H + h) * g.T + q0 + kr] = dsh[wave * 32 + kr] + rho[reg] * invH;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dQ: 2 waves x 32 query rows, 64 keys per step; the fp32 G tile is staged through LDS (coalesced rows in,
+// per-lane 4-key groups out)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void attn_dq_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
+                                                           const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                           const bf16_t* __restrict__ d_o,
+                                                           const float* __restrict__ lse2,
+                                                           const float* __restrict__ delta,
+                                                           const float* __restrict__ gm, int64_t gm_sb,
+                                                           bf16_t* __restrict__ dq) {
+    __shared__ __attribute__((aligned(16))) bf16_t kt[64 * BP];
+    __shared__ __attribute__((aligned(16))) bf16_t vt[64 * BP];
+    __shared__ __attribute__((aligned(16))) float gt[2 * 32 * GP];
+    const int nqt = (g.T + 63) >> 6;
+    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = id % nqt; id /= nqt;
+    const int h = id % g.H;
+    const int b = id / g.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int q0 = qt * 64 + wave * 32;
+    const int64_t base = (int64_t)b * g.sb + (int64_t)h * g.sh;
+    const int64_t obase = (int64_t)b * g.osb + (int64_t)h * g.osh;
+    const float c = g.scale * ACR_LOG2E;
+    bf16x8 qreg[4], doreg[4];
+    load_rows_bf(qreg, q + base, g.st, q0, g.T, lane);
+    load_rows_bf(doreg, d_o + obase, g.ost, q0, g.T, lane);
+    const bool qok = q0 + r < g.T;
+    const float l2 = qok ? lse2[((int64_t)b * g.H + h) * g.T + q0 + r] : 0.f;
+    const float dl = qok ? delta[((int64_t)b * g.H + h) * g.T + q0 + r] : 0.f;
+    const float invH = 1.f / (float)g.H;
+    const float* gb = gm ? gm + (int64_t)b * gm_sb : nullptr;
+    float* gw = gt + wave * 32 * GP;
+    f32x16 dq0 = {0}, dq1 = {0};
+    for (int k0 = 0; k0 < g.T; k0 += 64) {
+        __syncthreads();
+        stage_tile_bf<64, 128>(kt, k + base, g.st, k0, g.T, tid);
+        stage_tile_bf<64, 128>(vt, v + base, g.st, k0, g.T, tid);
+        if (gb) {
+            const int key = k0 + lane;
+#pragma unroll 8
+            for (int rr = 0; rr < 32; ++rr) {
+                const int qq = q0 + rr;
+                gw[rr * GP + lane] = (qq < g.T && key < g.T) ? gb[(int64_t)qq * g.T + key] * invH : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s = {0}, dp = {0};
+            mma_rowop_bf(s, kt + kb * 32 * BP, qreg, lane);     // S^T raw [key = krow][query = r]
+            mma_rowop_bf(dp, vt + kb * 32 * BP, doreg, lane);   // dP^T
+            f32x16 ds;
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+                if (gb) gv = *reinterpret_cast<const f32x4*>(gw + r * GP + 32 * kb + 8 * grp + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int reg = 4 * grp + e;
+                    const int key = k0 + 32 * kb + acr_krow(reg, hh);
+                    const float p = (qok && key < g.T) ? fast_exp2(fmaf(s[reg], c, -l2)) : 0.f;
+                    ds[reg] = p * (dp[reg] + gv[e] - dl);
+                }
+            }
+            mma_accop_a_bf(dq0, ds, kt + kb * 32 * BP, 0, lane);   // dQ[query = krow][d = 32*blk + r]
+            mma_accop_a_bf(dq1, ds, kt + kb * 32 * BP, 1, lane);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int qq = q0 + acr_krow(reg, hh);
+        if (qq < g.T) {
+            bf16_t* p = dq + base + (int64_t)qq * g.st;
+            p[r] = (bf16_t)(dq0[reg] * g.scale);
+            p[32 + r] = (bf16_t)(dq1[reg] * g.scale);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dK, dV: 2 waves x 32 keys (K, V fragments in registers), 64 queries per step
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void attn_dkdv_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
+                                                             const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                             const bf16_t* __restrict__ d_o,
+                                                             const float* __restrict__ lse2,
+                                                             const float* __restrict__ delta,
+                                                             const float* __restrict__ gm, int64_t gm_sb,
+                                                             bf16_t* __restrict__ dk, bf16_t* __restrict__ dv) {
+    __shared__ __attribute__((aligned(16))) bf16_t qtile[64 * BP];
+    __shared__ __attribute__((aligned(16))) bf16_t dotile[64 * BP];
+    __shared__ float l2s[64], dls[64];
+    const int nkt = (g.T + 63) >> 6;
+    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int ktile = id % nkt; id /= nkt;
+    const int h = id % g.H;
+    const int b = id / g.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int key0 = ktile * 64 + wave * 32;
+    const int64_t base = (int64_t)b * g.sb + (int64_t)h * g.sh;
+    const int64_t obase = (int64_t)b * g.osb + (int64_t)h * g.osh;
+    const float c = g.scale * ACR_LOG2E;
+    bf16x8 kreg[4], vreg[4];
+    load_rows_bf(kreg, k + base, g.st, key0, g.T, lane);
+    load_rows_bf(vreg, v + base, g.st, key0, g.T, lane);
+    const int key = key0 + r;
+    const bool kok = key < g.T;
+    const float invH = 1.f / (float)g.H;
+    const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
+    const float* drow = delta + ((int64_t)b * g.H + h) * g.T;
+    const float* gbase = gm ? gm + (int64_t)b * gm_sb : nullptr;
+    f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+    for (int q0 = 0; q0 < g.T; q0 += 64) {
+        __syncthreads();
+        stage_tile_bf<64, 128>(qtile, q + base, g.st, q0, g.T, tid);
+        stage_tile_bf<64, 128>(dotile, d_o + obase, g.ost, q0, g.T, tid);
+        if (tid < 64) {
+            const bool ok = q0 + tid < g.T;
+            l2s[tid] = ok ? lrow[q0 + tid] : 0.f;
+            dls[tid] = ok ? drow[q0 + tid] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 s = {0}, dp = {0};
+            mma_rowop_bf(s, qtile + qb * 32 * BP, kreg, lane);      // S raw [query = krow][key = r]
+            mma_rowop_bf(dp, dotile + qb * 32 * BP, vreg, lane);    // dP
+            f32x16 p, ds;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int kr = 32 * qb + acr_krow(reg, hh);
+                const int qq = q0 + kr;
+                const bool ok = kok && qq < g.T;
+                const float pv = ok ? fast_exp2(fmaf(s[reg], c, -l2s[kr])) : 0.f;
+                const float gv = (ok && gbase) ? gbase[(int64_t)qq * g.T + key] * invH : 0.f;
+                p[reg] = pv;
+                ds[reg] = pv * (dp[reg] + gv - dls[kr]);
+            }
+            mma_accop_a_bf(dv0, p, dotile + qb * 32 * BP, 0, lane);  // dV[key = krow][d = 32*blk + r]
+            mma_accop_a_bf(dv1, p, dotile + qb * 32 * BP, 1, lane);
+            mma_accop_a_bf(dk0, ds, qtile + qb * 32 * BP, 0, lane);
+            mma_accop_a_bf(dk1, ds, qtile + qb * 32 * BP, 1, lane);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int kk = key0 + acr_krow(reg, hh);
+        if (kk < g.T) {
+            bf16_t* pk = dk + base + (int64_t)kk * g.st;
+            bf16_t* pv = dv + base + (int64_t)kk * g.st;
+            pk[r] = (bf16_t)(dk0[reg] * g.scale);
+            pk[32 + r] = (bf16_t)(dk1[reg] * g.scale);
+            pv[r] = (bf16_t)dv0[reg];
+            pv[32 + r] = (bf16_t)dv1[reg];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers (called from the dtype dispatch in attn_f32.hip)
+// ---------------------------------------------------------------------------------------------
+static AttnGeomB geom_b(const acr_attn_desc* d) {
+    AttnGeomB g;
+    g.B = d->B; g.H = d->H; g.T = d->T; g.scale = d->scale;
+    g.sb = d->qkv_sb; g.st = d->qkv_st; g.sh = d->qkv_sh;
+    g.osb = d->o_sb; g.ost = d->o_st; g.osh = d->o_sh;
+    return g;
+}
+
+bool acr_bf16_mfma_ok(const acr_attn_desc* d, const void* const* ptrs, int n) {
+    if ((d->qkv_sb | d->qkv_st | d->qkv_sh | d->o_sb | d->o_st | d->o_sh) & 7) return false;
+    for (int i = 0; i < n; ++i)
+        if (reinterpret_cast<uintptr_t>(ptrs[i]) & 15) return false;
+    return true;
+}
+
+void acr_attn_fwd_bf16(const acr_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse2,
+                       float* pmean, int64_t pmean_sb, hipStream_t st) {
+    AttnGeomB g = geom_b(d);
+    const int nqt = (d->T + 63) / 64;
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(d->B * d->H * nqt), dim3(128), 0, st, g, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2);
+    if (pmean)
+        hipLaunchKernelGGL((attn_tile_qk_bf16_kernel<TQKB_PMEAN>), dim3(d->B * nqt * nqt), dim3(256), 0, st, g,
+                           (const bf16_t*)q, (const bf16_t*)k, (const float*)lse2, pmean, pmean_sb);
+}
+
+void acr_attn_bwd_bf16(const acr_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
+                       const void* d_o, const float* lse2, const float* gm, int64_t gm_sb, void* dq, void* dk, void* dv,
+                       float* delta, hipStream_t st) {
+    AttnGeomB g = geom_b(d);
+    const int nqt = (d->T + 63) / 64;
+    const dim3 grid(d->B * d->H * nqt);
+    hipLaunchKernelGGL(attn_delta_bf16_kernel, grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)o, (const bf16_t*)d_o, lse2, gm, gm_sb, delta);
+    hipLaunchKernelGGL(attn_dkdv_bf16_kernel, grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, (const float*)delta, gm, gm_sb, (bf16_t*)dk,
+                       (bf16_t*)dv);
+    hipLaunchKernelGGL(attn_dq_bf16_kernel, grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, (const float*)delta, gm, gm_sb, (bf16_t*)dq);
+}
+
+void acr_attn_probs_bf16(const acr_attn_desc* d, const void* q, const void* k, const float* lse2, float* probs,
+                         hipStream_t st) {
+    AttnGeomB g = geom_b(d);
+    const int nt = (d->T + 63) / 64;
+    hipLaunchKernelGGL((attn_tile_qk_bf16_kernel<TQKB_PROBS>), dim3(d->B * d->H * nt * nt), dim3(256), 0, st, g,
+                       (const bf16_t*)q, (const bf16_t*)k, lse2, probs, (int64_t)0);
+}
+
+void acr_attn_dprobs_bf16(const acr_attn_desc* d, const void* d_o, const void* v, float* dprobs, hipStream_t st) {
+    AttnGeomB g = geom_b(d);
+    const int nt = (d->T + 63) / 64;
+    hipLaunchKernelGGL((attn_tile_qk_bf16_kernel<TQKB_DPROBS>), dim3(d->B * d->H * nt * nt), dim3(256), 0, st, g,
+                       (const bf16_t*)d_o, (const bf16_t*)v, (const float*)nullptr, dprobs, (int64_t)0);
+}

@@ -497,11 +497,22 @@ __global__ __launch_bounds__(64) void getam_row_kernel(AttnGeom g, const T* __re
 // ---------------------------------------------------------------------------------------------
 // host entry points
 // ---------------------------------------------------------------------------------------------
+// bf16-MFMA launchers (attn_bf16.hip)
+bool acr_bf16_mfma_ok(const acr_attn_desc* d, const void* const* ptrs, int n);
+void acr_attn_fwd_bf16(const acr_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse2,
+                       float* pmean, int64_t pmean_sb, hipStream_t st);
+void acr_attn_bwd_bf16(const acr_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
+                       const void* d_o, const float* lse2, const float* gm, int64_t gm_sb, void* dq, void* dk, void* dv,
+                       float* delta, hipStream_t st);
+void acr_attn_probs_bf16(const acr_attn_desc* d, const void* q, const void* k, const float* lse2, float* probs,
+                         hipStream_t st);
+void acr_attn_dprobs_bf16(const acr_attn_desc* d, const void* d_o, const void* v, float* dprobs, hipStream_t st);
+
 static int check_desc(const acr_attn_desc* d, const char* who) {
     ACR_CHECK_ARG(d != nullptr, "%s: null desc", who);
     ACR_CHECK_ARG(d->B > 0 && d->H > 0 && d->T > 0, "%s: bad geometry B=%d H=%d T=%d", who, d->B, d->H, d->T);
     ACR_CHECK_ARG(d->head_dim == 64, "%s: head_dim %d unsupported (library is built for 64)", who, d->head_dim);
-    ACR_CHECK_ARG(d->dtype == ACR_F32 || d->dtype == ACR_BF16, "%s: unknown dtype %d", who, d->dtype);
+    ACR_CHECK_ARG(d->dtype == ACR_F32 || d->dtype == ACR_BF16 || d->dtype == ACR_BF16_F32MATH, "%s: unknown dtype %d", who, d->dtype);
     ACR_CHECK_ARG((d->qkv_sb % 4) == 0 && (d->qkv_st % 4) == 0 && (d->qkv_sh % 4) == 0 && (d->o_sb % 4) == 0 &&
                       (d->o_st % 4) == 0 && (d->o_sh % 4) == 0,
                   "%s: strides must be multiples of 4 elements (vector loads)", who);
@@ -541,8 +552,13 @@ extern "C" int acr_attn_fwd(const acr_attn_desc* d, const void* q, const void* k
                       : (aligned8(q) && aligned8(k) && aligned8(v) && aligned8(o)),
                   "acr_attn_fwd: q/k/v/o must be 16-byte (fp32) / 8-byte (bf16) aligned");
     ACR_CHECK_ARG(!pmean || pmean_sb >= (int64_t)d->T * d->T, "acr_attn_fwd: pmean batch stride < T*T");
-    return f32 ? attn_fwd_t<float>(d, q, k, v, o, lse2, pmean, pmean_sb, (hipStream_t)stream)
-               : attn_fwd_t<__bf16>(d, q, k, v, o, lse2, pmean, pmean_sb, (hipStream_t)stream);
+    if (f32) return attn_fwd_t<float>(d, q, k, v, o, lse2, pmean, pmean_sb, (hipStream_t)stream);
+    const void* ptrs[4] = {q, k, v, o};
+    if (d->dtype == ACR_BF16 && acr_bf16_mfma_ok(d, ptrs, 4)) {
+        acr_attn_fwd_bf16(d, q, k, v, o, lse2, pmean, pmean_sb, (hipStream_t)stream);
+        return acr_check_launch("acr_attn_fwd");
+    }
+    return attn_fwd_t<__bf16>(d, q, k, v, o, lse2, pmean, pmean_sb, (hipStream_t)stream);
 }
 
 template <typename T>
@@ -572,8 +588,13 @@ extern "C" int acr_attn_bwd(const acr_attn_desc* d, const void* q, const void* k
     ACR_CHECK_ARG(f32 ? (aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(d_o))
                       : (aligned8(q) && aligned8(k) && aligned8(v) && aligned8(o) && aligned8(d_o)),
                   "acr_attn_bwd: inputs must be 16-byte (fp32) / 8-byte (bf16) aligned");
-    return f32 ? attn_bwd_t<float>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, dq, dk, dv, delta_ws, (hipStream_t)stream)
-               : attn_bwd_t<__bf16>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, dq, dk, dv, delta_ws, (hipStream_t)stream);
+    if (f32) return attn_bwd_t<float>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, dq, dk, dv, delta_ws, (hipStream_t)stream);
+    const void* ptrs[8] = {q, k, v, o, d_o, dq, dk, dv};
+    if (d->dtype == ACR_BF16 && acr_bf16_mfma_ok(d, ptrs, 8)) {
+        acr_attn_bwd_bf16(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, dq, dk, dv, delta_ws, (hipStream_t)stream);
+        return acr_check_launch("acr_attn_bwd");
+    }
+    return attn_bwd_t<__bf16>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, dq, dk, dv, delta_ws, (hipStream_t)stream);
 }
 
 extern "C" int acr_attn_probs(const acr_attn_desc* d, const void* q, const void* k, const float* lse2, float* probs,
@@ -585,9 +606,12 @@ extern "C" int acr_attn_probs(const acr_attn_desc* d, const void* q, const void*
     const int nt = (d->T + 63) / 64;
     ACR_CHECK_ARG((int64_t)d->B * d->H * nt * nt < (1ll << 31), "acr_attn_probs: grid too large");
     const dim3 grid(d->B * d->H * nt * nt);
+    const void* pp[2] = {q, k};
     if (d->dtype == ACR_F32)
         hipLaunchKernelGGL((attn_tile_qk_kernel<float, TQK_PROBS>), grid, dim3(256), 0, (hipStream_t)stream, g,
                            (const float*)q, (const float*)k, lse2, probs, (int64_t)0);
+    else if (d->dtype == ACR_BF16 && acr_bf16_mfma_ok(d, pp, 2))
+        acr_attn_probs_bf16(d, q, k, lse2, probs, (hipStream_t)stream);
     else
         hipLaunchKernelGGL((attn_tile_qk_kernel<__bf16, TQK_PROBS>), grid, dim3(256), 0, (hipStream_t)stream, g,
                            (const __bf16*)q, (const __bf16*)k, lse2, probs, (int64_t)0);
@@ -602,9 +626,12 @@ extern "C" int acr_attn_dprobs(const acr_attn_desc* d, const void* d_o, const vo
     const int nt = (d->T + 63) / 64;
     ACR_CHECK_ARG((int64_t)d->B * d->H * nt * nt < (1ll << 31), "acr_attn_dprobs: grid too large");
     const dim3 grid(d->B * d->H * nt * nt);
+    const void* pp[2] = {d_o, v};
     if (d->dtype == ACR_F32)
         hipLaunchKernelGGL((attn_tile_qk_kernel<float, TQK_DPROBS>), grid, dim3(256), 0, (hipStream_t)stream, g,
                            (const float*)d_o, (const float*)v, (const float*)nullptr, dprobs, (int64_t)0);
+    else if (d->dtype == ACR_BF16 && acr_bf16_mfma_ok(d, pp, 2))
+        acr_attn_dprobs_bf16(d, d_o, v, dprobs, (hipStream_t)stream);
     else
         hipLaunchKernelGGL((attn_tile_qk_kernel<__bf16, TQK_DPROBS>), grid, dim3(256), 0, (hipStream_t)stream, g,
                            (const __bf16*)d_o, (const __bf16*)v, (const float*)nullptr, dprobs, (int64_t)0);

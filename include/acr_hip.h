@@ -33,7 +33,10 @@ typedef enum acr_status {
     ACR_ERR_UNSUPPORTED = -3   /* dtype / shape not built into this library */
 } acr_status;
 
-typedef enum acr_dtype { ACR_F32 = 0, ACR_BF16 = 1 } acr_dtype;
+/* ACR_F32: fp32 tensors, exact-fp32 MFMA (parity / inference precision).
+ * ACR_BF16: bf16 tensors, bf16 MFMA with fp32 accumulate and fp32 softmax (training throughput precision).
+ * ACR_BF16_F32MATH: bf16 tensors, every product in exact fp32 (debug / reference for the bf16 kernels). */
+typedef enum acr_dtype { ACR_F32 = 0, ACR_BF16 = 1, ACR_BF16_F32MATH = 2 } acr_dtype;
 
 typedef enum acr_getam_func {   /* DPT/ACR.py:189-205 */
     ACR_GETAM_GRAD = 0, ACR_GETAM_CAM_GRAD = 1, ACR_GETAM_GRAD_S = 2, ACR_GETAM_CAM_GRAD_S = 3
