@@ -35,9 +35,11 @@ __device__ __forceinline__ void stage_tile_bf(bf16_t* lds, const bf16_t* g, int6
     for (int i = 0; i < ROWS * 8 / NTHREADS; ++i) {
         const int slot = tid + i * NTHREADS;
         const int row = slot >> 3, c8 = slot & 7;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row0 + row < Tn) v = *reinterpret_cast<const bf16x8*>(g + (int64_t)(row0 + row) * st + c8 * 8);
-        *reinterpret_cast<bf16x8*>(lds + row * BP + c8 * 8) = v;
+        // unconditional load from a clamped row + select: a guarded load makes hipcc branch and drain vmcnt per chunk
+        const int rc = min(row0 + row, Tn - 1);
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(g + (int64_t)rc * st + c8 * 8);
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        *reinterpret_cast<bf16x8*>(lds + row * BP + c8 * 8) = (row0 + row < Tn) ? v : z;
     }
 }
 
@@ -45,12 +47,12 @@ __device__ __forceinline__ void stage_tile_bf(bf16_t* lds, const bf16_t* g, int6
 __device__ __forceinline__ void load_rows_bf(bf16x8 (&reg)[4], const bf16_t* g, int64_t st, int row0, int Tn, int lane) {
     const int r = lane & 31, h = lane >> 5;
     const bool ok = row0 + r < Tn;
-    const bf16_t* p = g + (int64_t)(row0 + r) * st + 8 * h;
+    const bf16_t* p = g + (int64_t)min(row0 + r, Tn - 1) * st + 8 * h;
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok) v = *reinterpret_cast<const bf16x8*>(p + 16 * s);
-        reg[s] = v;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p + 16 * s);
+        reg[s] = ok ? v : z;
     }
 }
 __device__ __forceinline__ void load_rows_lds_bf(bf16x8 (&reg)[4], const bf16_t* tile, int lane) {
@@ -213,9 +215,8 @@ __global__ __launch_bounds__(256) void attn_tile_qk_bf16_kernel(AttnGeomB g, con
             const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int qq = q0 + wq * 32 + acr_krow(reg, hh);
-                const float lv = (qq < g.T) ? lrow[qq] : 0.f;
-                acc[reg] += fast_exp2(fmaf(s[reg], c, -lv));
+                const int qq = min(q0 + wq * 32 + acr_krow(reg, hh), g.T - 1);
+                acc[reg] += fast_exp2(fmaf(s[reg], c, -lrow[qq]));
             }
         }
     }
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void attn_tile_qk_bf16_kernel(AttnGeomB g, con
 // ---------------------------------------------------------------------------------------------
 // delta[b,h,i] = rowsum(dO*O) + (1/H) sum_j P_h[i,j] G[b,i,j]
 // ---------------------------------------------------------------------------------------------
+template <bool HAS_G>
 __global__ __launch_bounds__(128) void attn_delta_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
                                                               const bf16_t* __restrict__ k, const bf16_t* __restrict__ o,
                                                               const bf16_t* __restrict__ d_o,
@@ -270,29 +272,37 @@ __global__ __launch_bounds__(128) void attn_delta_bf16_kernel(AttnGeomB g, const
     float rho[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) rho[reg] = 0.f;
-    if (gm != nullptr) {
+    if (HAS_G) {
         stage_tile_bf<64, 128>(qs, q + base, g.st, qt * 64, g.T, tid);
         float l2r[16];
+        int goff[16];
         const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int qq = q0 + acr_krow(reg, hh);
-            l2r[reg] = (qq < g.T) ? lrow[qq] : 0.f;
+            // rows beyond T: lse = +inf -> p = exp2(-inf) = 0, so no per-element guard is needed on the G load
+            l2r[reg] = (qq < g.T) ? lrow[min(qq, g.T - 1)] : INFINITY;
+            goff[reg] = min(qq, g.T - 1) * g.T;
         }
         __syncthreads();
         const float* grow = gm + (int64_t)b * gm_sb;
+        bf16x8 kreg[4], knext[4];
+        load_rows_bf(kreg, k + base, g.st, 0, g.T, lane);
         for (int k0 = 0; k0 < g.T; k0 += 32) {
-            bf16x8 kreg[4];
-            load_rows_bf(kreg, k + base, g.st, k0, g.T, lane);
+            if (k0 + 32 < g.T) load_rows_bf(knext, k + base, g.st, k0 + 32, g.T, lane);   // prefetch next key rows
+            const int key = k0 + r;
+            const int kc = min(key, g.T - 1);
+            float gv[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = grow[goff[reg] + kc];
             f32x16 s = {0};
             mma_rowop_bf(s, qs + wave * 32 * BP, kreg, lane);   // S raw [query = krow][key = k0 + r]
-            const int key = k0 + r;
+            const float kmask = (key < g.T) ? 1.f : 0.f;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int qq = q0 + acr_krow(reg, hh);
-                if (qq < g.T && key < g.T)
-                    rho[reg] = fmaf(fast_exp2(fmaf(s[reg], c, -l2r[reg])), grow[(int64_t)qq * g.T + key], rho[reg]);
-            }
+            for (int reg = 0; reg < 16; ++reg)
+                rho[reg] = fmaf(fast_exp2(fmaf(s[reg], c, -l2r[reg])) * kmask, gv[reg], rho[reg]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kreg[i] = knext[i];
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -315,6 +325,7 @@ __global__ __launch_bounds__(128) void attn_delta_bf16_kernel(AttnGeomB g, const
 // dQ: 2 waves x 32 query rows, 64 keys per step; the fp32 G tile is staged through LDS (coalesced rows in,
 // per-lane 4-key groups out)
 // ---------------------------------------------------------------------------------------------
+template <bool HAS_G>
 __global__ __launch_bounds__(128) void attn_dq_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
                                                            const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                            const bf16_t* __restrict__ d_o,
@@ -343,19 +354,21 @@ __global__ __launch_bounds__(128) void attn_dq_bf16_kernel(AttnGeomB g, const bf
     const float l2 = qok ? lse2[((int64_t)b * g.H + h) * g.T + q0 + r] : 0.f;
     const float dl = qok ? delta[((int64_t)b * g.H + h) * g.T + q0 + r] : 0.f;
     const float invH = 1.f / (float)g.H;
-    const float* gb = gm ? gm + (int64_t)b * gm_sb : nullptr;
+    const float* gb = HAS_G ? gm + (int64_t)b * gm_sb : nullptr;
     float* gw = gt + wave * 32 * GP;
     f32x16 dq0 = {0}, dq1 = {0};
     for (int k0 = 0; k0 < g.T; k0 += 64) {
         __syncthreads();
         stage_tile_bf<64, 128>(kt, k + base, g.st, k0, g.T, tid);
         stage_tile_bf<64, 128>(vt, v + base, g.st, k0, g.T, tid);
-        if (gb) {
-            const int key = k0 + lane;
-#pragma unroll 8
+        if (HAS_G) {
+            // coalesced 256-B row segments of G in, unconditional (clamped) loads: out-of-range keys / queries are
+            // masked through p = 0 below, never through the load
+            const int kc = min(k0 + lane, g.T - 1);
+#pragma unroll
             for (int rr = 0; rr < 32; ++rr) {
-                const int qq = q0 + rr;
-                gw[rr * GP + lane] = (qq < g.T && key < g.T) ? gb[(int64_t)qq * g.T + key] * invH : 0.f;
+                const int qc = min(q0 + rr, g.T - 1);
+                gw[rr * GP + lane] = gb[qc * g.T + kc] * invH;
             }
         }
         __syncthreads();
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(128) void attn_dq_bf16_kernel(AttnGeomB g, const bf
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
                 f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-                if (gb) gv = *reinterpret_cast<const f32x4*>(gw + r * GP + 32 * kb + 8 * grp + 4 * hh);
+                if (HAS_G) gv = *reinterpret_cast<const f32x4*>(gw + r * GP + 32 * kb + 8 * grp + 4 * hh);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int reg = 4 * grp + e;
@@ -395,6 +408,7 @@ __global__ __launch_bounds__(128) void attn_dq_bf16_kernel(AttnGeomB g, const bf
 // ---------------------------------------------------------------------------------------------
 // dK, dV: 2 waves x 32 keys (K, V fragments in registers), 64 queries per step
 // ---------------------------------------------------------------------------------------------
+template <bool HAS_G>
 __global__ __launch_bounds__(128) void attn_dkdv_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
                                                              const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                              const bf16_t* __restrict__ d_o,
@@ -424,16 +438,19 @@ __global__ __launch_bounds__(128) void attn_dkdv_bf16_kernel(AttnGeomB g, const 
     const float invH = 1.f / (float)g.H;
     const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
     const float* drow = delta + ((int64_t)b * g.H + h) * g.T;
-    const float* gbase = gm ? gm + (int64_t)b * gm_sb : nullptr;
+    const float* gbase = HAS_G ? gm + (int64_t)b * gm_sb + min(key, g.T - 1) : nullptr;
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
     for (int q0 = 0; q0 < g.T; q0 += 64) {
         __syncthreads();
         stage_tile_bf<64, 128>(qtile, q + base, g.st, q0, g.T, tid);
         stage_tile_bf<64, 128>(dotile, d_o + obase, g.ost, q0, g.T, tid);
         if (tid < 64) {
+            // queries beyond T get lse = +inf -> p = 0: no per-element guards in the compute loop
             const bool ok = q0 + tid < g.T;
-            l2s[tid] = ok ? lrow[q0 + tid] : 0.f;
-            dls[tid] = ok ? drow[q0 + tid] : 0.f;
+            const int qc = min(q0 + tid, g.T - 1);
+            const float lv = lrow[qc], dv_ = drow[qc];
+            l2s[tid] = ok ? lv : INFINITY;
+            dls[tid] = ok ? dv_ : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -441,16 +458,20 @@ __global__ __launch_bounds__(128) void attn_dkdv_bf16_kernel(AttnGeomB g, const 
             f32x16 s = {0}, dp = {0};
             mma_rowop_bf(s, qtile + qb * 32 * BP, kreg, lane);      // S raw [query = krow][key = r]
             mma_rowop_bf(dp, dotile + qb * 32 * BP, vreg, lane);    // dP
+            float gv[16];
+            if (HAS_G) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    gv[reg] = gbase[min(q0 + 32 * qb + acr_krow(reg, hh), g.T - 1) * g.T];
+            }
             f32x16 p, ds;
+            const float kmask = kok ? 1.f : 0.f;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int kr = 32 * qb + acr_krow(reg, hh);
-                const int qq = q0 + kr;
-                const bool ok = kok && qq < g.T;
-                const float pv = ok ? fast_exp2(fmaf(s[reg], c, -l2s[kr])) : 0.f;
-                const float gv = (ok && gbase) ? gbase[(int64_t)qq * g.T + key] * invH : 0.f;
+                const float pv = fast_exp2(fmaf(s[reg], c, -l2s[kr])) * kmask;
                 p[reg] = pv;
-                ds[reg] = pv * (dp[reg] + gv - dls[kr]);
+                ds[reg] = pv * (dp[reg] + (HAS_G ? gv[reg] * invH : 0.f) - dls[kr]);
             }
             mma_accop_a_bf(dv0, p, dotile + qb * 32 * BP, 0, lane);  // dV[key = krow][d = 32*blk + r]
             mma_accop_a_bf(dv1, p, dotile + qb * 32 * BP, 1, lane);
@@ -507,13 +528,16 @@ void acr_attn_bwd_bf16(const acr_attn_desc* d, const void* q, const void* k, con
     AttnGeomB g = geom_b(d);
     const int nqt = (d->T + 63) / 64;
     const dim3 grid(d->B * d->H * nqt);
-    hipLaunchKernelGGL(attn_delta_bf16_kernel, grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)o, (const bf16_t*)d_o, lse2, gm, gm_sb, delta);
-    hipLaunchKernelGGL(attn_dkdv_bf16_kernel, grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, (const float*)delta, gm, gm_sb, (bf16_t*)dk,
-                       (bf16_t*)dv);
-    hipLaunchKernelGGL(attn_dq_bf16_kernel, grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,
+#define ACR_BWD_LAUNCH(HG)                                                                                          \
+    hipLaunchKernelGGL((attn_delta_bf16_kernel<HG>), grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,  \
+                       (const bf16_t*)o, (const bf16_t*)d_o, lse2, gm, gm_sb, delta);                                \
+    hipLaunchKernelGGL((attn_dkdv_bf16_kernel<HG>), grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,   \
+                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, (const float*)delta, gm, gm_sb, (bf16_t*)dk,      \
+                       (bf16_t*)dv);                                                                                 \
+    hipLaunchKernelGGL((attn_dq_bf16_kernel<HG>), grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,     \
                        (const bf16_t*)v, (const bf16_t*)d_o, lse2, (const float*)delta, gm, gm_sb, (bf16_t*)dq);
+    if (gm) { ACR_BWD_LAUNCH(true) } else { ACR_BWD_LAUNCH(false) }
+#undef ACR_BWD_LAUNCH
 }
 
 void acr_attn_probs_bf16(const acr_attn_desc* d, const void* q, const void* k, const float* lse2, float* probs,

@@ -37,9 +37,10 @@ __device__ __forceinline__ void stage_tile(float* lds, const T* g, int64_t st, i
     for (int i = 0; i < 512 / NTHREADS; ++i) {
         const int slot = tid + i * NTHREADS;
         const int row = slot >> 4, c4 = slot & 15;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row0 + row < Tn) v = acr_load4<T>(g + (int64_t)(row0 + row) * st + c4 * 4) * mul;
-        *reinterpret_cast<f32x4*>(lds + row * LDP + c4 * 4) = v;
+        // unconditional load from a clamped row + select (a guarded load makes hipcc branch and drain vmcnt per chunk)
+        f32x4 v = acr_load4<T>(g + (int64_t)min(row0 + row, Tn - 1) * st + c4 * 4) * mul;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(lds + row * LDP + c4 * 4) = (row0 + row < Tn) ? v : z;
     }
 }
 
@@ -47,12 +48,11 @@ __device__ __forceinline__ void stage_tile(float* lds, const T* g, int64_t st, i
 template <typename T>
 __device__ __forceinline__ void load_rows(float (&reg)[32], const T* g, int64_t st, int row0, int Tn, int lane, float mul) {
     const int r = lane & 31, h = lane >> 5;
-    const bool ok = row0 + r < Tn;
-    const T* p = g + (int64_t)(row0 + r) * st + 32 * h;
+    const float okm = (row0 + r < Tn) ? mul : 0.f;
+    const T* p = g + (int64_t)min(row0 + r, Tn - 1) * st + 32 * h;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = acr_load4<T>(p + 4 * i) * mul;
+        f32x4 v = acr_load4<T>(p + 4 * i) * okm;
         reg[4 * i + 0] = v[0]; reg[4 * i + 1] = v[1]; reg[4 * i + 2] = v[2]; reg[4 * i + 3] = v[3];
     }
 }
@@ -214,9 +214,8 @@ __global__ __launch_bounds__(256) void attn_tile_qk_kernel(AttnGeom g, const T* 
             const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int qq = q0 + wq * 32 + acr_krow(reg, hh);
-                const float lv = (qq < g.T) ? lrow[qq] : 0.f;
-                acc[reg] += exp2f(s[reg] - lv);
+                const int qq = min(q0 + wq * 32 + acr_krow(reg, hh), g.T - 1);
+                acc[reg] += exp2f(s[reg] - lrow[qq]);
             }
         }
     }
@@ -273,25 +272,30 @@ __global__ __launch_bounds__(128) void attn_delta_kernel(AttnGeom g, const T* __
         stage_tile<T, 128>(qs, q + base, g.st, qt * 64, g.T, tid, 1.f);
         stage_tile<T, 128>(qs + TILE_FLOATS, q + base, g.st, qt * 64 + 32, g.T, tid, 1.f);
         float l2r[16];
+        int goff[16];
         const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int qq = q0 + acr_krow(reg, hh);
-            l2r[reg] = (qq < g.T) ? lrow[qq] : 0.f;
+            const float lv = lrow[min(qq, g.T - 1)];
+            l2r[reg] = (qq < g.T) ? lv : INFINITY;          // rows beyond T: p = exp2(-inf) = 0
+            goff[reg] = min(qq, g.T - 1) * g.T;
         }
         __syncthreads();
         const float* grow = gm + (int64_t)b * gm_sb;
         for (int k0 = 0; k0 < g.T; k0 += 32) {
             float kreg[32];
             load_rows<T>(kreg, k + base, g.st, k0, g.T, lane, g.scale * ACR_LOG2E);
+            const int key = k0 + r;
+            const int kc = min(key, g.T - 1);
+            float gv[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = grow[goff[reg] + kc];     // unconditional (clamped) loads
             f32x16 s = {0};
             mma_rowop(s, qs + wave * TILE_FLOATS, kreg, lane);   // s[reg] = S2[query = krow][key = k0 + r]
-            const int key = k0 + r;
+            const float kmask = (key < g.T) ? 1.f : 0.f;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int qq = q0 + acr_krow(reg, hh);
-                if (qq < g.T && key < g.T) rho[reg] += exp2f(s[reg] - l2r[reg]) * grow[(int64_t)qq * g.T + key];
-            }
+            for (int reg = 0; reg < 16; ++reg) rho[reg] += exp2f(s[reg] - l2r[reg]) * kmask * gv[reg];
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(128) void attn_dq_kernel(AttnGeom g, const T* __res
     const float l2 = qok ? lse2[((int64_t)b * g.H + h) * g.T + q0 + r] : 0.f;
     const float dl = qok ? delta[((int64_t)b * g.H + h) * g.T + q0 + r] : 0.f;
     const float invH = 1.f / (float)g.H;
-    const float* grow = gm ? gm + (int64_t)b * gm_sb + (int64_t)(q0 + r) * g.T : nullptr;
+    const float* grow = gm ? gm + (int64_t)b * gm_sb + (int64_t)min(q0 + r, g.T - 1) * g.T : nullptr;
     f32x16 dq0 = {0}, dq1 = {0};
     for (int k0 = 0; k0 < g.T; k0 += 32) {
         __syncthreads();
@@ -347,14 +351,20 @@ __global__ __launch_bounds__(128) void attn_dq_kernel(AttnGeom g, const T* __res
         f32x16 s = {0}, dp = {0};
         mma_rowop(s, kt, qreg, lane);                     // S2^T[key = krow][query = r]
         mma_rowop(dp, vt, doreg, lane);                   // dP^T[key][query]
+        float gv[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) gv[reg] = 0.f;
+        if (grow) {                                        // uniform branch; loads inside are unconditional (clamped)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = grow[min(k0 + acr_krow(reg, hh), g.T - 1)] * invH;
+        }
         f32x16 ds;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int key = k0 + acr_krow(reg, hh);
             const bool ok = qok && key < g.T;
             const float p = ok ? exp2f(s[reg] - l2) : 0.f;
-            const float gv = (ok && grow) ? grow[key] * invH : 0.f;
-            ds[reg] = p * (dp[reg] + gv - dl);
+            ds[reg] = p * (dp[reg] + gv[reg] - dl);
         }
         mma_accop_a(dq0, ds, kt, 0, lane);                // dQ[query = krow][d = 32*blk + r]
         mma_accop_a(dq1, ds, kt, 1, lane);
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(128) void attn_dkdv_kernel(AttnGeom g, const T* __r
     const float invH = 1.f / (float)g.H;
     const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
     const float* drow = delta + ((int64_t)b * g.H + h) * g.T;
-    const float* gbase = gm ? gm + (int64_t)b * gm_sb : nullptr;
+    const float* gbase = gm ? gm + (int64_t)b * gm_sb + min(key, g.T - 1) : nullptr;
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
     for (int q0 = 0; q0 < g.T; q0 += 32) {
         __syncthreads();
@@ -408,23 +418,30 @@ __global__ __launch_bounds__(128) void attn_dkdv_kernel(AttnGeom g, const T* __r
         stage_tile<T, 128>(dotile, d_o + obase, g.ost, q0, g.T, tid, 1.f);
         if (tid < 32) {
             const bool ok = q0 + tid < g.T;
-            l2s[tid] = ok ? lrow[q0 + tid] : 0.f;
-            dls[tid] = ok ? drow[q0 + tid] : 0.f;
+            const int qc = min(q0 + tid, g.T - 1);
+            const float lv = lrow[qc], dvv = drow[qc];
+            l2s[tid] = ok ? lv : INFINITY;                  // queries beyond T: p = exp2(-inf) = 0
+            dls[tid] = ok ? dvv : 0.f;
         }
         __syncthreads();
         f32x16 s = {0}, dp = {0};
         mma_rowop(s, qtile, kreg, lane);                  // S2[query = krow][key = r]
         mma_rowop(dp, dotile, vreg, lane);                // dP[query][key]
+        float gv[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) gv[reg] = 0.f;
+        if (gbase) {                                       // uniform branch; loads inside are unconditional (clamped)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = gbase[min(q0 + acr_krow(reg, hh), g.T - 1) * g.T] * invH;
+        }
         f32x16 p, ds;
+        const float kmask = kok ? 1.f : 0.f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int kr = acr_krow(reg, hh);
-            const int qq = q0 + kr;
-            const bool ok = kok && qq < g.T;
-            const float pv = ok ? exp2f(s[reg] - l2s[kr]) : 0.f;
-            const float gv = (ok && gbase) ? gbase[(int64_t)qq * g.T + key] * invH : 0.f;
+            const float pv = exp2f(s[reg] - l2s[kr]) * kmask;
             p[reg] = pv;
-            ds[reg] = pv * (dp[reg] + gv - dls[kr]);
+            ds[reg] = pv * (dp[reg] + gv[reg] - dls[kr]);
         }
         mma_accop_a(dv0, p, dotile, 0, lane);             // dV[key = krow][d = 32*blk + r]
         mma_accop_a(dv1, p, dotile, 1, lane);
