@@ -33,16 +33,17 @@ _P = ctypes.POINTER(AttnDesc)
 SIGNATURES = {
     "acr_version": (c_int32, []),
     "acr_last_error": (ctypes.c_char_p, []),
-    "acr_attn_fwd": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "acr_attn_fwd": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                               c_void_p]),
     "acr_attn_bwd": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                               c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acr_attn_probs": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acr_attn_dprobs": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acr_consistency_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),
     "acr_consistency_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                       c_void_p, c_void_p]),
     "acr_consistency_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,
-                                      c_void_p, c_void_p, c_int64, c_void_p]),
+                                      c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "acr_getam_row_accum": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       c_void_p, c_void_p]),
     "acr_aff_refine": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),

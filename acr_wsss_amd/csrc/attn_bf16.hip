@@ -29,18 +29,40 @@ struct AttnGeomB {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Compiler-level fence: global loads issued before it stay before it, LDS stores after it stay after it.  Without
+// it hipcc sinks every staging load next to its ds_write and drains vmcnt(0) per 16-byte chunk.
+#define ACR_MEMBAR() asm volatile("" ::: "memory")
+
+// 64-row x 64-col bf16 tile, two-phase staging (global -> registers now, registers -> LDS one iteration later)
+template <int NT>
+struct TileRegs { bf16x8 v[512 / NT]; };
+
+template <int NT>
+__device__ __forceinline__ void tile_gload(TileRegs<NT>& t, const bf16_t* g, int64_t st, int row0, int Tn, int tid) {
+#pragma unroll
+    for (int i = 0; i < 512 / NT; ++i) {
+        const int slot = tid + i * NT;
+        const int rc = min(row0 + (slot >> 3), Tn - 1);          // clamped: always a valid address
+        t.v[i] = *reinterpret_cast<const bf16x8*>(g + (int64_t)rc * st + (slot & 7) * 8);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void tile_lstore(bf16_t* lds, const TileRegs<NT>& t, int row0, int Tn, int tid) {
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 512 / NT; ++i) {
+        const int slot = tid + i * NT;
+        const int row = slot >> 3;
+        *reinterpret_cast<bf16x8*>(lds + row * BP + (slot & 7) * 8) = (row0 + row < Tn) ? t.v[i] : z;
+    }
+}
 template <int ROWS, int NTHREADS>
 __device__ __forceinline__ void stage_tile_bf(bf16_t* lds, const bf16_t* g, int64_t st, int row0, int Tn, int tid) {
-#pragma unroll
-    for (int i = 0; i < ROWS * 8 / NTHREADS; ++i) {
-        const int slot = tid + i * NTHREADS;
-        const int row = slot >> 3, c8 = slot & 7;
-        // unconditional load from a clamped row + select: a guarded load makes hipcc branch and drain vmcnt per chunk
-        const int rc = min(row0 + row, Tn - 1);
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(g + (int64_t)rc * st + c8 * 8);
-        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        *reinterpret_cast<bf16x8*>(lds + row * BP + c8 * 8) = (row0 + row < Tn) ? v : z;
-    }
+    static_assert(ROWS == 64, "64-row tiles");
+    TileRegs<NTHREADS> t;
+    tile_gload<NTHREADS>(t, g, st, row0, Tn, tid);
+    ACR_MEMBAR();
+    tile_lstore<NTHREADS>(lds, t, row0, Tn, tid);
 }
 
 // lane (r, h) owns row (row0 + r), k-slots 16s + 8h + j  (s = 0..3, j = 0..7)
@@ -99,13 +121,14 @@ __device__ __forceinline__ void mma_accop_b_bf(f32x16& acc, const f32x16& z, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward: 2 waves x 32 query rows, 64 keys per step
+// forward: 2 waves x 32 query rows, 64 keys per step, K/V tiles double-buffered in LDS with the next tile's
+// global loads in flight during the current tile's MFMA + softmax work (one barrier per step)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void attn_fwd_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
                                                             const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                             bf16_t* __restrict__ o, float* __restrict__ lse2) {
-    __shared__ __attribute__((aligned(16))) bf16_t kt[64 * BP];
-    __shared__ __attribute__((aligned(16))) bf16_t vt[64 * BP];
+    __shared__ __attribute__((aligned(16))) bf16_t kt[2][64 * BP];
+    __shared__ __attribute__((aligned(16))) bf16_t vt[2][64 * BP];
     const int nqt = (g.T + 63) >> 6;
     int id = acr_xcd_remap(blockIdx.x, gridDim.x);
     const int qt = id % nqt; id /= nqt;
@@ -118,16 +141,25 @@ __global__ __launch_bounds__(128) void attn_fwd_bf16_kernel(AttnGeomB g, const b
     const float c = g.scale * ACR_LOG2E;
     bf16x8 qreg[4];
     load_rows_bf(qreg, q + base, g.st, q0, g.T, lane);
+    TileRegs<128> kr, vr;
+    tile_gload<128>(kr, k + base, g.st, 0, g.T, tid);
+    tile_gload<128>(vr, v + base, g.st, 0, g.T, tid);
+    ACR_MEMBAR();
+    tile_lstore<128>(kt[0], kr, 0, g.T, tid);
+    tile_lstore<128>(vt[0], vr, 0, g.T, tid);
+    __syncthreads();
     float m = -INFINITY, l = 0.f;
     f32x16 o0 = {0}, o1 = {0};
-    for (int k0 = 0; k0 < g.T; k0 += 64) {
-        __syncthreads();
-        stage_tile_bf<64, 128>(kt, k + base, g.st, k0, g.T, tid);
-        stage_tile_bf<64, 128>(vt, v + base, g.st, k0, g.T, tid);
-        __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < g.T; k0 += 64, cur ^= 1) {
+        tile_gload<128>(kr, k + base, g.st, k0 + 64, g.T, tid);      // next tile (clamped rows past the end)
+        tile_gload<128>(vr, v + base, g.st, k0 + 64, g.T, tid);
+        ACR_MEMBAR();
+        const bf16_t* ktc = kt[cur];
+        const bf16_t* vtc = vt[cur];
         f32x16 s0 = {0}, s1 = {0};
-        mma_rowop_bf(s0, kt, qreg, lane);                  // s[reg] = q.k (raw) [key = k0 + 32*kb + krow][query = r]
-        mma_rowop_bf(s1, kt + 32 * BP, qreg, lane);
+        mma_rowop_bf(s0, ktc, qreg, lane);                 // s[reg] = q.k (raw) [key = k0 + 32*kb + krow][query = r]
+        mma_rowop_bf(s1, ktc + 32 * BP, qreg, lane);
         if (k0 + 64 > g.T) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -152,10 +184,14 @@ __global__ __launch_bounds__(128) void attn_fwd_bf16_kernel(AttnGeomB g, const b
         l = l * alpha + rs;
         m = mn;
         o0 *= alpha; o1 *= alpha;
-        mma_accop_b_bf(o0, s0, vt, 0, lane);               // o[reg] = O^T[d = 32*blk + krow][query = r]
-        mma_accop_b_bf(o1, s0, vt, 1, lane);
-        mma_accop_b_bf(o0, s1, vt + 32 * BP, 0, lane);
-        mma_accop_b_bf(o1, s1, vt + 32 * BP, 1, lane);
+        mma_accop_b_bf(o0, s0, vtc, 0, lane);              // o[reg] = O^T[d = 32*blk + krow][query = r]
+        mma_accop_b_bf(o1, s0, vtc, 1, lane);
+        mma_accop_b_bf(o0, s1, vtc + 32 * BP, 0, lane);
+        mma_accop_b_bf(o1, s1, vtc + 32 * BP, 1, lane);
+        ACR_MEMBAR();
+        tile_lstore<128>(kt[cur ^ 1], kr, k0 + 64, g.T, tid);
+        tile_lstore<128>(vt[cur ^ 1], vr, k0 + 64, g.T, tid);
+        __syncthreads();
     }
     if (q0 + r < g.T) {
         const float inv = 1.f / l;
@@ -172,7 +208,8 @@ __global__ __launch_bounds__(128) void attn_fwd_bf16_kernel(AttnGeomB g, const b
 }
 
 // ---------------------------------------------------------------------------------------------
-// 64x64 tiles of P / dO V^T (PMEAN over heads, PROBS / DPROBS per head); 4 waves as 2 x 2
+// 64x64 tiles of P / dO V^T (PMEAN over heads, PROBS / DPROBS per head); 4 waves as 2 x 2; the head loop of
+// PMEAN is double-buffered like the key loop of the forward
 // ---------------------------------------------------------------------------------------------
 enum { TQKB_PMEAN = 0, TQKB_PROBS = 1, TQKB_DPROBS = 2 };
 
@@ -180,9 +217,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void attn_tile_qk_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ xq,
                                                                 const bf16_t* __restrict__ xk,
                                                                 const float* __restrict__ lse2,
-                                                                float* __restrict__ out, int64_t out_sb) {
-    __shared__ __attribute__((aligned(16))) bf16_t qs[64 * BP];
-    __shared__ __attribute__((aligned(16))) bf16_t ks[64 * BP];
+                                                                float* __restrict__ out, int64_t out_sb, int64_t out_st) {
+    __shared__ __attribute__((aligned(16))) bf16_t qs[2][64 * BP];
+    __shared__ __attribute__((aligned(16))) bf16_t ks[2][64 * BP];
     const int nt = (g.T + 63) >> 6;
     int id = acr_xcd_remap(blockIdx.x, gridDim.x);
     const int kti = id % nt; id /= nt;
@@ -195,39 +232,59 @@ __global__ __launch_bounds__(256) void attn_tile_qk_bf16_kernel(AttnGeomB g, con
     const int q0 = qti * 64, k0 = kti * 64;
     const bool is_q = (MODE != TQKB_DPROBS);
     const float c = g.scale * ACR_LOG2E;
-    f32x16 acc = {0};
+    const int64_t qsb = is_q ? g.sb : g.osb, qsh = is_q ? g.sh : g.osh, qst = is_q ? g.st : g.ost;
     const int h_lo = (MODE == TQKB_PMEAN) ? 0 : hsel, h_hi = (MODE == TQKB_PMEAN) ? g.H : hsel + 1;
-    for (int h = h_lo; h < h_hi; ++h) {
-        const bf16_t* qb = is_q ? xq + (int64_t)b * g.sb + (int64_t)h * g.sh : xq + (int64_t)b * g.osb + (int64_t)h * g.osh;
-        const int64_t qst = is_q ? g.st : g.ost;
-        const bf16_t* kb = xk + (int64_t)b * g.sb + (int64_t)h * g.sh;
-        __syncthreads();
-        stage_tile_bf<64, 256>(qs, qb, qst, q0, g.T, tid);
-        stage_tile_bf<64, 256>(ks, kb, g.st, k0, g.T, tid);
-        __syncthreads();
+    TileRegs<256> qr, kr;
+    tile_gload<256>(qr, xq + (int64_t)b * qsb + (int64_t)h_lo * qsh, qst, q0, g.T, tid);
+    tile_gload<256>(kr, xk + (int64_t)b * g.sb + (int64_t)h_lo * g.sh, g.st, k0, g.T, tid);
+    ACR_MEMBAR();
+    tile_lstore<256>(qs[0], qr, q0, g.T, tid);
+    tile_lstore<256>(ks[0], kr, k0, g.T, tid);
+    __syncthreads();
+    int qrow[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) qrow[reg] = min(q0 + wq * 32 + acr_krow(reg, hh), g.T - 1);
+    f32x16 acc = {0};
+    int cur = 0;
+    for (int h = h_lo; h < h_hi; ++h, cur ^= 1) {
+        const int hn = min(h + 1, g.H - 1);
+        if (MODE == TQKB_PMEAN) {
+            tile_gload<256>(qr, xq + (int64_t)b * qsb + (int64_t)hn * qsh, qst, q0, g.T, tid);
+            tile_gload<256>(kr, xk + (int64_t)b * g.sb + (int64_t)hn * g.sh, g.st, k0, g.T, tid);
+        }
+        float lv[16];
+        if (MODE != TQKB_DPROBS) {
+            const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) lv[reg] = lrow[qrow[reg]];
+        }
+        ACR_MEMBAR();
         bf16x8 kreg[4];
-        load_rows_lds_bf(kreg, ks + wk * 32 * BP, lane);
+        load_rows_lds_bf(kreg, ks[cur] + wk * 32 * BP, lane);
         f32x16 s = {0};
-        mma_rowop_bf(s, qs + wq * 32 * BP, kreg, lane);    // s[reg] = X[query = krow][key = r]
+        mma_rowop_bf(s, qs[cur] + wq * 32 * BP, kreg, lane);    // s[reg] = X[query = krow][key = r]
         if (MODE == TQKB_DPROBS) {
             acc = s;
         } else {
-            const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int qq = min(q0 + wq * 32 + acr_krow(reg, hh), g.T - 1);
-                acc[reg] += fast_exp2(fmaf(s[reg], c, -lrow[qq]));
-            }
+            for (int reg = 0; reg < 16; ++reg) acc[reg] += fast_exp2(fmaf(s[reg], c, -lv[reg]));
+        }
+        if (MODE == TQKB_PMEAN) {
+            ACR_MEMBAR();
+            tile_lstore<256>(qs[cur ^ 1], qr, q0, g.T, tid);
+            tile_lstore<256>(ks[cur ^ 1], kr, k0, g.T, tid);
+            __syncthreads();
         }
     }
     const int key = k0 + wk * 32 + r;
     if (key < g.T) {
         float* ob = (MODE == TQKB_PMEAN) ? out + (int64_t)b * out_sb : out + ((int64_t)b * g.H + hsel) * (int64_t)g.T * g.T;
+        const int64_t ost = (MODE == TQKB_PMEAN) ? out_st : (int64_t)g.T;
         const float mul = (MODE == TQKB_PMEAN) ? 1.f / (float)g.H : 1.f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int qq = q0 + wq * 32 + acr_krow(reg, hh);
-            if (qq < g.T) ob[(int64_t)qq * g.T + key] = acc[reg] * mul;
+            if (qq < g.T) ob[(int64_t)qq * ost + key] = acc[reg] * mul;
         }
     }
 }
@@ -240,7 +297,7 @@ __global__ __launch_bounds__(128) void attn_delta_bf16_kernel(AttnGeomB g, const
                                                               const bf16_t* __restrict__ k, const bf16_t* __restrict__ o,
                                                               const bf16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse2,
-                                                              const float* __restrict__ gm, int64_t gm_sb,
+                                                              const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
                                                               float* __restrict__ delta) {
     __shared__ __attribute__((aligned(16))) bf16_t qs[64 * BP];
     __shared__ float dsh[64];
@@ -256,9 +313,10 @@ __global__ __launch_bounds__(128) void attn_delta_bf16_kernel(AttnGeomB g, const
     const int64_t obase = (int64_t)b * g.osb + (int64_t)h * g.osh;
     const float c = g.scale * ACR_LOG2E;
     float part = 0.f;
-    if (q0 + r < g.T) {
-        const bf16_t* op = o + obase + (int64_t)(q0 + r) * g.ost + 32 * hh;
-        const bf16_t* dp = d_o + obase + (int64_t)(q0 + r) * g.ost + 32 * hh;
+    {
+        const int qc = min(q0 + r, g.T - 1);
+        const bf16_t* op = o + obase + (int64_t)qc * g.ost + 32 * hh;
+        const bf16_t* dp = d_o + obase + (int64_t)qc * g.ost + 32 * hh;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(op + 8 * i);
@@ -281,20 +339,22 @@ __global__ __launch_bounds__(128) void attn_delta_bf16_kernel(AttnGeomB g, const
         for (int reg = 0; reg < 16; ++reg) {
             const int qq = q0 + acr_krow(reg, hh);
             // rows beyond T: lse = +inf -> p = exp2(-inf) = 0, so no per-element guard is needed on the G load
-            l2r[reg] = (qq < g.T) ? lrow[min(qq, g.T - 1)] : INFINITY;
-            goff[reg] = min(qq, g.T - 1) * g.T;
+            const float lv = lrow[min(qq, g.T - 1)];
+            l2r[reg] = (qq < g.T) ? lv : INFINITY;
+            goff[reg] = min(qq, g.T - 1) * (int)gm_st;
         }
         __syncthreads();
         const float* grow = gm + (int64_t)b * gm_sb;
         bf16x8 kreg[4], knext[4];
         load_rows_bf(kreg, k + base, g.st, 0, g.T, lane);
         for (int k0 = 0; k0 < g.T; k0 += 32) {
-            if (k0 + 32 < g.T) load_rows_bf(knext, k + base, g.st, k0 + 32, g.T, lane);   // prefetch next key rows
+            load_rows_bf(knext, k + base, g.st, k0 + 32, g.T, lane);       // prefetch next key rows (clamped)
             const int key = k0 + r;
             const int kc = min(key, g.T - 1);
             float gv[16];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) gv[reg] = grow[goff[reg] + kc];
+            ACR_MEMBAR();
             f32x16 s = {0};
             mma_rowop_bf(s, qs + wave * 32 * BP, kreg, lane);   // S raw [query = krow][key = k0 + r]
             const float kmask = (key < g.T) ? 1.f : 0.f;
@@ -322,8 +382,8 @@ __global__ __launch_bounds__(128) void attn_delta_bf16_kernel(AttnGeomB g, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// dQ: 2 waves x 32 query rows, 64 keys per step; the fp32 G tile is staged through LDS (coalesced rows in,
-// per-lane 4-key groups out)
+// dQ: 2 waves x 32 query rows, 64 keys per step (K/V tiles double-buffered); each lane pulls the G values of its
+// own query row as 16-byte groups (row pitch gm_st is a multiple of 4 floats) at the top of the step
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_G>
 __global__ __launch_bounds__(128) void attn_dq_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
@@ -331,11 +391,10 @@ __global__ __launch_bounds__(128) void attn_dq_bf16_kernel(AttnGeomB g, const bf
                                                            const bf16_t* __restrict__ d_o,
                                                            const float* __restrict__ lse2,
                                                            const float* __restrict__ delta,
-                                                           const float* __restrict__ gm, int64_t gm_sb,
+                                                           const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
                                                            bf16_t* __restrict__ dq) {
-    __shared__ __attribute__((aligned(16))) bf16_t kt[64 * BP];
-    __shared__ __attribute__((aligned(16))) bf16_t vt[64 * BP];
-    __shared__ __attribute__((aligned(16))) float gt[2 * 32 * GP];
+    __shared__ __attribute__((aligned(16))) bf16_t kt[2][64 * BP];
+    __shared__ __attribute__((aligned(16))) bf16_t vt[2][64 * BP];
     const int nqt = (g.T + 63) >> 6;
     int id = acr_xcd_remap(blockIdx.x, gridDim.x);
     const int qt = id % nqt; id /= nqt;
@@ -351,48 +410,62 @@ __global__ __launch_bounds__(128) void attn_dq_bf16_kernel(AttnGeomB g, const bf
     load_rows_bf(qreg, q + base, g.st, q0, g.T, lane);
     load_rows_bf(doreg, d_o + obase, g.ost, q0, g.T, lane);
     const bool qok = q0 + r < g.T;
-    const float l2 = qok ? lse2[((int64_t)b * g.H + h) * g.T + q0 + r] : 0.f;
-    const float dl = qok ? delta[((int64_t)b * g.H + h) * g.T + q0 + r] : 0.f;
+    const int qc = min(q0 + r, g.T - 1);
+    const float l2v = lse2[((int64_t)b * g.H + h) * g.T + qc];
+    const float dlv = delta[((int64_t)b * g.H + h) * g.T + qc];
+    const float l2 = qok ? l2v : INFINITY;                 // rows beyond T: p = exp2(-inf) = 0
+    const float dl = qok ? dlv : 0.f;
     const float invH = 1.f / (float)g.H;
-    const float* gb = HAS_G ? gm + (int64_t)b * gm_sb : nullptr;
-    float* gw = gt + wave * 32 * GP;
+    const float* grow = HAS_G ? gm + (int64_t)b * gm_sb + (int64_t)qc * gm_st + 4 * hh : nullptr;
+    const int gmax = (int)gm_st - 4 - 4 * hh;              // last in-row 16-byte group start (relative to grow)
+    TileRegs<128> kr, vr;
+    tile_gload<128>(kr, k + base, g.st, 0, g.T, tid);
+    tile_gload<128>(vr, v + base, g.st, 0, g.T, tid);
+    ACR_MEMBAR();
+    tile_lstore<128>(kt[0], kr, 0, g.T, tid);
+    tile_lstore<128>(vt[0], vr, 0, g.T, tid);
+    __syncthreads();
     f32x16 dq0 = {0}, dq1 = {0};
-    for (int k0 = 0; k0 < g.T; k0 += 64) {
-        __syncthreads();
-        stage_tile_bf<64, 128>(kt, k + base, g.st, k0, g.T, tid);
-        stage_tile_bf<64, 128>(vt, v + base, g.st, k0, g.T, tid);
+    int cur = 0;
+    for (int k0 = 0; k0 < g.T; k0 += 64, cur ^= 1) {
+        tile_gload<128>(kr, k + base, g.st, k0 + 64, g.T, tid);
+        tile_gload<128>(vr, v + base, g.st, k0 + 64, g.T, tid);
+        f32x4 gq[2][4];
         if (HAS_G) {
-            // coalesced 256-B row segments of G in, unconditional (clamped) loads: out-of-range keys / queries are
-            // masked through p = 0 below, never through the load
-            const int kc = min(k0 + lane, g.T - 1);
 #pragma unroll
-            for (int rr = 0; rr < 32; ++rr) {
-                const int qc = min(q0 + rr, g.T - 1);
-                gw[rr * GP + lane] = gb[qc * g.T + kc] * invH;
-            }
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp)
+                    __builtin_memcpy(&gq[kb][grp], grow + min(k0 + 32 * kb + 8 * grp, gmax), 16);
         }
-        __syncthreads();
+        ACR_MEMBAR();
+        const bool tail = k0 + 64 > g.T;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            const bf16_t* ktc = kt[cur] + kb * 32 * BP;
+            const bf16_t* vtc = vt[cur] + kb * 32 * BP;
             f32x16 s = {0}, dp = {0};
-            mma_rowop_bf(s, kt + kb * 32 * BP, qreg, lane);     // S^T raw [key = krow][query = r]
-            mma_rowop_bf(dp, vt + kb * 32 * BP, doreg, lane);   // dP^T
+            mma_rowop_bf(s, ktc, qreg, lane);               // S^T raw [key = krow][query = r]
+            mma_rowop_bf(dp, vtc, doreg, lane);             // dP^T
             f32x16 ds;
 #pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {
-                f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-                if (HAS_G) gv = *reinterpret_cast<const f32x4*>(gw + r * GP + 32 * kb + 8 * grp + 4 * hh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int reg = 4 * grp + e;
-                    const int key = k0 + 32 * kb + acr_krow(reg, hh);
-                    const float p = (qok && key < g.T) ? fast_exp2(fmaf(s[reg], c, -l2)) : 0.f;
-                    ds[reg] = p * (dp[reg] + gv[e] - dl);
+            for (int reg = 0; reg < 16; ++reg) {
+                float p = fast_exp2(fmaf(s[reg], c, -l2));
+                float gv = HAS_G ? gq[kb][reg >> 2][reg & 3] * invH : 0.f;
+                if (tail) {                                 // pad columns of G may hold anything: select, don't multiply
+                    const bool kv = k0 + 32 * kb + acr_krow(reg, hh) < g.T;
+                    p = kv ? p : 0.f;
+                    gv = kv ? gv : 0.f;
                 }
+                ds[reg] = p * (dp[reg] + gv - dl);
             }
-            mma_accop_a_bf(dq0, ds, kt + kb * 32 * BP, 0, lane);   // dQ[query = krow][d = 32*blk + r]
-            mma_accop_a_bf(dq1, ds, kt + kb * 32 * BP, 1, lane);
+            mma_accop_a_bf(dq0, ds, ktc, 0, lane);          // dQ[query = krow][d = 32*blk + r]
+            mma_accop_a_bf(dq1, ds, ktc, 1, lane);
         }
+        ACR_MEMBAR();
+        tile_lstore<128>(kt[cur ^ 1], kr, k0 + 64, g.T, tid);
+        tile_lstore<128>(vt[cur ^ 1], vr, k0 + 64, g.T, tid);
+        __syncthreads();
     }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -406,7 +479,7 @@ __global__ __launch_bounds__(128) void attn_dq_bf16_kernel(AttnGeomB g, const bf
 }
 
 // ---------------------------------------------------------------------------------------------
-// dK, dV: 2 waves x 32 keys (K, V fragments in registers), 64 queries per step
+// dK, dV: 2 waves x 32 keys (K, V fragments in registers), 64 queries per step (Q/dO tiles double-buffered)
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_G>
 __global__ __launch_bounds__(128) void attn_dkdv_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
@@ -414,11 +487,11 @@ __global__ __launch_bounds__(128) void attn_dkdv_bf16_kernel(AttnGeomB g, const 
                                                              const bf16_t* __restrict__ d_o,
                                                              const float* __restrict__ lse2,
                                                              const float* __restrict__ delta,
-                                                             const float* __restrict__ gm, int64_t gm_sb,
+                                                             const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
                                                              bf16_t* __restrict__ dk, bf16_t* __restrict__ dv) {
-    __shared__ __attribute__((aligned(16))) bf16_t qtile[64 * BP];
-    __shared__ __attribute__((aligned(16))) bf16_t dotile[64 * BP];
-    __shared__ float l2s[64], dls[64];
+    __shared__ __attribute__((aligned(16))) bf16_t qtile[2][64 * BP];
+    __shared__ __attribute__((aligned(16))) bf16_t dotile[2][64 * BP];
+    __shared__ float l2s[2][64], dls[2][64];
     const int nkt = (g.T + 63) >> 6;
     int id = acr_xcd_remap(blockIdx.x, gridDim.x);
     const int ktile = id % nkt; id /= nkt;
@@ -434,50 +507,66 @@ __global__ __launch_bounds__(128) void attn_dkdv_bf16_kernel(AttnGeomB g, const 
     load_rows_bf(kreg, k + base, g.st, key0, g.T, lane);
     load_rows_bf(vreg, v + base, g.st, key0, g.T, lane);
     const int key = key0 + r;
-    const bool kok = key < g.T;
+    const float kmask = (key < g.T) ? 1.f : 0.f;
     const float invH = 1.f / (float)g.H;
     const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
     const float* drow = delta + ((int64_t)b * g.H + h) * g.T;
     const float* gbase = HAS_G ? gm + (int64_t)b * gm_sb + min(key, g.T - 1) : nullptr;
+    const int gst = (int)gm_st;
+    TileRegs<128> qr, dr;
+    float lnext = 0.f, dnext = 0.f;
+    tile_gload<128>(qr, q + base, g.st, 0, g.T, tid);
+    tile_gload<128>(dr, d_o + obase, g.ost, 0, g.T, tid);
+    if (tid < 64) { lnext = lrow[min(tid, g.T - 1)]; dnext = drow[min(tid, g.T - 1)]; }
+    ACR_MEMBAR();
+    tile_lstore<128>(qtile[0], qr, 0, g.T, tid);
+    tile_lstore<128>(dotile[0], dr, 0, g.T, tid);
+    if (tid < 64) { l2s[0][tid] = (tid < g.T) ? lnext : INFINITY; dls[0][tid] = (tid < g.T) ? dnext : 0.f; }
+    __syncthreads();
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
-    for (int q0 = 0; q0 < g.T; q0 += 64) {
-        __syncthreads();
-        stage_tile_bf<64, 128>(qtile, q + base, g.st, q0, g.T, tid);
-        stage_tile_bf<64, 128>(dotile, d_o + obase, g.ost, q0, g.T, tid);
-        if (tid < 64) {
-            // queries beyond T get lse = +inf -> p = 0: no per-element guards in the compute loop
-            const bool ok = q0 + tid < g.T;
-            const int qc = min(q0 + tid, g.T - 1);
-            const float lv = lrow[qc], dv_ = drow[qc];
-            l2s[tid] = ok ? lv : INFINITY;
-            dls[tid] = ok ? dv_ : 0.f;
-        }
-        __syncthreads();
+    int cur = 0;
+    for (int q0 = 0; q0 < g.T; q0 += 64, cur ^= 1) {
+        tile_gload<128>(qr, q + base, g.st, q0 + 64, g.T, tid);
+        tile_gload<128>(dr, d_o + obase, g.ost, q0 + 64, g.T, tid);
+        if (tid < 64) { const int qn = min(q0 + 64 + tid, g.T - 1); lnext = lrow[qn]; dnext = drow[qn]; }
+        float gv[2][16];
+        if (HAS_G) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            f32x16 s = {0}, dp = {0};
-            mma_rowop_bf(s, qtile + qb * 32 * BP, kreg, lane);      // S raw [query = krow][key = r]
-            mma_rowop_bf(dp, dotile + qb * 32 * BP, vreg, lane);    // dP
-            float gv[16];
-            if (HAS_G) {
+            for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg)
-                    gv[reg] = gbase[min(q0 + 32 * qb + acr_krow(reg, hh), g.T - 1) * g.T];
-            }
+                    gv[qb][reg] = gbase[min(q0 + 32 * qb + acr_krow(reg, hh), g.T - 1) * gst];
+        }
+        ACR_MEMBAR();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const bf16_t* qtc = qtile[cur] + qb * 32 * BP;
+            const bf16_t* dtc = dotile[cur] + qb * 32 * BP;
+            f32x16 s = {0}, dp = {0};
+            mma_rowop_bf(s, qtc, kreg, lane);               // S raw [query = krow][key = r]
+            mma_rowop_bf(dp, dtc, vreg, lane);              // dP
             f32x16 p, ds;
-            const float kmask = kok ? 1.f : 0.f;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int kr = 32 * qb + acr_krow(reg, hh);
-                const float pv = fast_exp2(fmaf(s[reg], c, -l2s[kr])) * kmask;
+                const float pv = fast_exp2(fmaf(s[reg], c, -l2s[cur][kr])) * kmask;   // lse = +inf beyond T -> 0
                 p[reg] = pv;
-                ds[reg] = pv * (dp[reg] + (HAS_G ? gv[reg] * invH : 0.f) - dls[kr]);
+                ds[reg] = pv * (dp[reg] + (HAS_G ? gv[qb][reg] * invH : 0.f) - dls[cur][kr]);
             }
-            mma_accop_a_bf(dv0, p, dotile + qb * 32 * BP, 0, lane);  // dV[key = krow][d = 32*blk + r]
-            mma_accop_a_bf(dv1, p, dotile + qb * 32 * BP, 1, lane);
-            mma_accop_a_bf(dk0, ds, qtile + qb * 32 * BP, 0, lane);
-            mma_accop_a_bf(dk1, ds, qtile + qb * 32 * BP, 1, lane);
+            mma_accop_a_bf(dv0, p, dtc, 0, lane);           // dV[key = krow][d = 32*blk + r]
+            mma_accop_a_bf(dv1, p, dtc, 1, lane);
+            mma_accop_a_bf(dk0, ds, qtc, 0, lane);
+            mma_accop_a_bf(dk1, ds, qtc, 1, lane);
         }
+        ACR_MEMBAR();
+        tile_lstore<128>(qtile[cur ^ 1], qr, q0 + 64, g.T, tid);
+        tile_lstore<128>(dotile[cur ^ 1], dr, q0 + 64, g.T, tid);
+        if (tid < 64) {
+            const bool ok = q0 + 64 + tid < g.T;
+            l2s[cur ^ 1][tid] = ok ? lnext : INFINITY;
+            dls[cur ^ 1][tid] = ok ? dnext : 0.f;
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -512,30 +601,30 @@ bool acr_bf16_mfma_ok(const acr_attn_desc* d, const void* const* ptrs, int n) {
 }
 
 void acr_attn_fwd_bf16(const acr_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse2,
-                       float* pmean, int64_t pmean_sb, hipStream_t st) {
+                       float* pmean, int64_t pmean_sb, int64_t pmean_st, hipStream_t st) {
     AttnGeomB g = geom_b(d);
     const int nqt = (d->T + 63) / 64;
     hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(d->B * d->H * nqt), dim3(128), 0, st, g, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2);
     if (pmean)
         hipLaunchKernelGGL((attn_tile_qk_bf16_kernel<TQKB_PMEAN>), dim3(d->B * nqt * nqt), dim3(256), 0, st, g,
-                           (const bf16_t*)q, (const bf16_t*)k, (const float*)lse2, pmean, pmean_sb);
+                           (const bf16_t*)q, (const bf16_t*)k, (const float*)lse2, pmean, pmean_sb, pmean_st);
 }
 
 void acr_attn_bwd_bf16(const acr_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
-                       const void* d_o, const float* lse2, const float* gm, int64_t gm_sb, void* dq, void* dk, void* dv,
-                       float* delta, hipStream_t st) {
+                       const void* d_o, const float* lse2, const float* gm, int64_t gm_sb, int64_t gm_st, void* dq, void* dk,
+                       void* dv, float* delta, hipStream_t st) {
     AttnGeomB g = geom_b(d);
     const int nqt = (d->T + 63) / 64;
     const dim3 grid(d->B * d->H * nqt);
 #define ACR_BWD_LAUNCH(HG)                                                                                          \
     hipLaunchKernelGGL((attn_delta_bf16_kernel<HG>), grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,  \
-                       (const bf16_t*)o, (const bf16_t*)d_o, lse2, gm, gm_sb, delta);                                \
+                       (const bf16_t*)o, (const bf16_t*)d_o, lse2, gm, gm_sb, gm_st, delta);                                \
     hipLaunchKernelGGL((attn_dkdv_bf16_kernel<HG>), grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,   \
-                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, (const float*)delta, gm, gm_sb, (bf16_t*)dk,      \
+                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, (const float*)delta, gm, gm_sb, gm_st, (bf16_t*)dk, \
                        (bf16_t*)dv);                                                                                 \
     hipLaunchKernelGGL((attn_dq_bf16_kernel<HG>), grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,     \
-                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, (const float*)delta, gm, gm_sb, (bf16_t*)dq);
+                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, (const float*)delta, gm, gm_sb, gm_st, (bf16_t*)dq);
     if (gm) { ACR_BWD_LAUNCH(true) } else { ACR_BWD_LAUNCH(false) }
 #undef ACR_BWD_LAUNCH
 }
@@ -545,12 +634,12 @@ void acr_attn_probs_bf16(const acr_attn_desc* d, const void* q, const void* k, c
     AttnGeomB g = geom_b(d);
     const int nt = (d->T + 63) / 64;
     hipLaunchKernelGGL((attn_tile_qk_bf16_kernel<TQKB_PROBS>), dim3(d->B * d->H * nt * nt), dim3(256), 0, st, g,
-                       (const bf16_t*)q, (const bf16_t*)k, lse2, probs, (int64_t)0);
+                       (const bf16_t*)q, (const bf16_t*)k, lse2, probs, (int64_t)0, (int64_t)0);
 }
 
 void acr_attn_dprobs_bf16(const acr_attn_desc* d, const void* d_o, const void* v, float* dprobs, hipStream_t st) {
     AttnGeomB g = geom_b(d);
     const int nt = (d->T + 63) / 64;
     hipLaunchKernelGGL((attn_tile_qk_bf16_kernel<TQKB_DPROBS>), dim3(d->B * d->H * nt * nt), dim3(256), 0, st, g,
-                       (const bf16_t*)d_o, (const bf16_t*)v, (const float*)nullptr, dprobs, (int64_t)0);
+                       (const bf16_t*)d_o, (const bf16_t*)v, (const float*)nullptr, dprobs, (int64_t)0, (int64_t)0);
 }

@@ -177,7 +177,7 @@ enum { TQK_PMEAN = 0, TQK_PROBS = 1, TQK_DPROBS = 2 };
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void attn_tile_qk_kernel(AttnGeom g, const T* __restrict__ xq, const T* __restrict__ xk,
                                                            const float* __restrict__ lse2, float* __restrict__ out,
-                                                           int64_t out_sb) {
+                                                           int64_t out_sb, int64_t out_st) {
     __shared__ __attribute__((aligned(16))) float qs[2 * TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float ks[2 * TILE_FLOATS];
     const int nt = (g.T + 63) >> 6;
@@ -224,10 +224,11 @@ __global__ __launch_bounds__(256) void attn_tile_qk_kernel(AttnGeom g, const T* 
         float* ob = (MODE == TQK_PMEAN) ? out + (int64_t)b * out_sb
                                         : out + ((int64_t)b * g.H + hsel) * (int64_t)g.T * g.T;
         const float mul = (MODE == TQK_PMEAN) ? 1.f / (float)g.H : 1.f;
+        const int64_t ost = (MODE == TQK_PMEAN) ? out_st : (int64_t)g.T;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int qq = q0 + wq * 32 + acr_krow(reg, hh);
-            if (qq < g.T) ob[(int64_t)qq * g.T + key] = acc[reg] * mul;
+            if (qq < g.T) ob[(int64_t)qq * ost + key] = acc[reg] * mul;
         }
     }
 }
@@ -239,7 +240,7 @@ template <typename T>
 __global__ __launch_bounds__(128) void attn_delta_kernel(AttnGeom g, const T* __restrict__ q, const T* __restrict__ k,
                                                          const T* __restrict__ o, const T* __restrict__ d_o,
                                                          const float* __restrict__ lse2, const float* __restrict__ gm,
-                                                         int64_t gm_sb, float* __restrict__ delta) {
+                                                         int64_t gm_sb, int64_t gm_st, float* __restrict__ delta) {
     __shared__ __attribute__((aligned(16))) float qs[2 * TILE_FLOATS];
     __shared__ float dsh[64];
     const int nqt = (g.T + 63) >> 6;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(128) void attn_delta_kernel(AttnGeom g, const T* __
             const int qq = q0 + acr_krow(reg, hh);
             const float lv = lrow[min(qq, g.T - 1)];
             l2r[reg] = (qq < g.T) ? lv : INFINITY;          // rows beyond T: p = exp2(-inf) = 0
-            goff[reg] = min(qq, g.T - 1) * g.T;
+            goff[reg] = min(qq, g.T - 1) * (int)gm_st;
         }
         __syncthreads();
         const float* grow = gm + (int64_t)b * gm_sb;
@@ -321,7 +322,8 @@ template <typename T>
 __global__ __launch_bounds__(128) void attn_dq_kernel(AttnGeom g, const T* __restrict__ q, const T* __restrict__ k,
                                                       const T* __restrict__ v, const T* __restrict__ d_o,
                                                       const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                      const float* __restrict__ gm, int64_t gm_sb, T* __restrict__ dq) {
+                                                      const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
+                                                      T* __restrict__ dq) {
     __shared__ __attribute__((aligned(16))) float kt[TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float vt[TILE_FLOATS];
     const int nqt = (g.T + 63) >> 6;
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(128) void attn_dq_kernel(AttnGeom g, const T* __res
     const float l2 = qok ? lse2[((int64_t)b * g.H + h) * g.T + q0 + r] : 0.f;
     const float dl = qok ? delta[((int64_t)b * g.H + h) * g.T + q0 + r] : 0.f;
     const float invH = 1.f / (float)g.H;
-    const float* grow = gm ? gm + (int64_t)b * gm_sb + (int64_t)min(q0 + r, g.T - 1) * g.T : nullptr;
+    const float* grow = gm ? gm + (int64_t)b * gm_sb + (int64_t)min(q0 + r, g.T - 1) * gm_st : nullptr;
     f32x16 dq0 = {0}, dq1 = {0};
     for (int k0 = 0; k0 < g.T; k0 += 32) {
         __syncthreads();
@@ -387,7 +389,7 @@ template <typename T>
 __global__ __launch_bounds__(128) void attn_dkdv_kernel(AttnGeom g, const T* __restrict__ q, const T* __restrict__ k,
                                                         const T* __restrict__ v, const T* __restrict__ d_o,
                                                         const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                        const float* __restrict__ gm, int64_t gm_sb,
+                                                        const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
                                                         T* __restrict__ dk, T* __restrict__ dv) {
     __shared__ __attribute__((aligned(16))) float qtile[TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float dotile[TILE_FLOATS];
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(128) void attn_dkdv_kernel(AttnGeom g, const T* __r
         for (int reg = 0; reg < 16; ++reg) gv[reg] = 0.f;
         if (gbase) {                                       // uniform branch; loads inside are unconditional (clamped)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) gv[reg] = gbase[min(q0 + acr_krow(reg, hh), g.T - 1) * g.T] * invH;
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = gbase[min(q0 + acr_krow(reg, hh), g.T - 1) * (int)gm_st] * invH;
         }
         f32x16 p, ds;
         const float kmask = kok ? 1.f : 0.f;
@@ -517,10 +519,10 @@ __global__ __launch_bounds__(64) void getam_row_kernel(AttnGeom g, const T* __re
 // bf16-MFMA launchers (attn_bf16.hip)
 bool acr_bf16_mfma_ok(const acr_attn_desc* d, const void* const* ptrs, int n);
 void acr_attn_fwd_bf16(const acr_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse2,
-                       float* pmean, int64_t pmean_sb, hipStream_t st);
+                       float* pmean, int64_t pmean_sb, int64_t pmean_st, hipStream_t st);
 void acr_attn_bwd_bf16(const acr_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
-                       const void* d_o, const float* lse2, const float* gm, int64_t gm_sb, void* dq, void* dk, void* dv,
-                       float* delta, hipStream_t st);
+                       const void* d_o, const float* lse2, const float* gm, int64_t gm_sb, int64_t gm_st, void* dq, void* dk,
+                       void* dv, float* delta, hipStream_t st);
 void acr_attn_probs_bf16(const acr_attn_desc* d, const void* q, const void* k, const float* lse2, float* probs,
                          hipStream_t st);
 void acr_attn_dprobs_bf16(const acr_attn_desc* d, const void* d_o, const void* v, float* dprobs, hipStream_t st);
@@ -548,19 +550,19 @@ static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7
 
 template <typename T>
 static int attn_fwd_t(const acr_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse2,
-                      float* pmean, int64_t pmean_sb, hipStream_t st) {
+                      float* pmean, int64_t pmean_sb, int64_t pmean_st, hipStream_t st) {
     AttnGeom g = geom(d);
     const int nqt = (d->T + 63) / 64;
     hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(d->B * d->H * nqt), dim3(128), 0, st, g, (const T*)q, (const T*)k,
                        (const T*)v, (T*)o, lse2);
     if (pmean)
         hipLaunchKernelGGL((attn_tile_qk_kernel<T, TQK_PMEAN>), dim3(d->B * nqt * nqt), dim3(256), 0, st, g,
-                           (const T*)q, (const T*)k, (const float*)lse2, pmean, pmean_sb);
+                           (const T*)q, (const T*)k, (const float*)lse2, pmean, pmean_sb, pmean_st);
     return acr_check_launch("acr_attn_fwd");
 }
 
 extern "C" int acr_attn_fwd(const acr_attn_desc* d, const void* q, const void* k, const void* v, void* o,
-                            float* lse2, float* pmean, int64_t pmean_sb, void* stream) {
+                            float* lse2, float* pmean, int64_t pmean_sb, int64_t pmean_st, void* stream) {
     int rc = check_desc(d, "acr_attn_fwd");
     if (rc) return rc;
     ACR_CHECK_ARG(q && k && v && o && lse2, "acr_attn_fwd: null pointer");
@@ -568,50 +570,57 @@ extern "C" int acr_attn_fwd(const acr_attn_desc* d, const void* q, const void* k
     ACR_CHECK_ARG(f32 ? (aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o))
                       : (aligned8(q) && aligned8(k) && aligned8(v) && aligned8(o)),
                   "acr_attn_fwd: q/k/v/o must be 16-byte (fp32) / 8-byte (bf16) aligned");
-    ACR_CHECK_ARG(!pmean || pmean_sb >= (int64_t)d->T * d->T, "acr_attn_fwd: pmean batch stride < T*T");
-    if (f32) return attn_fwd_t<float>(d, q, k, v, o, lse2, pmean, pmean_sb, (hipStream_t)stream);
+    ACR_CHECK_ARG(!pmean || (pmean_st >= d->T && pmean_sb >= (int64_t)d->T * pmean_st),
+                  "acr_attn_fwd: pmean row pitch < T or batch stride < T*pitch");
+    if (f32) return attn_fwd_t<float>(d, q, k, v, o, lse2, pmean, pmean_sb, pmean_st, (hipStream_t)stream);
     const void* ptrs[4] = {q, k, v, o};
     if (d->dtype == ACR_BF16 && acr_bf16_mfma_ok(d, ptrs, 4)) {
-        acr_attn_fwd_bf16(d, q, k, v, o, lse2, pmean, pmean_sb, (hipStream_t)stream);
+        acr_attn_fwd_bf16(d, q, k, v, o, lse2, pmean, pmean_sb, pmean_st, (hipStream_t)stream);
         return acr_check_launch("acr_attn_fwd");
     }
-    return attn_fwd_t<__bf16>(d, q, k, v, o, lse2, pmean, pmean_sb, (hipStream_t)stream);
+    return attn_fwd_t<__bf16>(d, q, k, v, o, lse2, pmean, pmean_sb, pmean_st, (hipStream_t)stream);
 }
 
 template <typename T>
 static int attn_bwd_t(const acr_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
-                      const void* d_o, const float* lse2, const float* gm, int64_t gm_sb, void* dq, void* dk,
-                      void* dv, float* delta, hipStream_t st) {
+                      const void* d_o, const float* lse2, const float* gm, int64_t gm_sb, int64_t gm_st, void* dq,
+                      void* dk, void* dv, float* delta, hipStream_t st) {
     AttnGeom g = geom(d);
     const int nqt = (d->T + 63) / 64;
     const dim3 grid(d->B * d->H * nqt);
     hipLaunchKernelGGL((attn_delta_kernel<T>), grid, dim3(128), 0, st, g, (const T*)q, (const T*)k, (const T*)o,
-                       (const T*)d_o, lse2, gm, gm_sb, delta);
+                       (const T*)d_o, lse2, gm, gm_sb, gm_st, delta);
     hipLaunchKernelGGL((attn_dkdv_kernel<T>), grid, dim3(128), 0, st, g, (const T*)q, (const T*)k, (const T*)v,
-                       (const T*)d_o, lse2, (const float*)delta, gm, gm_sb, (T*)dk, (T*)dv);
+                       (const T*)d_o, lse2, (const float*)delta, gm, gm_sb, gm_st, (T*)dk, (T*)dv);
     hipLaunchKernelGGL((attn_dq_kernel<T>), grid, dim3(128), 0, st, g, (const T*)q, (const T*)k, (const T*)v,
-                       (const T*)d_o, lse2, (const float*)delta, gm, gm_sb, (T*)dq);
+                       (const T*)d_o, lse2, (const float*)delta, gm, gm_sb, gm_st, (T*)dq);
     return acr_check_launch("acr_attn_bwd");
 }
 
 extern "C" int acr_attn_bwd(const acr_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
-                            const void* d_o, const float* lse2, const float* gmean, int64_t gmean_sb, void* dq,
-                            void* dk, void* dv, float* delta_ws, void* stream) {
+                            const void* d_o, const float* lse2, const float* gmean, int64_t gmean_sb, int64_t gmean_st,
+                            void* dq, void* dk, void* dv, float* delta_ws, void* stream) {
     int rc = check_desc(d, "acr_attn_bwd");
     if (rc) return rc;
     ACR_CHECK_ARG(q && k && v && o && d_o && lse2 && dq && dk && dv && delta_ws, "acr_attn_bwd: null pointer");
-    ACR_CHECK_ARG(!gmean || gmean_sb >= (int64_t)d->T * d->T, "acr_attn_bwd: gmean batch stride < T*T");
+    ACR_CHECK_ARG(!gmean || (gmean_st >= d->T && gmean_sb >= (int64_t)d->T * gmean_st),
+                  "acr_attn_bwd: gmean row pitch < T or batch stride < T*pitch");
     const bool f32 = d->dtype == ACR_F32;
     ACR_CHECK_ARG(f32 ? (aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(d_o))
                       : (aligned8(q) && aligned8(k) && aligned8(v) && aligned8(o) && aligned8(d_o)),
                   "acr_attn_bwd: inputs must be 16-byte (fp32) / 8-byte (bf16) aligned");
-    if (f32) return attn_bwd_t<float>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, dq, dk, dv, delta_ws, (hipStream_t)stream);
+    if (f32)
+        return attn_bwd_t<float>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, gmean_st, dq, dk, dv, delta_ws, (hipStream_t)stream);
     const void* ptrs[8] = {q, k, v, o, d_o, dq, dk, dv};
-    if (d->dtype == ACR_BF16 && acr_bf16_mfma_ok(d, ptrs, 8)) {
-        acr_attn_bwd_bf16(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, dq, dk, dv, delta_ws, (hipStream_t)stream);
+    // the bf16-MFMA dQ kernel pulls G in 16-byte groups: it needs a row pitch that is a multiple of 4 floats and
+    // covers roundup4(T); other layouts take the exact-fp32 kernels (still HIP, any pitch)
+    const bool g_ok = !gmean || ((gmean_st & 3) == 0 && gmean_st >= ((d->T + 3) & ~3) && (gmean_sb & 3) == 0 &&
+                                 (reinterpret_cast<uintptr_t>(gmean) & 15) == 0);
+    if (d->dtype == ACR_BF16 && g_ok && acr_bf16_mfma_ok(d, ptrs, 8)) {
+        acr_attn_bwd_bf16(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, gmean_st, dq, dk, dv, delta_ws, (hipStream_t)stream);
         return acr_check_launch("acr_attn_bwd");
     }
-    return attn_bwd_t<__bf16>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, dq, dk, dv, delta_ws, (hipStream_t)stream);
+    return attn_bwd_t<__bf16>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, gmean_st, dq, dk, dv, delta_ws, (hipStream_t)stream);
 }
 
 extern "C" int acr_attn_probs(const acr_attn_desc* d, const void* q, const void* k, const float* lse2, float* probs,
@@ -626,12 +635,12 @@ extern "C" int acr_attn_probs(const acr_attn_desc* d, const void* q, const void*
     const void* pp[2] = {q, k};
     if (d->dtype == ACR_F32)
         hipLaunchKernelGGL((attn_tile_qk_kernel<float, TQK_PROBS>), grid, dim3(256), 0, (hipStream_t)stream, g,
-                           (const float*)q, (const float*)k, lse2, probs, (int64_t)0);
+                           (const float*)q, (const float*)k, lse2, probs, (int64_t)0, (int64_t)0);
     else if (d->dtype == ACR_BF16 && acr_bf16_mfma_ok(d, pp, 2))
         acr_attn_probs_bf16(d, q, k, lse2, probs, (hipStream_t)stream);
     else
         hipLaunchKernelGGL((attn_tile_qk_kernel<__bf16, TQK_PROBS>), grid, dim3(256), 0, (hipStream_t)stream, g,
-                           (const __bf16*)q, (const __bf16*)k, lse2, probs, (int64_t)0);
+                           (const __bf16*)q, (const __bf16*)k, lse2, probs, (int64_t)0, (int64_t)0);
     return acr_check_launch("acr_attn_probs");
 }
 
@@ -646,12 +655,12 @@ extern "C" int acr_attn_dprobs(const acr_attn_desc* d, const void* d_o, const vo
     const void* pp[2] = {d_o, v};
     if (d->dtype == ACR_F32)
         hipLaunchKernelGGL((attn_tile_qk_kernel<float, TQK_DPROBS>), grid, dim3(256), 0, (hipStream_t)stream, g,
-                           (const float*)d_o, (const float*)v, (const float*)nullptr, dprobs, (int64_t)0);
+                           (const float*)d_o, (const float*)v, (const float*)nullptr, dprobs, (int64_t)0, (int64_t)0);
     else if (d->dtype == ACR_BF16 && acr_bf16_mfma_ok(d, pp, 2))
         acr_attn_dprobs_bf16(d, d_o, v, dprobs, (hipStream_t)stream);
     else
         hipLaunchKernelGGL((attn_tile_qk_kernel<__bf16, TQK_DPROBS>), grid, dim3(256), 0, (hipStream_t)stream, g,
-                           (const __bf16*)d_o, (const __bf16*)v, (const float*)nullptr, dprobs, (int64_t)0);
+                           (const __bf16*)d_o, (const __bf16*)v, (const float*)nullptr, dprobs, (int64_t)0, (int64_t)0);
     return acr_check_launch("acr_attn_dprobs");
 }
 

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void cons_reduce_kernel(const float* __restric
 __global__ __launch_bounds__(CONS_THREADS) void cons_bwd_kernel(
         const float* __restrict__ a1, const float* __restrict__ a2, int64_t a_sb,
         int L, int T, int p, int64_t rows, const float* __restrict__ gout2,
-        float w_cls, float w_aff, float* __restrict__ g1, float* __restrict__ g2, int64_t g_sb) {
+        float w_cls, float w_aff, float* __restrict__ g1, float* __restrict__ g2, int64_t g_sb, int64_t g_st) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int N = T - 1;
     const float inv_p = 1.0f / (float)p;
@@ -106,14 +106,15 @@ __global__ __launch_bounds__(CONS_THREADS) void cons_bwd_kernel(
         const int l = (int)(bl % L);
         const int64_t b = bl / L;
         const int64_t abase = b * a_sb + (int64_t)l * TT;
-        const int64_t gbase = b * g_sb + (int64_t)l * TT;
+        const int64_t gbase = b * g_sb + (int64_t)l * T * g_st;
         const int i2 = (i == 0) ? 0 : 1 + flip_index(i - 1, p, inv_p);
         const float* r1 = a1 + abase + (int64_t)i * T + 1;
         const float* r2 = a2 + abase + (int64_t)i2 * T + 1;
-        float* o1 = g1 + gbase + (int64_t)i * T;
-        float* o2 = g2 + gbase + (int64_t)i2 * T;
+        float* o1 = g1 + gbase + (int64_t)i * g_st;
+        float* o2 = g2 + gbase + (int64_t)i2 * g_st;
         const float w = (i == 0) ? gc : ga;
         if (lane == 0) { o1[0] = 0.f; o2[0] = 0.f; }            // column 0 is never looked at
+        if (lane < (int)g_st - T) { o1[T + lane] = 0.f; o2[T + lane] = 0.f; }   // pad columns of the pitch (<= 3 here)
         for (int c = lane; c < N; c += 64) {
             const int c2 = flip_index(c, p, inv_p);
             const float d = r1[c] - r2[c2];
@@ -141,15 +142,16 @@ extern "C" int acr_consistency_fwd(const float* a1, const float* a2, int64_t a_s
 
 extern "C" int acr_consistency_bwd(const float* a1, const float* a2, int64_t a_sb, int32_t B, int32_t L,
                                    int32_t T, int32_t p, const float* gout2, float* g1, float* g2,
-                                   int64_t g_sb, void* stream) {
+                                   int64_t g_sb, int64_t g_st, void* stream) {
     ACR_CHECK_ARG(a1 && a2 && gout2 && g1 && g2, "acr_consistency_bwd: null pointer");
     ACR_CHECK_ARG(B > 0 && L > 0 && p > 0 && T == p * p + 1, "acr_consistency_bwd: need T == p*p+1 (T=%d p=%d)", T, p);
-    ACR_CHECK_ARG(a_sb >= (int64_t)L * T * T && g_sb >= (int64_t)L * T * T, "acr_consistency_bwd: batch stride < L*T*T");
+    ACR_CHECK_ARG(a_sb >= (int64_t)L * T * T && g_st >= T && g_st < T + 64 && g_sb >= (int64_t)L * T * g_st,
+                  "acr_consistency_bwd: batch stride / row pitch too small");
     const int64_t rows = (int64_t)B * L * T;
     const int nb = cons_blocks(rows);
     const double n = (double)(T - 1);
     hipLaunchKernelGGL(cons_bwd_kernel, dim3(nb), dim3(CONS_THREADS), 0, (hipStream_t)stream, a1, a2, a_sb, L, T, p,
                        rows, gout2, (float)(1.0 / ((double)B * L * n)), (float)(1.0 / ((double)B * L * n * n)),
-                       g1, g2, g_sb);
+                       g1, g2, g_sb, g_st);
     return acr_check_launch("acr_consistency_bwd");
 }

@@ -11,6 +11,11 @@ from . import _lib as L
 HEAD_DIM = 64
 
 
+def pad4(n):
+    """Row pitch (floats) of gradient maps: T rounded up to 16 bytes so kernels can use vector loads."""
+    return (n + 3) & ~3
+
+
 def _desc(B, H, T, dtype, packed_qkv=True):
     """Descriptor for q/k/v aliasing slices of the packed qkv Linear output (B,T,3,H,64) and o / do in
     the reference's (B,T,H*64) activation layout (models/vision_transformer.py:200-201,211)."""
@@ -63,7 +68,8 @@ class AttnCoreFn(Function):
             pm = stack.buf[:, layer]
         qp, kp, vp = _qkv_ptrs(qkv, heads)
         L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm),
-                                 stack.buf.stride(0) if stack is not None else 0, L.stream_ptr()), "acr_attn_fwd")
+                                 pm.stride(0) if pm is not None else 0, pm.stride(1) if pm is not None else 0,
+                                 L.stream_ptr()), "acr_attn_fwd")
         ctx.save_for_backward(qkv, o, lse2)
         ctx.heads = heads
         ctx.owner = owner
@@ -86,17 +92,23 @@ class AttnCoreFn(Function):
             d_o = d_o.contiguous()
         if d_o.dtype != qkv.dtype:
             d_o = d_o.to(qkv.dtype)
-        gm_sb = 0
+        gm_sb = gm_st = 0
         if g_pm is not None:
-            if g_pm.dtype != torch.float32 or g_pm.stride(2) != 1 or g_pm.stride(1) != T:
-                g_pm = g_pm.float().contiguous()
-            gm_sb = g_pm.stride(0)
+            # kernels want fp32 rows with a pitch that is a multiple of 4 floats (16-byte groups); the fused loss
+            # (ConsistencyFn.backward) delivers exactly that, anything else is re-laid-out once here
+            ok = (g_pm.dtype == torch.float32 and g_pm.stride(2) == 1 and g_pm.stride(1) % 4 == 0
+                  and g_pm.stride(1) >= pad4(T) and g_pm.stride(0) % 4 == 0 and g_pm.data_ptr() % 16 == 0)
+            if not ok:
+                buf = torch.zeros((B, T, pad4(T)), dtype=torch.float32, device=qkv.device)
+                buf[:, :, :T].copy_(g_pm)
+                g_pm = buf[:, :, :T]
+            gm_sb, gm_st = g_pm.stride(0), g_pm.stride(1)
         d = _desc(B, heads, T, qkv.dtype)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device)
         qp, kp, vp = _qkv_ptrs(qkv, heads)
         dqp, dkp, dvp = _qkv_ptrs(dqkv, heads)
-        L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(g_pm), gm_sb,
+        L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(g_pm), gm_sb, gm_st,
                                  dqp, dkp, dvp, L.ptr(delta), L.stream_ptr()), "acr_attn_bwd")
         if ctx.owner is not None:
             ctx.owner._saved_do = d_o
@@ -180,10 +192,12 @@ class ConsistencyFn(Function):
         B = B2 // 2
         lib = L.load()
         gout = gout.contiguous().float()
-        g = torch.empty((B2, Ly, T, T), dtype=torch.float32, device=a.device)
+        # gradient stack with a 16-byte-aligned row pitch; what autograd sees is the [..., :T] view of it
+        g = torch.empty((B2, Ly, T, pad4(T)), dtype=torch.float32, device=a.device)
         L.check(lib.acr_consistency_bwd(L.ptr(a[:B]), L.ptr(a[B:]), a.stride(0), B, Ly, T, ctx.p, L.ptr(gout),
-                                        L.ptr(g[:B]), L.ptr(g[B:]), g.stride(0), L.stream_ptr()), "acr_consistency_bwd")
-        return g, None
+                                        L.ptr(g[:B]), L.ptr(g[B:]), g.stride(0), g.stride(2), L.stream_ptr()),
+                "acr_consistency_bwd")
+        return g[..., :T], None
 
 
 def consistency(a, p, a2=None):

@@ -74,7 +74,7 @@ def roofline_probe(args, dev):
     g = torch.Generator(device="cpu").manual_seed(0)
     qkv = torch.randn(B, T, 3 * H * 64, generator=g).to(dev).to(dt)
     d_o = torch.randn(B, T, H * 64, generator=g).to(dev).to(dt)
-    gm = torch.randn(B, T, T, generator=g).to(dev) * 1e-3
+    gm = (torch.randn(B, T, ops.pad4(T), generator=g).to(dev) * 1e-3)[:, :, :T]
     o = torch.empty(B, T, H * 64, dtype=dt, device=dev)
     lse2 = torch.empty(B, H, T, dtype=torch.float32, device=dev)
     pm = torch.empty(B, T, T, dtype=torch.float32, device=dev)
@@ -86,10 +86,10 @@ def roofline_probe(args, dev):
     st = L.stream_ptr()
 
     def fwd():
-        L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm), T * T, st), "fwd")
+        L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm), T * T, T, st), "fwd")
 
     def bwd():
-        L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(gm), T * T, dqp, dkp, dvp,
+        L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(gm), gm.stride(0), gm.stride(1), dqp, dkp, dvp,
                                  L.ptr(delta), st), "bwd")
 
     t_fwd = time_kernel(fwd)

@@ -62,18 +62,18 @@ const char* acr_last_error(void);
 /* ---- attention (models/vision_transformer.py:198-214 `Attention.forward`, minus the two Linears) ----
  * O = softmax(q k^T * scale) v without materialising P.  lse2 (B,H,T) fp32 receives the row
  * log-sum-exp in base-2 units of the scaled logits: P[b,h,i,j] = exp2(s2 - lse2), s2 = q.k*scale*log2(e).
- * If pmean != NULL it receives mean_h P (B,T,T) fp32 with batch stride pmean_sb and row stride T:
- * the per-layer slice of the (B,L,T,T) stack DPT/ACR.py:107-112 builds with 12 mean kernels + stack. */
+ * If pmean != NULL it receives mean_h P (B,T,T) fp32 with batch stride pmean_sb and row pitch pmean_st
+ * (>= T): the per-layer slice of the (B,L,T,T) stack DPT/ACR.py:107-112 builds with 12 mean kernels + stack. */
 int acr_attn_fwd(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
-                 void* o, float* lse2, float* pmean, int64_t pmean_sb, void* stream);
+                 void* o, float* lse2, float* pmean, int64_t pmean_sb, int64_t pmean_st, void* stream);
 
 /* Backward of acr_attn_fwd.  gmean (nullable) is dLoss/d(mean_h P), (B,T,T) fp32, batch stride
- * gmean_sb, row stride T (what autograd delivers to the `torch.mean(attn, dim=1)` node of
- * DPT/ACR.py:109).  dP_h = dO_h V_h^T + gmean/H.  delta_ws: caller-owned (B,H,T) fp32 scratch.
+ * gmean_sb, row pitch gmean_st >= T (what autograd delivers to the `torch.mean(attn, dim=1)` node of
+ * DPT/ACR.py:109; a pitch that is a multiple of 4 floats lets the bf16 kernels pull it in 16-byte groups).  dP_h = dO_h V_h^T + gmean/H.  delta_ws: caller-owned (B,H,T) fp32 scratch.
  * dq/dk/dv use the q/k/v strides (they may alias slices of one packed (B,T,3,H,d) buffer). */
 int acr_attn_bwd(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
                  const void* o, const void* d_o, const float* lse2,
-                 const float* gmean, int64_t gmean_sb,
+                 const float* gmean, int64_t gmean_sb, int64_t gmean_st,
                  void* dq, void* dk, void* dv, float* delta_ws, void* stream);
 
 /* Materialise per-head maps for API compatibility with `Attention.get_attn()` /
@@ -96,10 +96,11 @@ size_t acr_consistency_ws_floats(int32_t B, int32_t L, int32_t T);
 int acr_consistency_fwd(const float* a1, const float* a2, int64_t a_sb, int32_t B, int32_t L,
                         int32_t T, int32_t p, float* partial_ws, float* out2, void* stream);
 /* gout2: device pointer to the two upstream gradients (d/d out[0], d/d out[1]).  Writes
- * g1, g2 (same geometry as a1, a2; every element written, zeros where the loss does not look). */
+ * g1, g2: (B,L,T,g_st) with row pitch g_st >= T and batch stride g_sb >= L*T*g_st; every element of
+ * the T x T maps is written (zeros where the loss does not look); pad columns are left untouched. */
 int acr_consistency_bwd(const float* a1, const float* a2, int64_t a_sb, int32_t B, int32_t L,
                         int32_t T, int32_t p, const float* gout2, float* g1, float* g2,
-                        int64_t g_sb, void* stream);
+                        int64_t g_sb, int64_t g_st, void* stream);
 
 /* ---- GETAM (DPT/ACR.py:177-215 `ACR.getam`) ----
  * Adds one layer's contribution to cam_row (T fp32, caller zero-initialised):
