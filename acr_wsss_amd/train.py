@@ -55,6 +55,51 @@ class PolyOptimizer(torch.optim.SGD):
         self.global_step += 1
 
 
+class MasterWeights:
+    """bf16 model, fp32 master weights: the MI355X training precision of this build.
+
+    The module's parameters (and therefore every activation, gradient and gradient all-reduce) are bf16; the
+    optimizer -- the reference's PolyOptimizer, quirk included -- runs on fp32 master copies, which are cast
+    back into the module after every step.  Compared with autocast this removes the fp32<->bf16 cast kernels
+    around every Linear / norm and halves the elementwise and RCCL bytes.  ``optimizer_factory(params)`` must
+    build the optimizer over the list of fp32 masters it is given."""
+
+    def __init__(self, model, optimizer_factory):
+        self.model_params = [p for p in model.parameters() if p.requires_grad]
+        self.masters = [p.detach().float().clone() for p in self.model_params]
+        for m in self.masters:
+            m.requires_grad_(True)
+        for p in self.model_params:
+            p.data = p.data.to(torch.bfloat16)
+        for b in model.buffers():
+            if b.is_floating_point():
+                b.data = b.data.to(torch.bfloat16)
+        self.optimizer = optimizer_factory(self.masters)
+        self.param_groups = self.optimizer.param_groups
+
+    @property
+    def global_step(self):
+        return self.optimizer.global_step
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.model_params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        live = [(m, p) for m, p in zip(self.masters, self.model_params) if p.grad is not None]
+        for m, _ in live:
+            if m.grad is None:
+                m.grad = torch.empty_like(m)
+        for m, p in zip(self.masters, self.model_params):
+            if p.grad is None:
+                m.grad = None
+        if live:
+            torch._foreach_copy_([m.grad for m, _ in live], [p.grad for _, p in live])
+        self.optimizer.step()
+        torch._foreach_copy_([p for p in self.model_params], self.masters)
+
+
 def train_step(model, optimizer, img, label, alpha, grad_sync=None, amp_dtype=None):
     """One iteration of train_acr.py:127-174: view 2 = h-flip, forward_mirror, ACR loss, backward, SGD step.
 

@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("ACR_BENCH_DTYPE", "f32"))
     ap.add_argument("--classes", type=int, default=20)
     ap.add_argument("--alpha", type=int, default=125)
+    ap.add_argument("--amp", choices=["master", "autocast"], default="master",
+                    help="bf16 mode: bf16 model + fp32 master weights (default) or torch.autocast")
+    ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -176,17 +179,25 @@ def main():
     torch.cuda.set_device(dev)
 
     from acr_wsss_amd.DPT.ACR import ACR
-    from acr_wsss_amd.train import PolyOptimizer, train_step
+    from acr_wsss_amd.train import MasterWeights, PolyOptimizer, train_step
     from acr_wsss_amd.dp import GradSync, broadcast_parameters
 
     torch.manual_seed(0)
-    model = ACR(num_classes=args.classes, backbone_name="vitb_hybrid", use_pretrain=False).to(dev)
+    model = ACR(num_classes=args.classes, backbone_name="vitb_hybrid", use_pretrain=False,
+                channels_last=args.channels_last).to(dev)
+    if args.channels_last:
+        model = model.to(memory_format=torch.channels_last)
     model.train()
     broadcast_parameters(model)
-    sync = GradSync(model.parameters()) if world > 1 else None
-    opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=100000)
     img, label = make_batch(args.batch, args.size, args.classes, rank, dev)
-    amp = torch.bfloat16 if args.dtype == "bf16" else None
+    amp = None
+    if args.dtype == "bf16" and args.amp == "master":
+        opt = MasterWeights(model, lambda ps: PolyOptimizer(ps, lr=0.05, weight_decay=5e-4, max_step=100000))
+        img = img.to(torch.bfloat16)
+    else:
+        opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=100000)
+        amp = torch.bfloat16 if args.dtype == "bf16" else None
+    sync = GradSync(model.parameters()) if world > 1 else None
 
     def step():
         return train_step(model, opt, img, label, args.alpha, grad_sync=sync, amp_dtype=amp)
@@ -221,6 +232,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "precision": ("bf16 params/activations/grads, fp32 master weights + fp32 softmax/loss" if (args.dtype == "bf16" and args.amp == "master")
+                          else ("torch.autocast(bf16)" if args.dtype == "bf16" else "fp32 end to end (reference precision)")),
             "config": {"workload": "BASELINE configs[1]: ViT-hybrid-base (DPT) %dx%d, batch %d per GPU, ACR train step "
                                    "(2 views, fwd+bwd+SGD)" % (args.size, args.size, args.batch),
                        "global_batch": args.batch * world, "classes": args.classes, "alpha": args.alpha,
