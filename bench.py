@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU (BASELINE configs[1]: 16)")
     ap.add_argument("--size", type=int, default=448)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("ACR_BENCH_DTYPE", "f32"))
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("ACR_BENCH_DTYPE", "bf16"))
     ap.add_argument("--classes", type=int, default=20)
     ap.add_argument("--alpha", type=int, default=125)
     ap.add_argument("--amp", choices=["master", "autocast"], default="master",
