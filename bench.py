@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--probe-only", action="store_true", help="run only the kernel roofline probe (for rocprofv3 --pmc passes)")
     return ap.parse_args()
 
 
@@ -112,9 +113,18 @@ def roofline_probe(args, dev):
     k3_bytes = 4.0 * B * Lyr * T * T
     peak = PEAK_MFMA[args.dtype] if args.dtype == "f32" else PEAK_MFMA["bf16"]
     ach = fl_bwd / t_bwd / 1e12
+    # HBM traffic of the same launches from the committed rocprofv3 PMC passes (bench.py --probe-only under
+    # --pmc FETCH_SIZE / --pmc WRITE_SIZE, gfx950 x2 fetch correction applied); only valid for the default geometry
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            if args.dtype == "bf16" and args.batch == 16 and args.size == 448:
+                traffic = json.load(f)["acr_attn_bwd_bytes_per_launch"]
+    except OSError:
+        pass
     return {
         "bound": "mfma", "kernel": "acr_attn_bwd (delta + dkdv + dq)", "achieved": round(ach, 2),
-        "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / (peak / 1e12), 4), "traffic": None,
+        "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / (peak / 1e12), 4), "traffic": traffic,
         "launch_ms": round(t_bwd * 1e3, 3), "flops_per_launch": fl_bwd,
         "attn_fwd": {"achieved": round(fl_fwd / t_fwd / 1e12, 2), "launch_ms": round(t_fwd * 1e3, 3)},
         "consistency_fwd": {"bound": "hbm", "achieved": round(k3_bytes / t_k3 / 1e9, 1), "peak": 8000.0,
@@ -177,6 +187,9 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if args.probe_only:
+        print(json.dumps(roofline_probe(args, dev)), flush=True)
+        return
 
     from acr_wsss_amd.DPT.ACR import ACR
     from acr_wsss_amd.train import MasterWeights, PolyOptimizer, train_step
