@@ -1,0 +1,81 @@
+"""Data-parallel training step on the GPU: two ranks (sharing cuda:0, collectives over gloo -- RCCL needs one
+GPU per rank) each run acr_wsss_amd.train.train_step on half of a batch with GradSync; replicas must stay
+identical and match a single process stepping on the whole batch."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build():
+    from acr_wsss_amd.DPT.ACR import ACR
+    torch.manual_seed(3)
+    m = ACR(num_classes=20, backbone_name="vit_tiny", use_pretrain=False).to("cuda:0")
+    with torch.no_grad():                                  # sharper attention than the 0.02-std init
+        for blk in m.pretrained.model.blocks:
+            blk.attn.qkv.weight.mul_(8.0)
+    return m
+
+
+def _batch():
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(4, 3, 64, 64, generator=g)
+    label = (torch.rand(4, 20, generator=g) > 0.7).float()
+    return img, label
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from acr_wsss_amd.dp import GradSync, broadcast_parameters
+    from acr_wsss_amd.train import PolyOptimizer, train_step
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _build()
+    if rank == 1:
+        with torch.no_grad():
+            model.cls_head.weight.add_(1.0)                # must be overwritten by the broadcast
+    broadcast_parameters(model, 0)
+    sync = GradSync(model.parameters(), bucket_mb=4)
+    opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=10)
+    img, label = _batch()
+    sl = slice(rank * 2, rank * 2 + 2)
+    for _ in range(2):
+        loss, _ = train_step(model, opt, img[sl].cuda(), label[sl].cuda(), 125, grad_sync=sync)
+    out[rank] = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])
+    out["nb"] = len(sync.buckets)
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_step_matches_single_process():
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out["nb"] >= 2
+    torch.testing.assert_close(out[0], out[1], rtol=0, atol=0)
+    from acr_wsss_amd.train import PolyOptimizer, train_step
+    model = _build()
+    opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=10)
+    img, label = _batch()
+    for _ in range(2):
+        train_step(model, opt, img.cuda(), label.cuda(), 125)
+    ref = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])
+    # sign() gradients of the L1 terms make the comparison tolerant, not exact: a 2-sample shard and the 4-sample
+    # batch reduce in different orders
+    diff = (out[0] - ref).abs()
+    assert diff.max() <= 2e-3 * ref.abs().max() and diff.mean() <= 1e-5 * ref.abs().max(), (diff.max(), diff.mean())
