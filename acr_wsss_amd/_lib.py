@@ -44,6 +44,8 @@ SIGNATURES = {
                                       c_void_p, c_void_p]),
     "acr_consistency_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                       c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "acr_linear_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                  c_int32, c_int32, c_int32, c_void_p]),
     "acr_getam_row_accum": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       c_void_p, c_void_p]),
     "acr_aff_refine": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),

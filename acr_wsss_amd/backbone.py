@@ -184,11 +184,15 @@ class Attention(nn.Module):
         self._override = {}
         self.last_pm = None         # (B,T,T) head-mean map of the last forward (slice of the MeanStack)
 
-    def forward(self, x, stack=None, layer=0):
+    hip_linear = True       # bf16 mode: qkv / proj on the hand-written MFMA GEMM (acr_linear_bf16)
+
+    def forward(self, x, stack=None, layer=0, resid=None):
+        """Returns proj(attention(qkv(x))) (+ resid when given: the block's residual add is fused into the
+        proj GEMM epilogue on the bf16 path)."""
         self._override = {}
-        qkv = self.qkv(x)                                           # packed (B, T, 3*H*64): no permute copy
+        qkv = ops.linear_or_hip(x, self.qkv, None, self.hip_linear)  # packed (B, T, 3*H*64): no permute copy
         o, self.last_pm = ops.attention_core(qkv, self.num_heads, stack, layer, self)
-        return self.proj(o)
+        return ops.linear_or_hip(o, self.proj, resid, self.hip_linear)
 
     # -- reference state API (vision_transformer.py:186-196) --
     def get_attn(self):
@@ -230,7 +234,7 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x, stack=None, layer=0):
-        x = x + self.attn(self.norm1(x), stack, layer)
+        x = self.attn(self.norm1(x), stack, layer, resid=x)
         return x + self.mlp(self.norm2(x))
 
 

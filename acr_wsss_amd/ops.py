@@ -164,6 +164,65 @@ def getam_row_accum(qkv, d_o, lse2, heads, batch, func, cam_row):
                                     L.GETAM_FUNCS[func], L.ptr(cam_row), L.stream_ptr()), "acr_getam_row_accum")
 
 
+def linear_bf16(x, weight, bias=None, resid=None, out=None):
+    """y = x @ weight.T (+ bias) (+ resid) on the hand-written bf16 MFMA GEMM (acr_linear_bf16).
+    x (M,K), weight (N,K), bias (N,), resid (M,N), all bf16 with unit inner stride."""
+    L.require_gpu(x, weight)
+    M, K = x.shape
+    N = weight.shape[0]
+    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.stride(1) == 1 and weight.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().acr_linear_bf16(L.ptr(x), x.stride(0), L.ptr(weight), weight.stride(0), L.ptr(bias),
+                                     L.ptr(resid), resid.stride(0) if resid is not None else 0, L.ptr(out),
+                                     out.stride(0), M, N, K, L.stream_ptr()), "acr_linear_bf16")
+    return out
+
+
+class LinearBf16Fn(Function):
+    """y = x W^T + b (+ resid) for the attention block's qkv / proj Linears in the bf16 mode, on the hand-written
+    MFMA GEMM for forward and input gradient; the weight gradient (a reduction over all tokens) stays on
+    hipBLASLt through torch.mm."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, resid):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        r2 = resid.reshape(-1, weight.shape[0]) if resid is not None else None
+        y = linear_bf16(x2, weight, bias, r2)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias, ctx.has_resid = bias is not None, resid is not None
+        return y.reshape(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if weight.shape[0] % 64 == 0:
+                dx = linear_bf16(dy2, weight.t().contiguous())
+            else:                                           # contraction length not a multiple of the K tile
+                dx = torch.mm(dy2, weight)
+            dx = dx.reshape(*dy.shape[:-1], weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            dw = torch.mm(dy2.t(), x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(dim=0)
+        return dx, dw, db, (dy if ctx.has_resid else None)
+
+
+def linear_or_hip(x, lin, resid=None, use_hip=True):
+    """nn.Linear forward; bf16 CUDA tensors with K % 64 == 0 take the hand-written GEMM (resid fused)."""
+    if (use_hip and x.is_cuda and x.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16
+            and lin.weight.shape[1] % 64 == 0 and x.is_contiguous()):
+        return LinearBf16Fn.apply(x, lin.weight, lin.bias, resid)
+    y = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    return y if resid is None else resid + y
+
+
 class ConsistencyFn(Function):
     """(cls_align, aff_align) of train_acr.py:143-161 on one (2B,L,T,T) stack holding view 1 in [:B] and
     view 2 in [B:] (both views run as one 2B batch; GroupNorm/LayerNorm are per-sample so this is exact)."""

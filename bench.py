@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--amp", choices=["master", "autocast"], default="master",
                     help="bf16 mode: bf16 model + fp32 master weights (default) or torch.autocast")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--stock-linear", action="store_true", help="qkv/proj on torch F.linear instead of acr_linear_bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -207,6 +208,9 @@ def main():
                 channels_last=args.channels_last).to(dev)
     if args.channels_last:
         model = model.to(memory_format=torch.channels_last)
+    if args.stock_linear:
+        from acr_wsss_amd.backbone import Attention
+        Attention.hip_linear = False
     model.train()
     broadcast_parameters(model)
     img, label = make_batch(args.batch, args.size, args.classes, rank, dev)

@@ -84,6 +84,16 @@ int acr_attn_probs(const acr_attn_desc* desc, const void* q, const void* k, cons
 int acr_attn_dprobs(const acr_attn_desc* desc, const void* d_o, const void* v,
                     float* dprobs, void* stream);
 
+/* ---- projections of the attention block (models/vision_transformer.py:200 `self.qkv(x)`, :212 `self.proj(x)`) ----
+ * y[M,N] = a[M,K] . b[N,K]^T (+ bias[N]) (+ resid[M,N]); bf16 tensors, fp32 accumulate, hand-written MFMA GEMM.
+ * a = activations (rows = tokens), b = nn.Linear weight as stored (N,K).  Also computes the input gradient
+ * dX = dY . W when given b = W^T.  ld* are row pitches in elements (multiples of 8), K %% 64 == 0.
+ * bias / resid may be NULL.  With y = the packed (B*T, 3*H*64) buffer this is the projection half of the
+ * "fused qkv-projection + attention" path: acr_linear_bf16 -> acr_attn_fwd read it in place, no permute. */
+int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const void* bias,
+                    const void* resid, int64_t ldr, void* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
+                    void* stream);
+
 /* ---- attention-consistency regulariser (train_acr.py:143-161, inline in train()) ----
  * a1, a2: (B,L,T,T) fp32 head-mean stacks of view 1 / view 2 (T = p*p + 1), batch stride a_sb each
  * (so both may live in one (2B,L,T,T) buffer).  With pi(i*p+j) = i*p+(p-1-j):

@@ -205,3 +205,34 @@ def test_errors_are_loud():
     lib = _lib.load()
     rc = lib.acr_consistency_fwd(None, None, 0, 1, 1, 5, 2, None, None, None)
     assert rc < 0 and b"null" in lib.acr_last_error()
+
+
+@pytest.mark.parametrize("M,N,K,bias,resid", [(1, 128, 64, True, False), (130, 200, 128, True, True),
+                                              (785, 2304, 768, True, False), (2 * 785, 768, 768, False, True),
+                                              (333, 768, 2304, False, False)])
+def test_linear_bf16(M, N, K, bias, resid):
+    """acr_linear_bf16 (hand-written MFMA GEMM) forward + autograd against fp64; ragged M/N tails included."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dev).bfloat16().requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).bfloat16().requires_grad_(True)
+    b = torch.randn(N, generator=g).to(dev).bfloat16().requires_grad_(True) if bias else None
+    r = torch.randn(M, N, generator=g).to(dev).bfloat16().requires_grad_(True) if resid else None
+    y = ops.LinearBf16Fn.apply(x, w, b, r)
+    dy = torch.randn(M, N, generator=g).to(dev).bfloat16()
+    (y.float() * dy.float()).sum().backward()
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    ref = xd @ wd.t()
+    if bias:
+        ref = ref + b.detach().double()
+    if resid:
+        ref = ref + r.detach().double()
+    (ref * dy.double()).sum().backward()
+    assert (y.double() - ref).abs().max() <= 1e-2 * ref.abs().max()
+    assert (x.grad.double() - xd.grad).abs().max() <= 1.5e-2 * xd.grad.abs().max()
+    assert (w.grad.double() - wd.grad).abs().max() <= 1.5e-2 * wd.grad.abs().max()
+    if bias:
+        assert (b.grad.double() - dy.double().sum(0)).abs().max() <= 2e-2 * dy.double().sum(0).abs().max()
+    if resid:
+        torch.testing.assert_close(r.grad, dy)
