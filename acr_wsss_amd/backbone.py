@@ -56,12 +56,22 @@ class StdConv2dSame(nn.Conv2d):
 
 
 class GroupNormAct(nn.GroupNorm):
+    """GroupNorm(32) [+ ReLU]; ``forward(x, resid)`` additionally fuses ``relu(gn(x) + resid)`` (the tail of a
+    bottleneck).  bf16 NCHW tensors on the GPU run the fused HIP kernel (one read + one write forward), everything
+    else the stock torch ops with identical semantics."""
+    fused = True
+
     def __init__(self, channels, apply_act=True):
         super().__init__(32, channels, eps=1e-5)
         self.apply_act = apply_act
 
-    def forward(self, x):
+    def forward(self, x, resid=None):
+        if self.fused and ops.groupnorm_fusable(x, resid):
+            act = "add_relu" if resid is not None else ("relu" if self.apply_act else "none")
+            return ops.groupnorm_act(x, self.weight, self.bias, act, resid, self.eps)
         x = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+        if resid is not None:
+            return F.relu(x + resid)
         return F.relu(x) if self.apply_act else x
 
 
@@ -96,8 +106,7 @@ class Bottleneck(nn.Module):
         shortcut = x if self.downsample is None else self.downsample(x)
         x = self.norm1(self.conv1(x))
         x = self.norm2(self.conv2(x))
-        x = self.norm3(self.conv3(x))
-        return F.relu(x + shortcut)
+        return self.norm3(self.conv3(x), shortcut)          # relu(gn(conv3) + shortcut), fused on the bf16 path
 
 
 class ResNetStage(nn.Module):

@@ -223,6 +223,55 @@ def linear_or_hip(x, lin, resid=None, use_hip=True):
     return y if resid is None else resid + y
 
 
+GN_ACT = {"none": 0, "relu": 1, "add_relu": 2}
+
+
+def groupnorm_fusable(x, resid=None):
+    """Shapes/dtypes the fused bf16 GroupNorm kernel handles (everything else stays on torch ops)."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    N, C, H, W = x.shape
+    if C % 32 or (H * W) % 8 or (C // 32) * H * W // 8 > 1024 * 13:
+        return False
+    return resid is None or (resid.shape == x.shape and resid.dtype == x.dtype and resid.is_contiguous())
+
+
+class GroupNormActFn(Function):
+    """y = act(GroupNorm32(x) [+ resid]) on acr_groupnorm_{fwd,bwd}_bf16 (bf16 NCHW)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, resid, act, eps):
+        N, C, H, W = x.shape
+        lib = L.load()
+        y = torch.empty_like(x)
+        stats = torch.empty(N * 32 * 2, dtype=torch.float32, device=x.device)
+        L.check(lib.acr_groupnorm_fwd_bf16(L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats),
+                                           N, C, H * W, eps, act, L.stream_ptr()), "acr_groupnorm_fwd_bf16")
+        ctx.save_for_backward(x, weight, bias, stats, resid if act == 2 else None)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, stats, resid = ctx.saved_tensors
+        N, C, H, W = x.shape
+        lib = L.load()
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.act == 2 else None
+        part = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
+        L.check(lib.acr_groupnorm_bwd_bf16(L.ptr(dy), L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(stats),
+                                           L.ptr(dx), L.ptr(dres), L.ptr(part[0]), L.ptr(part[1]), N, C, H * W, ctx.act,
+                                           L.stream_ptr()), "acr_groupnorm_bwd_bf16")
+        sums = part.sum(dim=1)                              # fixed-order reduction over samples
+        return dx, sums[0].to(weight.dtype), sums[1].to(bias.dtype), dres, None, None
+
+
+def groupnorm_act(x, weight, bias, act="relu", resid=None, eps=1e-5):
+    return GroupNormActFn.apply(x, weight.to(x.dtype), bias.to(x.dtype), resid, GN_ACT[act], eps)
+
+
 class ConsistencyFn(Function):
     """(cls_align, aff_align) of train_acr.py:143-161 on one (2B,L,T,T) stack holding view 1 in [:B] and
     view 2 in [B:] (both views run as one 2B batch; GroupNorm/LayerNorm are per-sample so this is exact)."""

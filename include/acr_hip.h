@@ -94,6 +94,18 @@ int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, cons
                     const void* resid, int64_t ldr, void* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
                     void* stream);
 
+/* ---- ResNetV2 stem: fused GroupNorm(32) [+ residual] [+ ReLU], bf16 NCHW ----
+ * models/layers/norm_act.py:69-85 (GroupNormAct), models/resnetv2.py:205-215 (norm3 -> act3(x + shortcut)).
+ * act: 0 = none, 1 = ReLU, 2 = ReLU(gn(x) + resid).  x/resid/y: (N,C,H,W) contiguous, HW = H*W (multiple of 8),
+ * C a multiple of 32; stats: (N*32*2) fp32 [mean, rstd] written by forward, read by backward.
+ * Backward writes dx (and dresid for act 2) plus per-sample partials dgamma_part/dbeta_part (N,C) fp32 that the
+ * caller sums over N. */
+int acr_groupnorm_fwd_bf16(const void* x, const void* resid, const void* gamma, const void* beta, void* y,
+                           float* stats, int32_t N, int32_t C, int32_t HW, float eps, int32_t act, void* stream);
+int acr_groupnorm_bwd_bf16(const void* dy, const void* x, const void* resid, const void* gamma, const void* beta,
+                           const float* stats, void* dx, void* dresid, float* dgamma_part, float* dbeta_part,
+                           int32_t N, int32_t C, int32_t HW, int32_t act, void* stream);
+
 /* ---- attention-consistency regulariser (train_acr.py:143-161, inline in train()) ----
  * a1, a2: (B,L,T,T) fp32 head-mean stacks of view 1 / view 2 (T = p*p + 1), batch stride a_sb each
  * (so both may live in one (2B,L,T,T) buffer).  With pi(i*p+j) = i*p+(p-1-j):

@@ -236,3 +236,36 @@ def test_linear_bf16(M, N, K, bias, resid):
         assert (b.grad.double() - dy.double().sum(0)).abs().max() <= 2e-2 * dy.double().sum(0).abs().max()
     if resid:
         torch.testing.assert_close(r.grad, dy)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 8, 8), (3, 256, 16, 24), (2, 1024, 28, 28), (1, 64, 224, 224)])
+@pytest.mark.parametrize("act", ["none", "relu", "add_relu"])
+def test_groupnorm_fused(N, C, H, W, act):
+    """Fused bf16 GroupNorm(32) [+ residual] [+ ReLU] forward/backward vs torch group_norm + relu in fp64."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.7 + 0.3).to(dev).bfloat16().requires_grad_(True)
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(dev).bfloat16().requires_grad_(True)
+    b = (0.3 * torch.randn(C, generator=g)).to(dev).bfloat16().requires_grad_(True)
+    r = torch.randn(N, C, H, W, generator=g).to(dev).bfloat16().requires_grad_(True) if act == "add_relu" else None
+    assert ops.groupnorm_fusable(x, r)
+    y = ops.groupnorm_act(x, w, b, act, r)
+    dy = torch.randn(N, C, H, W, generator=g).to(dev).bfloat16()
+    (y.float() * dy.float()).sum().backward()
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    ref = F.group_norm(xd, 32, wd, bd, 1e-5)
+    if r is not None:
+        rd = r.detach().double().requires_grad_(True)
+        ref = ref + rd
+    if act != "none":
+        # take the ReLU mask from the kernel's own (bf16-rounded) output so elements that round to +-0 agree
+        ref = ref * (y.detach() > 0).double()
+    (ref * dy.double()).sum().backward()
+    assert (y.double() - ref).abs().max() <= 1.2e-2 * ref.abs().max()
+    assert (x.grad.double() - xd.grad).abs().max() <= 2e-2 * xd.grad.abs().max()
+    assert (w.grad.double() - wd.grad).abs().max() <= 2e-2 * wd.grad.abs().max() + 1e-2
+    assert (b.grad.double() - bd.grad).abs().max() <= 2e-2 * bd.grad.abs().max() + 1e-2
+    if r is not None:
+        assert (r.grad.double() - rd.grad).abs().max() <= 1e-2 * rd.grad.abs().max()
