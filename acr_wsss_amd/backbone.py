@@ -52,7 +52,10 @@ class StdConv2dSame(nn.Conv2d):
     def forward(self, x):
         if self.dynamic_pad:
             x = pad_same(x, self.kernel_size[0], self.stride[0])
-        return F.conv2d(x, self.standardized_weight(), None, self.stride, self.padding)
+        w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
+        return F.conv2d(x, w_hat, None, self.stride, self.padding)
+
+    _w_hat = None           # set for one forward by ResNetV2 when all weights are standardised in one fused launch
 
 
 class GroupNormAct(nn.GroupNorm):
@@ -138,12 +141,29 @@ class ResNetV2(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
+    fused_weight_std = True
+
     def forward(self, x, taps=None):
-        x = self.stem(x)
-        for i, st in enumerate(self.stages):
-            x = st(x)
-            if taps is not None and i < 2:
-                taps[str(i + 1)] = x           # DPT/vit.py:426-431 forward hooks "1", "2"
+        convs = None
+        if self.fused_weight_std and x.is_cuda and x.dtype == torch.bfloat16:
+            # one HIP launch standardises all 52 conv weights (and one more in backward) instead of ~10 tiny
+            # kernels per convolution and direction
+            convs = [m for m in self.modules() if isinstance(m, StdConv2dSame)]
+            if all(c.weight.dtype == torch.bfloat16 for c in convs):
+                for c, w_hat in zip(convs, ops.weight_std_all([c.weight for c in convs], convs[0].eps)):
+                    c._w_hat = w_hat
+            else:
+                convs = None
+        try:
+            x = self.stem(x)
+            for i, st in enumerate(self.stages):
+                x = st(x)
+                if taps is not None and i < 2:
+                    taps[str(i + 1)] = x           # DPT/vit.py:426-431 forward hooks "1", "2"
+        finally:
+            if convs is not None:
+                for c in convs:
+                    c._w_hat = None
         return x
 
 

@@ -272,6 +272,49 @@ def groupnorm_act(x, weight, bias, act="relu", resid=None, eps=1e-5):
     return GroupNormActFn.apply(x, weight.to(x.dtype), bias.to(x.dtype), resid, GN_ACT[act], eps)
 
 
+def _wstd_desc(p0s, p1s, p2s, device):
+    import numpy as np
+    rec = np.zeros(len(p0s), dtype=[("p0", "<u8"), ("p1", "<u8"), ("p2", "<u8"), ("p3", "<u8"), ("cout", "<i4"),
+                                    ("n", "<i4"), ("ch_start", "<i4"), ("pad", "<i4")])
+    ch = 0
+    for i, w in enumerate(p0s):
+        cout = w.shape[0]
+        rec[i] = (w.data_ptr(), p1s[i].data_ptr(), p2s[i].data_ptr() if p2s is not None else 0, 0, cout,
+                  w.numel() // cout, ch, 0)
+        ch += cout
+    return torch.from_numpy(rec.view(np.uint8)).to(device), ch
+
+
+class WeightStdAllFn(Function):
+    """w_hat_i = (w_i - mean) / (std + eps) for ALL conv weights of the stem at once (one launch forward, one
+    backward) on acr_weight_std_bf16.  Inputs and outputs are tuples of (cout, cin, k, k) bf16 tensors."""
+
+    @staticmethod
+    def forward(ctx, eps, *weights):
+        ws = [w.contiguous() for w in weights]
+        outs = [torch.empty_like(w) for w in ws]
+        desc, total = _wstd_desc(ws, outs, None, ws[0].device)
+        L.check(L.load().acr_weight_std_bf16(L.ptr(desc), len(ws), total, eps, 0, L.stream_ptr()), "acr_weight_std_bf16")
+        ctx.save_for_backward(*ws)
+        ctx.eps = eps
+        ctx._keep = desc
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ws = ctx.saved_tensors
+        gs = [g.contiguous() if g is not None else torch.zeros_like(w) for g, w in zip(grads, ws)]
+        dws = [torch.empty_like(w) for w in ws]
+        desc, total = _wstd_desc(list(ws), gs, dws, ws[0].device)
+        L.check(L.load().acr_weight_std_bf16(L.ptr(desc), len(ws), total, ctx.eps, 1, L.stream_ptr()), "acr_weight_std_bf16")
+        ctx._keep_b = desc
+        return (None,) + tuple(dws)
+
+
+def weight_std_all(weights, eps=1e-5):
+    return WeightStdAllFn.apply(eps, *weights)
+
+
 class ConsistencyFn(Function):
     """(cls_align, aff_align) of train_acr.py:143-161 on one (2B,L,T,T) stack holding view 1 in [:B] and
     view 2 in [B:] (both views run as one 2B batch; GroupNorm/LayerNorm are per-sample so this is exact)."""

@@ -106,6 +106,13 @@ int acr_groupnorm_bwd_bf16(const void* dy, const void* x, const void* resid, con
                            const float* stats, void* dx, void* dresid, float* dgamma_part, float* dbeta_part,
                            int32_t N, int32_t C, int32_t HW, int32_t act, void* stream);
 
+/* Weight standardisation of all StdConv2dSame weights of the stem in one launch (models/layers/std_conv.py:56-59).
+ * desc_dev: device array of n_conv records {uint64 p0,p1,p2,p3; int32 cout, n, ch_start, pad} sorted by ch_start
+ * (first global output-channel index of the conv), n = fan-in.  forward (backward = 0): p0 = w, p1 = w_hat out;
+ * backward: p0 = w, p1 = dL/dw_hat, p2 = dL/dw out.  bf16 tensors, fp32 statistics. */
+int acr_weight_std_bf16(const void* desc_dev, int32_t n_conv, int32_t total_channels, float eps, int32_t backward,
+                        void* stream);
+
 /* ---- attention-consistency regulariser (train_acr.py:143-161, inline in train()) ----
  * a1, a2: (B,L,T,T) fp32 head-mean stacks of view 1 / view 2 (T = p*p + 1), batch stride a_sb each
  * (so both may live in one (2B,L,T,T) buffer).  With pi(i*p+j) = i*p+(p-1-j):

@@ -269,3 +269,22 @@ def test_groupnorm_fused(N, C, H, W, act):
     assert (b.grad.double() - bd.grad).abs().max() <= 2e-2 * bd.grad.abs().max() + 1e-2
     if r is not None:
         assert (r.grad.double() - rd.grad).abs().max() <= 1e-2 * rd.grad.abs().max()
+
+
+def test_weight_std_all_fused():
+    """One-launch weight standardisation of several conv weights vs the torch expression (std_conv.py:56-59)."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    shapes = [(64, 3, 7, 7), (64, 64, 1, 1), (256, 64, 3, 3), (33, 5, 1, 1)]
+    ws = [(torch.randn(s, generator=g) * 0.3 + 0.05).to(dev).bfloat16().requires_grad_(True) for s in shapes]
+    outs = ops.weight_std_all(ws)
+    gs = [torch.randn(s, generator=g).to(dev).bfloat16() for s in shapes]
+    sum((o.float() * gi.float()).sum() for o, gi in zip(outs, gs)).backward()
+    for w, o, gi in zip(ws, outs, gs):
+        wd = w.detach().double().requires_grad_(True)
+        std, mean = torch.std_mean(wd, dim=[1, 2, 3], keepdim=True, unbiased=False)
+        ref = (wd - mean) / (std + 1e-5)
+        (ref * gi.double()).sum().backward()
+        assert (o.double() - ref).abs().max() <= 1e-2 * ref.abs().max()
+        assert (w.grad.double() - wd.grad).abs().max() <= 2e-2 * wd.grad.abs().max() + 1e-3
