@@ -190,8 +190,12 @@ class Mlp(nn.Module):
         self.act = nn.GELU()
         self.fc2 = nn.Linear(hidden, dim)
 
-    def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+    def forward(self, x, resid=None):
+        """fc2(gelu(fc1(x))) [+ resid].  On the bf16 path fc2 runs on the hand-written GEMM with the block's residual
+        add fused into its epilogue (ties hipBLASLt on this long-K shape and saves the add kernel); fc1 and the
+        input gradients stay on hipBLASLt, which is faster on the short-K / wide-N shapes (scripts/bench_gemm.py)."""
+        h = self.act(self.fc1(x))
+        return ops.linear_or_hip(h, self.fc2, resid, Attention.hip_linear, hip_dx=False)
 
 
 class Attention(nn.Module):
@@ -264,7 +268,7 @@ class Block(nn.Module):
 
     def forward(self, x, stack=None, layer=0):
         x = self.attn(self.norm1(x), stack, layer, resid=x)
-        return x + self.mlp(self.norm2(x))
+        return self.mlp(self.norm2(x), resid=x)
 
 
 class VisionTransformer(nn.Module):

@@ -8,6 +8,8 @@
 // the current step's 64 MFMAs (two LDS buffers, one barrier per step); LDS rows padded to 144 B so every
 // ds_read_b128 lane group is conflict-free; XCD-aware tile order keeps the 128-row A panel of consecutive N tiles
 // in one L2.  fp32 accumulate, bias / residual fused in the epilogue, bf16 out.
+#include <stdlib.h>
+
 #include "acr_common.h"
 
 typedef __bf16 bf16_t;
@@ -111,6 +113,248 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const bf16_t* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant: tiles go global -> LDS directly (global_load_lds_dwordx4, no staging VGPRs, no ds_write path).
+// A DMA wave-instruction writes 64 lanes x 16 B = 1 KiB linearly, i.e. 8 unpadded 128-byte rows; bank conflicts of
+// the ds_read_b128 fragment reads are removed by an XOR swizzle applied on the SOURCE address (lane fetches logical
+// chunk  p ^ ((row >> 1) & 7)  into physical chunk p) and mirrored on the read -- rows r and r+1 sit in different
+// halves of the 256-byte bank row, so the 16 rows of any ds_read_b128 lane group land on 16 distinct 16-byte slots.
+// ---------------------------------------------------------------------------------------------------------------
+#define GEMM_GROUP_M 8
+#define GL_TILE (128 * 64)            // elements per operand tile (unpadded)
+
+__device__ __forceinline__ void glds_stage(bf16_t* ldsbuf, const bf16_t* g, int64_t ld, int row0, int nrows, int k0,
+                                           int wave, int lane) {
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rbase = (wave * 4 + i) * 8;
+        const int row = rbase + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        const bf16_t* src = g + (int64_t)min(row0 + row, nrows - 1) * ld + k0 + lc * 8;
+        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(ldsbuf + rbase * 64), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ bf16x8 glds_frag(const bf16_t* ldsbuf, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(ldsbuf + row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3));
+}
+
+template <bool BIAS, bool RESID>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_dma_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                               const bf16_t* __restrict__ B, int64_t ldb,
+                                                               const bf16_t* __restrict__ bias,
+                                                               const bf16_t* __restrict__ R, int64_t ldr,
+                                                               bf16_t* __restrict__ Y, int64_t ldy, int M, int N, int K) {
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[4 * GL_TILE];      // [A0 | B0 | A1 | B1], ONE array
+    // Tile order: XCD-contiguous chunks, and inside a chunk "grouped" rasterisation (bands of GEMM_GROUP_M row panels
+    // walked column by column) so a band's A panels (8 x 196 KB at K = 768) stay L2-resident while each 128-column
+    // weight tile is fetched once per band instead of once per row panel (N = 3072: the weight alone is 4.7 MB > L2).
+    const int ntn = (N + 127) >> 7, ntm = (M + 127) >> 7;
+    const int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = id / ntn, tn = id % ntn;
+    (void)ntm;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int nk = K >> 6;
+    glds_stage(smem, A, lda, m0, M, 0, wave, lane);
+    glds_stage(smem + GL_TILE, B, ldb, n0, N, 0, wave, lane);
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt, cur ^= 1) {
+        if (kt + 1 < nk) {
+            glds_stage(smem + (cur ^ 1) * 2 * GL_TILE, A, lda, m0, M, (kt + 1) * 64, wave, lane);
+            glds_stage(smem + (cur ^ 1) * 2 * GL_TILE + GL_TILE, B, ldb, n0, N, (kt + 1) * 64, wave, lane);
+        }
+        const bf16_t* as = smem + cur * 2 * GL_TILE;
+        const bf16_t* bs = as + GL_TILE;
+        const int ra = wm * 64 + r, rb = wn * 64 + r;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + hh;
+            const bf16x8 a0 = glds_frag(as, ra, c), a1 = glds_frag(as, ra + 32, c);
+            const bf16x8 b0 = glds_frag(bs, rb, c), b1 = glds_frag(bs, rb + 32, c);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();                                    // drains the DMA (vmcnt) and frees buffer `cur`
+    }
+    // Epilogue through LDS (the operand buffers are free after the last barrier): each wave parks its 64x64 fp32
+    // tile in its own 16 KiB, then re-reads it row-major so that 8 lanes store one full 128-byte row segment with
+    // 16-byte stores (a 2-byte-per-lane store tail is store-issue bound; row-scattered 8-byte stores measured worse).
+    float* stile = reinterpret_cast<float*>(smem) + wave * 4096;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                stile[(mt * 32 + acr_krow(reg, hh)) * 64 + nt * 32 + r] = acc[mt][nt][reg];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;
+        const int lrow = idx >> 3, c8 = (idx & 7) * 8;
+        const int row = m0 + wm * 64 + lrow, col = n0 + wn * 64 + c8;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8 + 4);
+        if (row < M && col < N) {
+            float y[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (BIAS) {
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bias + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] += (float)bv[e];
+            }
+            if (RESID) {
+                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * ldr + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] += (float)rv[e];
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)y[e];
+            *reinterpret_cast<bf16x8*>(Y + (int64_t)row * ldy + col) = o;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256x128x64 variant, 8 waves (4 x 2, each 64x64), THREE LDS stages filled by LDS-DMA two K-steps ahead.
+// One K-step of MFMAs (~1k cycles for the two waves of a SIMD) does not cover a loaded HBM/L2 round trip, so the
+// 2-stage kernel above waits on every step; here the wait before the barrier is a COUNTED s_waitcnt vmcnt(6) that
+// leaves the newest stage's 6 DMA instructions in flight, and the barrier is a raw s_barrier (a __syncthreads()
+// would drain vmcnt(0)).  48 KiB per stage -> 144 KiB, one workgroup (8 waves, 2 per SIMD) per CU.
+// ---------------------------------------------------------------------------------------------------------------
+#define G3_BM 256
+#define G3_STAGE (G3_BM * 64 + 128 * 64)          // elements per stage: A tile then B tile
+
+__device__ __forceinline__ void glds_stage_rows(bf16_t* ldsbuf, const bf16_t* g, int64_t ld, int row0, int nrows, int k0,
+                                                int wave, int lane, int ninstr) {
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < ninstr) {
+            const int rbase = (wave * ninstr + i) * 8;
+            const int row = rbase + (lane >> 3);
+            const int lc = (lane & 7) ^ ((row >> 1) & 7);
+            const bf16_t* src = g + (int64_t)min(row0 + row, nrows - 1) * ld + k0 + lc * 8;
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(ldsbuf + rbase * 64), 16, 0, 0);
+        }
+    }
+}
+
+template <bool BIAS, bool RESID>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_dma3_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                const bf16_t* __restrict__ B, int64_t ldb,
+                                                                const bf16_t* __restrict__ bias,
+                                                                const bf16_t* __restrict__ R, int64_t ldr,
+                                                                bf16_t* __restrict__ Y, int64_t ldy, int M, int N, int K) {
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[3 * G3_STAGE];
+    const int ntn = (N + 127) >> 7;
+    const int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = id / ntn, tn = id % ntn;
+    const int m0 = tm * G3_BM, n0 = tn * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int nk = K >> 6;
+    // prologue: tiles 0 and 1 in flight, wait for tile 0 only
+    glds_stage_rows(smem, A, lda, m0, M, 0, wave, lane, 4);
+    glds_stage_rows(smem + G3_BM * 64, B, ldb, n0, N, 0, wave, lane, 2);
+    if (nk > 1) {
+        glds_stage_rows(smem + G3_STAGE, A, lda, m0, M, 64, wave, lane, 4);
+        glds_stage_rows(smem + G3_STAGE + G3_BM * 64, B, ldb, n0, N, 64, wave, lane, 2);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int st = 0, st2 = 2;                                    // stage of tile kt, stage of tile kt+2
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) {
+            glds_stage_rows(smem + st2 * G3_STAGE, A, lda, m0, M, (kt + 2) * 64, wave, lane, 4);
+            glds_stage_rows(smem + st2 * G3_STAGE + G3_BM * 64, B, ldb, n0, N, (kt + 2) * 64, wave, lane, 2);
+        }
+        const bf16_t* as = smem + st * G3_STAGE;
+        const bf16_t* bs = as + G3_BM * 64;
+        const int ra = wm * 64 + r, rb = wn * 64 + r;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + hh;
+            const bf16x8 a0 = glds_frag(as, ra, c), a1 = glds_frag(as, ra + 32, c);
+            const bf16x8 b0 = glds_frag(bs, rb, c), b1 = glds_frag(bs, rb + 32, c);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        // tile kt+1 must have landed (its 6 DMA instructions are older than tile kt+2's 6); every wave has consumed
+        // stage `st` (its fragment reads were waited for by the MFMAs) before anyone refills it next step
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        st = (st == 2) ? 0 : st + 1;
+        st2 = (st2 == 2) ? 0 : st2 + 1;
+    }
+    float* stile = reinterpret_cast<float*>(smem) + wave * 4096;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                stile[(mt * 32 + acr_krow(reg, hh)) * 64 + nt * 32 + r] = acc[mt][nt][reg];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;
+        const int lrow = idx >> 3, c8 = (idx & 7) * 8;
+        const int row = m0 + wm * 64 + lrow, col = n0 + wn * 64 + c8;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8 + 4);
+        if (row < M && col < N) {
+            float y[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (BIAS) {
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bias + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] += (float)bv[e];
+            }
+            if (RESID) {
+                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * ldr + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] += (float)rv[e];
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)y[e];
+            *reinterpret_cast<bf16x8*>(Y + (int64_t)row * ldy + col) = o;
+        }
+    }
+}
+
 extern "C" int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const void* bias,
                                const void* resid, int64_t ldr, void* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
                                void* stream) {
@@ -122,10 +366,24 @@ extern "C" int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_
     const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
     ACR_CHECK_ARG(tiles < (1ll << 31), "acr_linear_bf16: grid too large");
     const dim3 grid((unsigned)tiles);
+    const dim3 grid3((unsigned)(((M + G3_BM - 1) / G3_BM) * ((N + 127) / 128)));
     hipStream_t st = (hipStream_t)stream;
+    static const int env_variant = getenv("ACR_GEMM_VARIANT") ? atoi(getenv("ACR_GEMM_VARIANT")) : 2;   // 2: 128x128 2-stage (fastest measured), 3: 256x128 3-stage
+    // LDS-DMA kernel stores 8-column (16-byte) groups: needs N, ldy, ldr multiples of 8 and 16-byte aligned y/bias/resid
+    const bool vec_ok = (N % 8) == 0 && (ldy % 8) == 0 && (ldr % 8) == 0 && ((uintptr_t)y & 15) == 0 &&
+                        ((uintptr_t)bias & 15) == 0 && ((uintptr_t)resid & 15) == 0;
+    static const bool env_regstage = getenv("ACR_GEMM_REGSTAGE") != nullptr;       // A/B switch for the older variant
+    const bool use_regstage = env_regstage || !vec_ok;
 #define ACR_GEMM_LAUNCH(BI, RE)                                                                                       \
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<BI, RE>), grid, dim3(256), 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, \
-                       ldb, (const bf16_t*)bias, (const bf16_t*)resid, ldr, (bf16_t*)y, ldy, M, N, K)
+    if (use_regstage)                                                                                                 \
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<BI, RE>), grid, dim3(256), 0, st, (const bf16_t*)a, lda,               \
+                           (const bf16_t*)b, ldb, (const bf16_t*)bias, (const bf16_t*)resid, ldr, (bf16_t*)y, ldy, M, N, K); \
+    else if (env_variant == 3)                                                                                        \
+        hipLaunchKernelGGL((gemm_nt_bf16_dma3_kernel<BI, RE>), grid3, dim3(512), 0, st, (const bf16_t*)a, lda,         \
+                           (const bf16_t*)b, ldb, (const bf16_t*)bias, (const bf16_t*)resid, ldr, (bf16_t*)y, ldy, M, N, K); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<BI, RE>), grid, dim3(256), 0, st, (const bf16_t*)a, lda,           \
+                           (const bf16_t*)b, ldb, (const bf16_t*)bias, (const bf16_t*)resid, ldr, (bf16_t*)y, ldy, M, N, K)
     if (bias && resid) ACR_GEMM_LAUNCH(true, true);
     else if (bias) ACR_GEMM_LAUNCH(true, false);
     else if (resid) ACR_GEMM_LAUNCH(false, true);

@@ -185,7 +185,8 @@ class LinearBf16Fn(Function):
     hipBLASLt through torch.mm."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, resid):
+    def forward(ctx, x, weight, bias, resid, hip_dx=True):
+        ctx.hip_dx = hip_dx
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         r2 = resid.reshape(-1, weight.shape[0]) if resid is not None else None
@@ -202,7 +203,7 @@ class LinearBf16Fn(Function):
             dy2 = dy2.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if weight.shape[0] % 64 == 0:
+            if ctx.hip_dx and weight.shape[0] % 64 == 0:
                 dx = linear_bf16(dy2, weight.t().contiguous())
             else:                                           # contraction length not a multiple of the K tile
                 dx = torch.mm(dy2, weight)
@@ -211,14 +212,15 @@ class LinearBf16Fn(Function):
             dw = torch.mm(dy2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(dim=0)
-        return dx, dw, db, (dy if ctx.has_resid else None)
+        return dx, dw, db, (dy if ctx.has_resid else None), None
 
 
-def linear_or_hip(x, lin, resid=None, use_hip=True):
-    """nn.Linear forward; bf16 CUDA tensors with K % 64 == 0 take the hand-written GEMM (resid fused)."""
+def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True):
+    """nn.Linear forward; bf16 CUDA tensors with K % 64 == 0 take the hand-written GEMM (resid fused).
+    ``hip_dx`` = False leaves the input gradient on hipBLASLt (shapes where the library kernel is faster)."""
     if (use_hip and x.is_cuda and x.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16
             and lin.weight.shape[1] % 64 == 0 and x.is_contiguous()):
-        return LinearBf16Fn.apply(x, lin.weight, lin.bias, resid)
+        return LinearBf16Fn.apply(x, lin.weight, lin.bias, resid, hip_dx)
     y = torch.nn.functional.linear(x, lin.weight, lin.bias)
     return y if resid is None else resid + y
 
