@@ -252,14 +252,15 @@ def main():
         imgs = args.batch * world * args.steps
         value = imgs / elapsed
         out = {
-            "metric": "img/s ACR-ViT-hybrid-base 448x448 train step", "value": round(value, 3), "unit": "img/s",
+            "metric": "img/s ACR-ViT-hybrid-base %dx%d train step" % (args.size, args.size), "value": round(value, 3), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "precision": ("bf16 params/activations/grads, fp32 master weights + fp32 softmax/loss" if (args.dtype == "bf16" and args.amp == "master")
                           else ("torch.autocast(bf16)" if args.dtype == "bf16" else "fp32 end to end (reference precision)")),
-            "config": {"workload": "BASELINE configs[1]: ViT-hybrid-base (DPT) %dx%d, batch %d per GPU, ACR train step "
-                                   "(2 views, fwd+bwd+SGD)" % (args.size, args.size, args.batch),
+            "config": {"workload": "%sViT-hybrid-base (DPT) %dx%d, batch %d per GPU, ACR train step "
+                                   "(2 views, fwd+bwd+SGD)" % ("BASELINE configs[1]: " if (args.size, args.batch, args.classes) == (448, 16, 20) else "",
+                                                               args.size, args.size, args.batch),
                        "global_batch": args.batch * world, "classes": args.classes, "alpha": args.alpha,
                        "parallelism": "dp%d" % world, "tokens_per_view": (args.size // 16) ** 2 + 1},
             "loss": round(loss_val, 5),

@@ -1,0 +1,20 @@
+"""CAM-generation throughput (BASELINE configs[3], informational): infer_cam_image at scales {0.5,1,1.5,2} of 384^2,
+2 positive classes per image, fp32 (parity precision), one GPU."""
+import sys, os, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from acr_wsss_amd.DPT.ACR import ACR
+from acr_wsss_amd.infer_cam import infer_cam_image
+dev = "cuda:0"
+torch.manual_seed(0)
+m = ACR(20, "vitb_hybrid", use_pretrain=False).to(dev).eval()
+g = torch.Generator().manual_seed(0)
+img = torch.randn(1, 3, 384, 384, generator=g).to(dev)
+lab = torch.zeros(1, 20); lab[0, 3] = 1; lab[0, 11] = 1
+for scales in ((1,), (0.5, 1.0, 1.5, 2.0)):
+    for _ in range(2):
+        infer_cam_image(m, img, lab, (375, 500), scales=scales)
+    torch.cuda.synchronize(); t0 = time.time(); n = 5
+    for _ in range(n):
+        cam, _ = infer_cam_image(m, img, lab, (375, 500), scales=scales)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / n
+    print("scales %-22s %.1f ms/image  %.2f img/s  (cam %s, peak mem %.1f GB)" % (scales, dt * 1e3, 1 / dt, cam[3].shape, torch.cuda.max_memory_allocated() / 2**30))
