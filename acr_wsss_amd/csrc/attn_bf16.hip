@@ -124,7 +124,7 @@ __device__ __forceinline__ void mma_accop_b_bf(f32x16& acc, const f32x16& z, con
 // forward: 2 waves x 32 query rows, 64 keys per step, K/V tiles double-buffered in LDS with the next tile's
 // global loads in flight during the current tile's MFMA + softmax work (one barrier per step)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void attn_fwd_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
+__global__ __launch_bounds__(128, 2) void attn_fwd_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
                                                             const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                             bf16_t* __restrict__ o, float* __restrict__ lse2) {
     __shared__ __attribute__((aligned(16))) bf16_t kt[2][64 * BP];
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void attn_tile_qk_bf16_kernel(AttnGeomB g, con
 // delta[b,h,i] = rowsum(dO*O) + (1/H) sum_j P_h[i,j] G[b,i,j]
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_G>
-__global__ __launch_bounds__(128) void attn_delta_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
+__global__ __launch_bounds__(128, 4) void attn_delta_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
                                                               const bf16_t* __restrict__ k, const bf16_t* __restrict__ o,
                                                               const bf16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse2,
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(128) void attn_delta_bf16_kernel(AttnGeomB g, const
 // own query row as 16-byte groups (row pitch gm_st is a multiple of 4 floats) at the top of the step
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_G>
-__global__ __launch_bounds__(128) void attn_dq_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
+__global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
                                                            const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                            const bf16_t* __restrict__ d_o,
                                                            const float* __restrict__ lse2,
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(128) void attn_dq_bf16_kernel(AttnGeomB g, const bf
 // dK, dV: 2 waves x 32 keys (K, V fragments in registers), 64 queries per step (Q/dO tiles double-buffered)
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_G>
-__global__ __launch_bounds__(128) void attn_dkdv_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
+__global__ __launch_bounds__(128, 2) void attn_dkdv_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
                                                              const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                              const bf16_t* __restrict__ d_o,
                                                              const float* __restrict__ lse2,
@@ -526,20 +526,24 @@ __global__ __launch_bounds__(128) void attn_dkdv_bf16_kernel(AttnGeomB g, const 
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
     int cur = 0;
     for (int q0 = 0; q0 < g.T; q0 += 64, cur ^= 1) {
-        tile_gload<128>(qr, q + base, g.st, q0 + 64, g.T, tid);
-        tile_gload<128>(dr, d_o + obase, g.ost, q0 + 64, g.T, tid);
-        if (tid < 64) { const int qn = min(q0 + 64 + tid, g.T - 1); lnext = lrow[qn]; dnext = drow[qn]; }
-        float gv[2][16];
-        if (HAS_G) {
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    gv[qb][reg] = gbase[min(q0 + 32 * qb + acr_krow(reg, hh), g.T - 1) * gst];
-        }
-        ACR_MEMBAR();
+        // Register diet (this kernel sat at 318 VGPR+AGPR = 1 wave/SIMD): the next Q tile and the G values of the
+        // first 32 queries are fetched before the first half's MFMAs, the next dO tile and the second half's G values
+        // only before the second half, so at most one staging tile + 16 G values are live beside the accumulators.
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            if (qb == 0) {
+                tile_gload<128>(qr, q + base, g.st, q0 + 64, g.T, tid);
+                if (tid < 64) { const int qn = min(q0 + 64 + tid, g.T - 1); lnext = lrow[qn]; dnext = drow[qn]; }
+            } else {
+                tile_gload<128>(dr, d_o + obase, g.ost, q0 + 64, g.T, tid);
+            }
+            float gv[16];
+            if (HAS_G) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    gv[reg] = gbase[min(q0 + 32 * qb + acr_krow(reg, hh), g.T - 1) * gst];
+            }
+            ACR_MEMBAR();
             const bf16_t* qtc = qtile[cur] + qb * 32 * BP;
             const bf16_t* dtc = dotile[cur] + qb * 32 * BP;
             f32x16 s = {0}, dp = {0};
@@ -551,15 +555,18 @@ __global__ __launch_bounds__(128) void attn_dkdv_bf16_kernel(AttnGeomB g, const 
                 const int kr = 32 * qb + acr_krow(reg, hh);
                 const float pv = fast_exp2(fmaf(s[reg], c, -l2s[cur][kr])) * kmask;   // lse = +inf beyond T -> 0
                 p[reg] = pv;
-                ds[reg] = pv * (dp[reg] + (HAS_G ? gv[qb][reg] * invH : 0.f) - dls[cur][kr]);
+                ds[reg] = pv * (dp[reg] + (HAS_G ? gv[reg] * invH : 0.f) - dls[cur][kr]);
             }
             mma_accop_a_bf(dv0, p, dtc, 0, lane);           // dV[key = krow][d = 32*blk + r]
             mma_accop_a_bf(dv1, p, dtc, 1, lane);
             mma_accop_a_bf(dk0, ds, qtc, 0, lane);
             mma_accop_a_bf(dk1, ds, qtc, 1, lane);
+            if (qb == 0) {                                   // Q tile of the next step can go to LDS already
+                ACR_MEMBAR();
+                tile_lstore<128>(qtile[cur ^ 1], qr, q0 + 64, g.T, tid);
+            }
         }
         ACR_MEMBAR();
-        tile_lstore<128>(qtile[cur ^ 1], qr, q0 + 64, g.T, tid);
         tile_lstore<128>(dotile[cur ^ 1], dr, q0 + 64, g.T, tid);
         if (tid < 64) {
             const bool ok = q0 + 64 + tid < g.T;
