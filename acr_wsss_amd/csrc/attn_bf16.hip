@@ -14,6 +14,8 @@
 //   * P and dS are rounded to bf16 for the second-stage products (standard flash-attention numerics), row
 //     sums / log-sum-exp / delta / the head-mean output stay fp32.
 // The fp32-accumulated head-mean map (B,T,T) and lse2 have the same meaning as on the fp32 path.
+#include <type_traits>
+
 #include "acr_common.h"
 
 typedef __bf16 bf16_t;
@@ -37,23 +39,27 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 template <int NT>
 struct TileRegs { bf16x8 v[512 / NT]; };
 
-template <int NT>
+// EDGE = false: the whole 64-row tile is inside [0, Tn) -- plain pointer arithmetic, no clamps (the clamp + select
+// versions cost ~190 of 640 instructions per step of the dQ loop).  EDGE = true: rows are clamped to Tn-1, i.e. rows
+// past the end alias the last valid row; every consumer masks them (key >= T -> p = 0 / -inf, query >= T -> lse = +inf
+// -> p = 0, or the output row is simply not stored), so no zero-fill is needed and garbage stays finite.
+template <int NT, bool EDGE = true>
 __device__ __forceinline__ void tile_gload(TileRegs<NT>& t, const bf16_t* g, int64_t st, int row0, int Tn, int tid) {
 #pragma unroll
     for (int i = 0; i < 512 / NT; ++i) {
         const int slot = tid + i * NT;
-        const int rc = min(row0 + (slot >> 3), Tn - 1);          // clamped: always a valid address
+        const int row = row0 + (slot >> 3);
+        const int rc = EDGE ? min(row, Tn - 1) : row;
         t.v[i] = *reinterpret_cast<const bf16x8*>(g + (int64_t)rc * st + (slot & 7) * 8);
     }
 }
 template <int NT>
 __device__ __forceinline__ void tile_lstore(bf16_t* lds, const TileRegs<NT>& t, int row0, int Tn, int tid) {
-    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)row0; (void)Tn;
 #pragma unroll
     for (int i = 0; i < 512 / NT; ++i) {
         const int slot = tid + i * NT;
-        const int row = slot >> 3;
-        *reinterpret_cast<bf16x8*>(lds + row * BP + (slot & 7) * 8) = (row0 + row < Tn) ? t.v[i] : z;
+        *reinterpret_cast<bf16x8*>(lds + (slot >> 3) * BP + (slot & 7) * 8) = t.v[i];
     }
 }
 template <int ROWS, int NTHREADS>
@@ -66,10 +72,11 @@ __device__ __forceinline__ void stage_tile_bf(bf16_t* lds, const bf16_t* g, int6
 }
 
 // lane (r, h) owns row (row0 + r), k-slots 16s + 8h + j  (s = 0..3, j = 0..7)
+template <bool EDGE = true>
 __device__ __forceinline__ void load_rows_bf(bf16x8 (&reg)[4], const bf16_t* g, int64_t st, int row0, int Tn, int lane) {
     const int r = lane & 31, h = lane >> 5;
-    const bool ok = row0 + r < Tn;
-    const bf16_t* p = g + (int64_t)min(row0 + r, Tn - 1) * st + 8 * h;
+    const bool ok = !EDGE || row0 + r < Tn;
+    const bf16_t* p = g + (int64_t)(EDGE ? min(row0 + r, Tn - 1) : row0 + r) * st + 8 * h;
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -151,16 +158,17 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_bf16_kernel(AttnGeomB g, cons
     float m = -INFINITY, l = 0.f;
     f32x16 o0 = {0}, o1 = {0};
     int cur = 0;
-    for (int k0 = 0; k0 < g.T; k0 += 64, cur ^= 1) {
-        tile_gload<128>(kr, k + base, g.st, k0 + 64, g.T, tid);      // next tile (clamped rows past the end)
-        tile_gload<128>(vr, v + base, g.st, k0 + 64, g.T, tid);
+    auto step = [&](int k0, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        tile_gload<128, EDGE>(kr, k + base, g.st, k0 + 64, g.T, tid);      // next tile
+        tile_gload<128, EDGE>(vr, v + base, g.st, k0 + 64, g.T, tid);
         ACR_MEMBAR();
         const bf16_t* ktc = kt[cur];
         const bf16_t* vtc = vt[cur];
         f32x16 s0 = {0}, s1 = {0};
         mma_rowop_bf(s0, ktc, qreg, lane);                 // s[reg] = q.k (raw) [key = k0 + 32*kb + krow][query = r]
         mma_rowop_bf(s1, ktc + 32 * BP, qreg, lane);
-        if (k0 + 64 > g.T) {
+        if (EDGE) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 if (k0 + acr_krow(reg, hh) >= g.T) s0[reg] = -INFINITY;
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_bf16_kernel(AttnGeomB g, cons
             rs += s0[reg] + s1[reg];
         }
         rs += __shfl_xor(rs, 32);
-        l = l * alpha + rs;
+        l = fmaf(l, alpha, rs);
         m = mn;
         o0 *= alpha; o1 *= alpha;
         mma_accop_b_bf(o0, s0, vtc, 0, lane);              // o[reg] = O^T[d = 32*blk + krow][query = r]
@@ -192,6 +200,12 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_bf16_kernel(AttnGeomB g, cons
         tile_lstore<128>(kt[cur ^ 1], kr, k0 + 64, g.T, tid);
         tile_lstore<128>(vt[cur ^ 1], vr, k0 + 64, g.T, tid);
         __syncthreads();
+        cur ^= 1;
+    };
+    {
+        int k0 = 0;
+        for (; k0 + 128 <= g.T; k0 += 64) step(k0, std::false_type{});
+        for (; k0 < g.T; k0 += 64) step(k0, std::true_type{});
     }
     if (q0 + r < g.T) {
         const float inv = 1.f / l;
@@ -347,22 +361,31 @@ __global__ __launch_bounds__(128, 4) void attn_delta_bf16_kernel(AttnGeomB g, co
         const float* grow = gm + (int64_t)b * gm_sb;
         bf16x8 kreg[4], knext[4];
         load_rows_bf(kreg, k + base, g.st, 0, g.T, lane);
-        for (int k0 = 0; k0 < g.T; k0 += 32) {
-            load_rows_bf(knext, k + base, g.st, k0 + 32, g.T, lane);       // prefetch next key rows (clamped)
+        auto step = [&](int k0, auto edge_tag) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            load_rows_bf<EDGE>(knext, k + base, g.st, k0 + 32, g.T, lane);       // prefetch next key rows
             const int key = k0 + r;
-            const int kc = min(key, g.T - 1);
+            const int kc = EDGE ? min(key, g.T - 1) : key;
             float gv[16];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) gv[reg] = grow[goff[reg] + kc];
             ACR_MEMBAR();
             f32x16 s = {0};
             mma_rowop_bf(s, qs + wave * 32 * BP, kreg, lane);   // S raw [query = krow][key = k0 + r]
-            const float kmask = (key < g.T) ? 1.f : 0.f;
+            const float kmask = (!EDGE || key < g.T) ? 1.f : 0.f;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                rho[reg] = fmaf(fast_exp2(fmaf(s[reg], c, -l2r[reg])) * kmask, gv[reg], rho[reg]);
+            for (int reg = 0; reg < 16; ++reg) {
+                float pg = fast_exp2(fmaf(s[reg], c, -l2r[reg]));
+                if (EDGE) pg *= kmask;
+                rho[reg] = fmaf(pg, gv[reg], rho[reg]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) kreg[i] = knext[i];
+        };
+        {
+            int k0 = 0;
+            for (; k0 + 64 <= g.T; k0 += 32) step(k0, std::false_type{});
+            for (; k0 < g.T; k0 += 32) step(k0, std::true_type{});
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -427,19 +450,23 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
     __syncthreads();
     f32x16 dq0 = {0}, dq1 = {0};
     int cur = 0;
-    for (int k0 = 0; k0 < g.T; k0 += 64, cur ^= 1) {
-        tile_gload<128>(kr, k + base, g.st, k0 + 64, g.T, tid);
-        tile_gload<128>(vr, v + base, g.st, k0 + 64, g.T, tid);
+    // one step = 64 keys.  EDGE steps (the partial last tile, and the step that prefetches it) carry the clamps and
+    // the key masks; all other steps are straight-line code without a single compare/select.
+    auto step = [&](int k0, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        tile_gload<128, EDGE>(kr, k + base, g.st, k0 + 64, g.T, tid);
+        tile_gload<128, EDGE>(vr, v + base, g.st, k0 + 64, g.T, tid);
         f32x4 gq[2][4];
         if (HAS_G) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int grp = 0; grp < 4; ++grp)
-                    __builtin_memcpy(&gq[kb][grp], grow + min(k0 + 32 * kb + 8 * grp, gmax), 16);
+                for (int grp = 0; grp < 4; ++grp) {
+                    const int go = k0 + 32 * kb + 8 * grp;
+                    __builtin_memcpy(&gq[kb][grp], grow + (EDGE ? min(go, gmax) : go), 16);
+                }
         }
         ACR_MEMBAR();
-        const bool tail = k0 + 64 > g.T;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const bf16_t* ktc = kt[cur] + kb * 32 * BP;
@@ -451,13 +478,13 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 float p = fast_exp2(fmaf(s[reg], c, -l2));
-                float gv = HAS_G ? gq[kb][reg >> 2][reg & 3] * invH : 0.f;
-                if (tail) {                                 // pad columns of G may hold anything: select, don't multiply
+                float t = HAS_G ? fmaf(gq[kb][reg >> 2][reg & 3], invH, dp[reg]) : dp[reg];
+                if (EDGE) {                                 // pad columns of G may hold anything: select, don't multiply
                     const bool kv = k0 + 32 * kb + acr_krow(reg, hh) < g.T;
                     p = kv ? p : 0.f;
-                    gv = kv ? gv : 0.f;
+                    t = kv ? t : 0.f;
                 }
-                ds[reg] = p * (dp[reg] + gv - dl);
+                ds[reg] = p * (t - dl);
             }
             mma_accop_a_bf(dq0, ds, ktc, 0, lane);          // dQ[query = krow][d = 32*blk + r]
             mma_accop_a_bf(dq1, ds, ktc, 1, lane);
@@ -466,7 +493,11 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
         tile_lstore<128>(kt[cur ^ 1], kr, k0 + 64, g.T, tid);
         tile_lstore<128>(vt[cur ^ 1], vr, k0 + 64, g.T, tid);
         __syncthreads();
-    }
+        cur ^= 1;
+    };
+    int k0 = 0;
+    for (; k0 + 128 <= g.T; k0 += 64) step(k0, std::false_type{});
+    for (; k0 < g.T; k0 += 64) step(k0, std::true_type{});
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int qq = q0 + acr_krow(reg, hh);
@@ -525,23 +556,29 @@ __global__ __launch_bounds__(128, 2) void attn_dkdv_bf16_kernel(AttnGeomB g, con
     __syncthreads();
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
     int cur = 0;
-    for (int q0 = 0; q0 < g.T; q0 += 64, cur ^= 1) {
-        // Register diet (this kernel sat at 318 VGPR+AGPR = 1 wave/SIMD): the next Q tile and the G values of the
-        // first 32 queries are fetched before the first half's MFMAs, the next dO tile and the second half's G values
-        // only before the second half, so at most one staging tile + 16 G values are live beside the accumulators.
+    // Register diet (this kernel sat at 318 VGPR+AGPR = 1 wave/SIMD): the next Q tile and the G values of the first
+    // 32 queries are fetched before the first half's MFMAs, the next dO tile and the second half's G values only
+    // before the second half.  EDGE steps (partial last query tile / the step prefetching it) carry clamps and masks.
+    auto step = [&](int q0, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             if (qb == 0) {
-                tile_gload<128>(qr, q + base, g.st, q0 + 64, g.T, tid);
-                if (tid < 64) { const int qn = min(q0 + 64 + tid, g.T - 1); lnext = lrow[qn]; dnext = drow[qn]; }
+                tile_gload<128, EDGE>(qr, q + base, g.st, q0 + 64, g.T, tid);
+                if (tid < 64) {
+                    const int qn = EDGE ? min(q0 + 64 + tid, g.T - 1) : q0 + 64 + tid;
+                    lnext = lrow[qn]; dnext = drow[qn];
+                }
             } else {
-                tile_gload<128>(dr, d_o + obase, g.ost, q0 + 64, g.T, tid);
+                tile_gload<128, EDGE>(dr, d_o + obase, g.ost, q0 + 64, g.T, tid);
             }
             float gv[16];
             if (HAS_G) {
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    gv[reg] = gbase[min(q0 + 32 * qb + acr_krow(reg, hh), g.T - 1) * gst];
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int qq = q0 + 32 * qb + acr_krow(reg, hh);
+                    gv[reg] = gbase[(EDGE ? min(qq, g.T - 1) : qq) * gst];
+                }
             }
             ACR_MEMBAR();
             const bf16_t* qtc = qtile[cur] + qb * 32 * BP;
@@ -555,7 +592,8 @@ __global__ __launch_bounds__(128, 2) void attn_dkdv_bf16_kernel(AttnGeomB g, con
                 const int kr = 32 * qb + acr_krow(reg, hh);
                 const float pv = fast_exp2(fmaf(s[reg], c, -l2s[cur][kr])) * kmask;   // lse = +inf beyond T -> 0
                 p[reg] = pv;
-                ds[reg] = pv * (dp[reg] + (HAS_G ? gv[reg] * invH : 0.f) - dls[cur][kr]);
+                const float t = HAS_G ? fmaf(gv[reg], invH, dp[reg]) : dp[reg];
+                ds[reg] = pv * (t - dls[cur][kr]);
             }
             mma_accop_a_bf(dv0, p, dtc, 0, lane);           // dV[key = krow][d = 32*blk + r]
             mma_accop_a_bf(dv1, p, dtc, 1, lane);
@@ -569,11 +607,17 @@ __global__ __launch_bounds__(128, 2) void attn_dkdv_bf16_kernel(AttnGeomB g, con
         ACR_MEMBAR();
         tile_lstore<128>(dotile[cur ^ 1], dr, q0 + 64, g.T, tid);
         if (tid < 64) {
-            const bool ok = q0 + 64 + tid < g.T;
+            const bool ok = !EDGE || q0 + 64 + tid < g.T;
             l2s[cur ^ 1][tid] = ok ? lnext : INFINITY;
             dls[cur ^ 1][tid] = ok ? dnext : 0.f;
         }
         __syncthreads();
+        cur ^= 1;
+    };
+    {
+        int q0 = 0;
+        for (; q0 + 128 <= g.T; q0 += 64) step(q0, std::false_type{});
+        for (; q0 < g.T; q0 += 64) step(q0, std::true_type{});
     }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
