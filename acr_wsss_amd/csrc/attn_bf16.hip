@@ -305,16 +305,18 @@ __global__ __launch_bounds__(256) void attn_tile_qk_bf16_kernel(AttnGeomB g, con
 
 // ---------------------------------------------------------------------------------------------
 // delta[b,h,i] = rowsum(dO*O) + (1/H) sum_j P_h[i,j] G[b,i,j]
+// Same skeleton as the dQ sweep (query on the lane, K tiles double-buffered in LDS, G pulled as 16-byte groups of
+// the lane's own row): the row sum over keys is then an in-lane accumulation + one cross-half add, and a 64-key step
+// needs 8 G loads instead of 32 coalesced scalar ones.
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_G>
-__global__ __launch_bounds__(128, 4) void attn_delta_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
-                                                              const bf16_t* __restrict__ k, const bf16_t* __restrict__ o,
-                                                              const bf16_t* __restrict__ d_o,
-                                                              const float* __restrict__ lse2,
-                                                              const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
-                                                              float* __restrict__ delta) {
-    __shared__ __attribute__((aligned(16))) bf16_t qs[64 * BP];
-    __shared__ float dsh[64];
+__global__ __launch_bounds__(128, 2) void attn_delta_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ q,
+                                                                 const bf16_t* __restrict__ k, const bf16_t* __restrict__ o,
+                                                                 const bf16_t* __restrict__ d_o,
+                                                                 const float* __restrict__ lse2,
+                                                                 const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
+                                                                 float* __restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) bf16_t kt[2][64 * BP];
     const int nqt = (g.T + 63) >> 6;
     int id = acr_xcd_remap(blockIdx.x, gridDim.x);
     const int qt = id % nqt; id /= nqt;
@@ -326,9 +328,10 @@ __global__ __launch_bounds__(128, 4) void attn_delta_bf16_kernel(AttnGeomB g, co
     const int64_t base = (int64_t)b * g.sb + (int64_t)h * g.sh;
     const int64_t obase = (int64_t)b * g.osb + (int64_t)h * g.osh;
     const float c = g.scale * ACR_LOG2E;
+    const bool qok = q0 + r < g.T;
+    const int qc = min(q0 + r, g.T - 1);
     float part = 0.f;
     {
-        const int qc = min(q0 + r, g.T - 1);
         const bf16_t* op = o + obase + (int64_t)qc * g.ost + 32 * hh;
         const bf16_t* dp = d_o + obase + (int64_t)qc * g.ost + 32 * hh;
 #pragma unroll
@@ -339,69 +342,61 @@ __global__ __launch_bounds__(128, 4) void attn_delta_bf16_kernel(AttnGeomB g, co
             for (int e = 0; e < 8; ++e) part = fmaf((float)a[e], (float)d8[e], part);
         }
     }
-    part += __shfl_xor(part, 32);
-    if (hh == 0) dsh[wave * 32 + r] = part;
-    float rho[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) rho[reg] = 0.f;
+    float rho = 0.f;
     if (HAS_G) {
-        stage_tile_bf<64, 128>(qs, q + base, g.st, qt * 64, g.T, tid);
-        float l2r[16];
-        int goff[16];
-        const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int qq = q0 + acr_krow(reg, hh);
-            // rows beyond T: lse = +inf -> p = exp2(-inf) = 0, so no per-element guard is needed on the G load
-            const float lv = lrow[min(qq, g.T - 1)];
-            l2r[reg] = (qq < g.T) ? lv : INFINITY;
-            goff[reg] = min(qq, g.T - 1) * (int)gm_st;
-        }
+        bf16x8 qreg[4];
+        load_rows_bf(qreg, q + base, g.st, q0, g.T, lane);
+        const float l2v = lse2[((int64_t)b * g.H + h) * g.T + qc];
+        const float l2 = qok ? l2v : INFINITY;              // rows beyond T: p = exp2(-inf) = 0
+        const float* grow = gm + (int64_t)b * gm_sb + (int64_t)qc * gm_st + 4 * hh;
+        const int gmax = (int)gm_st - 4 - 4 * hh;
+        TileRegs<128> kr;
+        tile_gload<128>(kr, k + base, g.st, 0, g.T, tid);
+        ACR_MEMBAR();
+        tile_lstore<128>(kt[0], kr, 0, g.T, tid);
         __syncthreads();
-        const float* grow = gm + (int64_t)b * gm_sb;
-        bf16x8 kreg[4], knext[4];
-        load_rows_bf(kreg, k + base, g.st, 0, g.T, lane);
+        int cur = 0;
         auto step = [&](int k0, auto edge_tag) {
             constexpr bool EDGE = decltype(edge_tag)::value;
-            load_rows_bf<EDGE>(knext, k + base, g.st, k0 + 32, g.T, lane);       // prefetch next key rows
-            const int key = k0 + r;
-            const int kc = EDGE ? min(key, g.T - 1) : key;
-            float gv[16];
+            tile_gload<128, EDGE>(kr, k + base, g.st, k0 + 64, g.T, tid);
+            f32x4 gq[2][4];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) gv[reg] = grow[goff[reg] + kc];
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    const int go = k0 + 32 * kb + 8 * grp;
+                    __builtin_memcpy(&gq[kb][grp], grow + (EDGE ? min(go, gmax) : go), 16);
+                }
             ACR_MEMBAR();
-            f32x16 s = {0};
-            mma_rowop_bf(s, qs + wave * 32 * BP, kreg, lane);   // S raw [query = krow][key = k0 + r]
-            const float kmask = (!EDGE || key < g.T) ? 1.f : 0.f;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                float pg = fast_exp2(fmaf(s[reg], c, -l2r[reg]));
-                if (EDGE) pg *= kmask;
-                rho[reg] = fmaf(pg, gv[reg], rho[reg]);
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 s = {0};
+                mma_rowop_bf(s, kt[cur] + kb * 32 * BP, qreg, lane);     // S^T raw [key = krow][query = r]
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float p = fast_exp2(fmaf(s[reg], c, -l2));
+                    float gv = gq[kb][reg >> 2][reg & 3];
+                    if (EDGE) {
+                        const bool kv = k0 + 32 * kb + acr_krow(reg, hh) < g.T;
+                        p = kv ? p : 0.f;
+                        gv = kv ? gv : 0.f;
+                    }
+                    rho = fmaf(p, gv, rho);
+                }
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) kreg[i] = knext[i];
+            ACR_MEMBAR();
+            tile_lstore<128>(kt[cur ^ 1], kr, k0 + 64, g.T, tid);
+            __syncthreads();
+            cur ^= 1;
         };
-        {
-            int k0 = 0;
-            for (; k0 + 64 <= g.T; k0 += 32) step(k0, std::false_type{});
-            for (; k0 < g.T; k0 += 32) step(k0, std::true_type{});
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) rho[reg] += __shfl_xor(rho[reg], off);
-        }
+        int k0 = 0;
+        for (; k0 + 128 <= g.T; k0 += 64) step(k0, std::false_type{});
+        for (; k0 < g.T; k0 += 64) step(k0, std::true_type{});
     }
-    __syncthreads();
-    if (r == 0) {
-        const float invH = 1.f / (float)g.H;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int kr = acr_krow(reg, hh);
-            if (q0 + kr < g.T) delta[((int64_t)b * g.H + h) * g.T + q0 + kr] = dsh[wave * 32 + kr] + rho[reg] * invH;
-        }
-    }
+    // both halves of a lane pair (r, r+32) hold partial sums of the same query row
+    part += __shfl_xor(part, 32);
+    rho += __shfl_xor(rho, 32);
+    if (hh == 0 && qok) delta[((int64_t)b * g.H + h) * g.T + q0 + r] = part + rho * (1.f / (float)g.H);
 }
 
 // ---------------------------------------------------------------------------------------------
