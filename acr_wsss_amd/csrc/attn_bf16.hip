@@ -227,6 +227,72 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_bf16_kernel(AttnGeomB g, cons
 // ---------------------------------------------------------------------------------------------
 enum { TQKB_PMEAN = 0, TQKB_PROBS = 1, TQKB_DPROBS = 2 };
 
+template <int MODE, bool EDGE>
+__device__ __forceinline__ void tile_qk_body(const AttnGeomB& g, const bf16_t* __restrict__ xq, const bf16_t* __restrict__ xk,
+                                             const float* __restrict__ lse2, float* __restrict__ out, int64_t out_sb,
+                                             int64_t out_st, bf16_t (*qs)[64 * BP], bf16_t (*ks)[64 * BP], int b, int hsel,
+                                             int q0, int k0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wq = wave >> 1, wk = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const bool is_q = (MODE != TQKB_DPROBS);
+    const float c = g.scale * ACR_LOG2E;
+    const int64_t qsb = is_q ? g.sb : g.osb, qsh = is_q ? g.sh : g.osh, qst = is_q ? g.st : g.ost;
+    const int h_lo = (MODE == TQKB_PMEAN) ? 0 : hsel, h_hi = (MODE == TQKB_PMEAN) ? g.H : hsel + 1;
+    TileRegs<256> qr, kr;
+    tile_gload<256, EDGE>(qr, xq + (int64_t)b * qsb + (int64_t)h_lo * qsh, qst, q0, g.T, tid);
+    tile_gload<256, EDGE>(kr, xk + (int64_t)b * g.sb + (int64_t)h_lo * g.sh, g.st, k0, g.T, tid);
+    ACR_MEMBAR();
+    tile_lstore<256>(qs[0], qr, q0, g.T, tid);
+    tile_lstore<256>(ks[0], kr, k0, g.T, tid);
+    __syncthreads();
+    // query on the lane (S^T[key = krow][query = r]): the row log-sum-exp is ONE coalesced load per head and lane
+    const int qlane = EDGE ? min(q0 + wq * 32 + r, g.T - 1) : q0 + wq * 32 + r;
+    f32x16 acc = {0};
+    int cur = 0;
+    for (int h = h_lo; h < h_hi; ++h, cur ^= 1) {
+        const int hn = min(h + 1, g.H - 1);
+        if (MODE == TQKB_PMEAN) {
+            tile_gload<256, EDGE>(qr, xq + (int64_t)b * qsb + (int64_t)hn * qsh, qst, q0, g.T, tid);
+            tile_gload<256, EDGE>(kr, xk + (int64_t)b * g.sb + (int64_t)hn * g.sh, g.st, k0, g.T, tid);
+        }
+        float lv = 0.f;
+        if (MODE != TQKB_DPROBS) lv = lse2[((int64_t)b * g.H + h) * g.T + qlane];
+        ACR_MEMBAR();
+        bf16x8 qreg[4];
+        load_rows_lds_bf(qreg, qs[cur] + wq * 32 * BP, lane);
+        f32x16 s = {0};
+        mma_rowop_bf(s, ks[cur] + wk * 32 * BP, qreg, lane);    // s[reg] = X^T[key = krow][query = r]
+        if (MODE == TQKB_DPROBS) {
+            acc = s;
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[reg] += fast_exp2(fmaf(s[reg], c, -lv));
+        }
+        if (MODE == TQKB_PMEAN) {
+            ACR_MEMBAR();
+            tile_lstore<256>(qs[cur ^ 1], qr, q0, g.T, tid);
+            tile_lstore<256>(ks[cur ^ 1], kr, k0, g.T, tid);
+        }
+        __syncthreads();
+    }
+    // transpose the wave's 32x32 tile through LDS (free now) so every store instruction writes 128 contiguous bytes
+    float* tt = reinterpret_cast<float*>(&qs[0][0]) + wave * (32 * 33);
+    const float mul = (MODE == TQKB_PMEAN) ? 1.f / (float)g.H : 1.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) tt[r * 33 + acr_krow(reg, hh)] = acc[reg] * mul;
+    float* ob = (MODE == TQKB_PMEAN) ? out + (int64_t)b * out_sb : out + ((int64_t)b * g.H + hsel) * (int64_t)g.T * g.T;
+    const int64_t ost = (MODE == TQKB_PMEAN) ? out_st : (int64_t)g.T;
+    const int key = k0 + wk * 32 + r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ql = 2 * i + hh;
+        const int qq = q0 + wq * 32 + ql;
+        const float v = tt[ql * 33 + r];
+        if (!EDGE || (qq < g.T && key < g.T)) ob[(int64_t)qq * ost + key] = v;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void attn_tile_qk_bf16_kernel(AttnGeomB g, const bf16_t* __restrict__ xq,
                                                                 const bf16_t* __restrict__ xk,
@@ -240,67 +306,11 @@ __global__ __launch_bounds__(256) void attn_tile_qk_bf16_kernel(AttnGeomB g, con
     const int qti = id % nt; id /= nt;
     int b, hsel;
     if (MODE == TQKB_PMEAN) { b = id; hsel = 0; } else { hsel = id % g.H; b = id / g.H; }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wq = wave >> 1, wk = wave & 1;
-    const int r = lane & 31, hh = lane >> 5;
     const int q0 = qti * 64, k0 = kti * 64;
-    const bool is_q = (MODE != TQKB_DPROBS);
-    const float c = g.scale * ACR_LOG2E;
-    const int64_t qsb = is_q ? g.sb : g.osb, qsh = is_q ? g.sh : g.osh, qst = is_q ? g.st : g.ost;
-    const int h_lo = (MODE == TQKB_PMEAN) ? 0 : hsel, h_hi = (MODE == TQKB_PMEAN) ? g.H : hsel + 1;
-    TileRegs<256> qr, kr;
-    tile_gload<256>(qr, xq + (int64_t)b * qsb + (int64_t)h_lo * qsh, qst, q0, g.T, tid);
-    tile_gload<256>(kr, xk + (int64_t)b * g.sb + (int64_t)h_lo * g.sh, g.st, k0, g.T, tid);
-    ACR_MEMBAR();
-    tile_lstore<256>(qs[0], qr, q0, g.T, tid);
-    tile_lstore<256>(ks[0], kr, k0, g.T, tid);
-    __syncthreads();
-    int qrow[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) qrow[reg] = min(q0 + wq * 32 + acr_krow(reg, hh), g.T - 1);
-    f32x16 acc = {0};
-    int cur = 0;
-    for (int h = h_lo; h < h_hi; ++h, cur ^= 1) {
-        const int hn = min(h + 1, g.H - 1);
-        if (MODE == TQKB_PMEAN) {
-            tile_gload<256>(qr, xq + (int64_t)b * qsb + (int64_t)hn * qsh, qst, q0, g.T, tid);
-            tile_gload<256>(kr, xk + (int64_t)b * g.sb + (int64_t)hn * g.sh, g.st, k0, g.T, tid);
-        }
-        float lv[16];
-        if (MODE != TQKB_DPROBS) {
-            const float* lrow = lse2 + ((int64_t)b * g.H + h) * g.T;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) lv[reg] = lrow[qrow[reg]];
-        }
-        ACR_MEMBAR();
-        bf16x8 kreg[4];
-        load_rows_lds_bf(kreg, ks[cur] + wk * 32 * BP, lane);
-        f32x16 s = {0};
-        mma_rowop_bf(s, qs[cur] + wq * 32 * BP, kreg, lane);    // s[reg] = X[query = krow][key = r]
-        if (MODE == TQKB_DPROBS) {
-            acc = s;
-        } else {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[reg] += fast_exp2(fmaf(s[reg], c, -lv[reg]));
-        }
-        if (MODE == TQKB_PMEAN) {
-            ACR_MEMBAR();
-            tile_lstore<256>(qs[cur ^ 1], qr, q0, g.T, tid);
-            tile_lstore<256>(ks[cur ^ 1], kr, k0, g.T, tid);
-            __syncthreads();
-        }
-    }
-    const int key = k0 + wk * 32 + r;
-    if (key < g.T) {
-        float* ob = (MODE == TQKB_PMEAN) ? out + (int64_t)b * out_sb : out + ((int64_t)b * g.H + hsel) * (int64_t)g.T * g.T;
-        const int64_t ost = (MODE == TQKB_PMEAN) ? out_st : (int64_t)g.T;
-        const float mul = (MODE == TQKB_PMEAN) ? 1.f / (float)g.H : 1.f;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int qq = q0 + wq * 32 + acr_krow(reg, hh);
-            if (qq < g.T) ob[(int64_t)qq * ost + key] = acc[reg] * mul;
-        }
-    }
+    if (q0 + 64 <= g.T && k0 + 64 <= g.T)
+        tile_qk_body<MODE, false>(g, xq, xk, lse2, out, out_sb, out_st, qs, ks, b, hsel, q0, k0);
+    else
+        tile_qk_body<MODE, true>(g, xq, xk, lse2, out, out_sb, out_st, qs, ks, b, hsel, q0, k0);
 }
 
 // ---------------------------------------------------------------------------------------------
