@@ -391,3 +391,55 @@ extern "C" int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_
 #undef ACR_GEMM_LAUNCH
     return acr_check_launch("acr_linear_bf16");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Bias gradient of the projections: out[n] = sum_m dy[m, n] (fp32 accumulate, bf16 out), two deterministic stages.
+// The stock reduction runs this tall-matrix column sum at ~1.3 TB/s (30 us for 25120 x 768); here each workgroup
+// streams a 256-row slab with 16-byte loads (8 columns per lane) and the slab partials are summed in slab order.
+// ---------------------------------------------------------------------------------------------------------------
+#define CS_ROWS 256
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ dy, int64_t ld, int M, int N,
+                                                             float* __restrict__ part) {
+    const int nvec = N >> 3;                                // 8-column vectors per row
+    const int slab = blockIdx.y, v = blockIdx.x * 64 + (threadIdx.x & 63), rgrp = threadIdx.x >> 6;
+    __shared__ float sh[4][64][8];
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (v < nvec) {
+        const int r0 = slab * CS_ROWS, r1 = min(r0 + CS_ROWS, M);
+        for (int r = r0 + rgrp; r < r1; r += 4) {
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(dy + (int64_t)r * ld + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)x[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[rgrp][threadIdx.x & 63][e] = acc[e];
+    __syncthreads();
+    if (rgrp == 0 && v < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            part[(int64_t)slab * N + v * 8 + e] = sh[0][threadIdx.x][e] + sh[1][threadIdx.x][e] + sh[2][threadIdx.x][e] + sh[3][threadIdx.x][e];
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nslab, int N,
+                                                           bf16_t* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int i = 0; i < nslab; ++i) s += part[(int64_t)i * N + n];
+    out[n] = (bf16_t)s;
+}
+
+extern "C" size_t acr_colsum_ws_floats(int32_t M, int32_t N) { return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * (size_t)N; }
+
+extern "C" int acr_colsum_bf16(const void* dy, int64_t ld, int32_t M, int32_t N, float* ws, void* out, void* stream) {
+    ACR_CHECK_ARG(dy && ws && out, "acr_colsum_bf16: null pointer");
+    ACR_CHECK_ARG(M > 0 && N > 0 && (N % 8) == 0 && (ld % 8) == 0 && ld >= N && ((uintptr_t)dy & 15) == 0,
+                  "acr_colsum_bf16: need N %% 8 == 0, ld %% 8 == 0 and a 16-byte aligned matrix (M=%d N=%d)", M, N);
+    const int nslab = (M + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N / 8 + 63) / 64, nslab), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dy, ld, M, N, ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
+                       nslab, N, (bf16_t*)out);
+    return acr_check_launch("acr_colsum_bf16");
+}

@@ -179,6 +179,18 @@ def linear_bf16(x, weight, bias=None, resid=None, out=None):
     return out
 
 
+def colsum_bf16(dy2):
+    """Column sums of a (M, N) bf16 matrix -> (N,) bf16 (bias gradient), deterministic two-stage HIP reduction."""
+    M, N = dy2.shape
+    lib = L.load()
+    if N % 8 or dy2.stride(1) != 1 or dy2.stride(0) % 8 or dy2.data_ptr() % 16:
+        return dy2.sum(dim=0)
+    ws = torch.empty(lib.acr_colsum_ws_floats(M, N), dtype=torch.float32, device=dy2.device)
+    out = torch.empty(N, dtype=torch.bfloat16, device=dy2.device)
+    L.check(lib.acr_colsum_bf16(L.ptr(dy2), dy2.stride(0), M, N, L.ptr(ws), L.ptr(out), L.stream_ptr()), "acr_colsum_bf16")
+    return out
+
+
 class LinearBf16Fn(Function):
     """y = x W^T + b (+ resid) for the attention block's qkv / proj Linears in the bf16 mode, on the hand-written
     MFMA GEMM for forward and input gradient; the weight gradient (a reduction over all tokens) stays on
@@ -211,7 +223,7 @@ class LinearBf16Fn(Function):
         if ctx.needs_input_grad[1]:
             dw = torch.mm(dy2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(dim=0)
+            db = colsum_bf16(dy2)
         return dx, dw, db, (dy if ctx.has_resid else None), None
 
 

@@ -94,6 +94,11 @@ int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, cons
                     const void* resid, int64_t ldr, void* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
                     void* stream);
 
+/* Bias gradient of a projection: out[n] = sum_m dy[m, n], bf16 in/out, fp32 two-stage deterministic accumulation.
+ * ws: caller-owned fp32 scratch of acr_colsum_ws_floats(M, N) floats.  N and ld multiples of 8. */
+size_t acr_colsum_ws_floats(int32_t M, int32_t N);
+int acr_colsum_bf16(const void* dy, int64_t ld, int32_t M, int32_t N, float* ws, void* out, void* stream);
+
 /* ---- ResNetV2 stem: fused GroupNorm(32) [+ residual] [+ ReLU], bf16 NCHW ----
  * models/layers/norm_act.py:69-85 (GroupNormAct), models/resnetv2.py:205-215 (norm3 -> act3(x + shortcut)).
  * act: 0 = none, 1 = ReLU, 2 = ReLU(gn(x) + resid).  x/resid/y: (N,C,H,W) contiguous, HW = H*W (multiple of 8),
