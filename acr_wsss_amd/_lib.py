@@ -46,6 +46,9 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "acr_linear_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int32, c_int32, c_int32, c_void_p]),
+    "acr_wgrad_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),
+    "acr_wgrad_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                 c_void_p]),
     "acr_colsum_ws_floats": (c_size_t, [c_int32, c_int32]),
     "acr_colsum_bf16": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "acr_groupnorm_fwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,

@@ -194,7 +194,9 @@ class Mlp(nn.Module):
         """fc2(gelu(fc1(x))) [+ resid].  On the bf16 path fc2 runs on the hand-written GEMM with the block's residual
         add fused into its epilogue (ties hipBLASLt on this long-K shape and saves the add kernel); fc1 and the
         input gradients stay on hipBLASLt, which is faster on the short-K / wide-N shapes (scripts/bench_gemm.py)."""
-        h = self.act(self.fc1(x))
+        # fc1: forward and input gradient on hipBLASLt (faster on this short-K / wide-N shape), weight and bias gradient
+        # on the hand-written split-M TN GEMM / column-sum kernels (scripts/bench_gemm.py)
+        h = self.act(ops.linear_or_hip(x, self.fc1, None, Attention.hip_linear, hip_dx=False, hip_fwd=False))
         return ops.linear_or_hip(h, self.fc2, resid, Attention.hip_linear, hip_dx=False)
 
 

@@ -443,3 +443,157 @@ extern "C" int acr_colsum_bf16(const void* dy, int64_t ld, int32_t M, int32_t N,
                        nslab, N, (bf16_t*)out);
     return acr_check_launch("acr_colsum_bf16");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the projections ("TN"): dW[N,K] = dY[M,N]^T . X[M,K], contraction over the M = B*T tokens.
+// Both operands are stored with the contraction index as the ROW, so both MFMA fragments come from the hardware
+// transpose read (ds_read_b64_tr_b16) of row-major [64 m][128 n|k] LDS tiles filled by LDS-DMA; 256-byte rows would
+// put the 4 rows of a transpose read on the same banks, so 16-byte chunk c of row m is stored at chunk
+// c ^ ((m & 3) << 2) (source-side swizzle, mirrored on the read) -> the four 64-byte row segments of a 32-lane half
+// cover all 64 banks.  The output is small (N*K) and the contraction long, so the M range is split over S workgroups
+// per 128x128 tile (S chosen to fill ~2 workgroups per CU); fp32 partial slabs are summed in split order by a second
+// kernel -- deterministic, no float atomics.
+// ---------------------------------------------------------------------------------------------------------------
+#define WG_TILE (64 * 128)            // elements per operand tile
+
+__device__ __forceinline__ void wg_stage(bf16_t* ldsbuf, const bf16_t* g, int64_t ld, int m0, int M, int col0,
+                                         int wave, int lane) {
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rbase = (wave * 4 + i) * 4;                // 4 rows (1 KiB) per DMA instruction
+        const int row = rbase + (lane >> 4);
+        const int lc = (lane & 15) ^ ((row & 3) << 2);
+        const bf16_t* src = g + (int64_t)min(m0 + row, M - 1) * ld + col0 + lc * 8;
+        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(ldsbuf + rbase * 128), 16, 0, 0);
+    }
+}
+// fragment for k-step s (16 contraction rows) and 32-column block blk: element j of lane half h = tile[16s + 8(j>>2) + 4h + (j&3)][32 blk + (l&31)]
+__device__ __forceinline__ bf16x8 wg_frag(const bf16_t* tile, int s, int blk, int lane) {
+    const int i = lane & 15, h = lane >> 5;
+    const int row = 16 * s + 4 * h + (i >> 2);
+    const int col = 32 * blk + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+    const int sw = ((col >> 3) ^ ((row & 3) << 2)) << 3;     // row + 8 has the same (row & 3)
+    const bf16_t* a0 = tile + row * 128 + sw + (col & 7);
+    typedef __attribute__((address_space(3))) bf16x4* lds_p;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + 8 * 128));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ dY, int64_t ldy,
+                                                           const bf16_t* __restrict__ X, int64_t ldx,
+                                                           float* __restrict__ slabs, int M, int N, int K, int nsplit,
+                                                           int steps_per_split) {
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[4 * WG_TILE];      // [A0 | B0 | A1 | B1]
+    const int ntk = K >> 7, ntn = N >> 7;
+    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id % nsplit; id /= nsplit;
+    const int tk = id % ntk, tn = id / ntk;
+    (void)ntn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int total_steps = (M + 63) >> 6;
+    const int st0 = split * steps_per_split, st1 = min(st0 + steps_per_split, total_steps);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (st0 < st1) {
+        wg_stage(smem, dY, ldy, st0 * 64, M, tn * 128, wave, lane);
+        wg_stage(smem + WG_TILE, X, ldx, st0 * 64, M, tk * 128, wave, lane);
+        __syncthreads();
+        int cur = 0;
+        for (int stp = st0; stp < st1; ++stp, cur ^= 1) {
+            if (stp + 1 < st1) {
+                wg_stage(smem + (cur ^ 1) * 2 * WG_TILE, dY, ldy, (stp + 1) * 64, M, tn * 128, wave, lane);
+                wg_stage(smem + (cur ^ 1) * 2 * WG_TILE + WG_TILE, X, ldx, (stp + 1) * 64, M, tk * 128, wave, lane);
+            }
+            bf16_t* as = smem + cur * 2 * WG_TILE;
+            const bf16_t* bs = as + WG_TILE;
+            if (stp * 64 + 64 > M) {
+                // ragged last chunk: rows >= M alias row M-1 (clamped DMA); zero them in the dY tile so they add nothing
+                for (int idx = tid; idx < 64 * 16; idx += 256) {
+                    const int row = idx >> 4;
+                    if (stp * 64 + row >= M) {
+                        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                        *reinterpret_cast<bf16x8*>(as + row * 128 + (idx & 15) * 8) = z;
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 a0 = wg_frag(as, s, 2 * wi, lane), a1 = wg_frag(as, s, 2 * wi + 1, lane);
+                const bf16x8 b0 = wg_frag(bs, s, 2 * wj, lane), b1 = wg_frag(bs, s, 2 * wj + 1, lane);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    // acc[ni][kj][reg] = dW[tn*128 + 32(2wi+ni) + krow(reg,hh)][tk*128 + 32(2wj+kj) + r]
+    float* slab = slabs + (int64_t)split * N * K;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int kj = 0; kj < 2; ++kj)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int n = tn * 128 + 32 * (2 * wi + ni) + acr_krow(reg, hh);
+                const int kk = tk * 128 + 32 * (2 * wj + kj) + r;
+                slab[(int64_t)n * K + kk] = acc[ni][kj][reg];
+            }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, int64_t nk,
+                                                           bf16_t* __restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= nk) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
+    for (int sp = 1; sp < nsplit; ++sp) s += *reinterpret_cast<const f32x4*>(slabs + (int64_t)sp * nk + i);
+    acr_store4<bf16_t>(out + i, s);
+}
+
+static int wgrad_split(int M, int N, int K) {
+    const int tiles = (N / 128) * (K / 128);
+    int s = 512 / tiles;                                     // ~2 resident workgroups per CU
+    const int total_steps = (M + 63) / 64;
+    if (s < 1) s = 1;
+    if (s > 32) s = 32;
+    if (s > total_steps) s = total_steps;
+    return s;
+}
+
+extern "C" size_t acr_wgrad_ws_floats(int32_t M, int32_t N, int32_t K) {
+    if (N <= 0 || K <= 0 || (N % 128) || (K % 128)) return 0;
+    return (size_t)wgrad_split(M, N, K) * (size_t)N * (size_t)K;
+}
+
+extern "C" int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int32_t M, int32_t N, int32_t K,
+                              float* ws, void* dw, void* stream) {
+    ACR_CHECK_ARG(dy && x && ws && dw, "acr_wgrad_bf16: null pointer");
+    ACR_CHECK_ARG(M > 0 && N > 0 && K > 0 && (N % 128) == 0 && (K % 128) == 0, "acr_wgrad_bf16: N and K must be multiples of 128 (N=%d K=%d)", N, K);
+    ACR_CHECK_ARG((ldy % 8) == 0 && (ldx % 8) == 0 && ldy >= N && ldx >= K && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0,
+                  "acr_wgrad_bf16: row pitches must be multiples of 8 elements and operands 16-byte aligned");
+    const int nsplit = wgrad_split(M, N, K);
+    const int total_steps = (M + 63) / 64;
+    const int sps = (total_steps + nsplit - 1) / nsplit;
+    const int tiles = (N / 128) * (K / 128);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tiles * nsplit), dim3(256), 0, st, (const bf16_t*)dy, ldy, (const bf16_t*)x,
+                       ldx, ws, M, N, K, nsplit, sps);
+    const int64_t nk = (int64_t)N * K;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsplit,
+                       nk, (bf16_t*)dw);
+    return acr_check_launch("acr_wgrad_bf16");
+}

@@ -191,18 +191,40 @@ def colsum_bf16(dy2):
     return out
 
 
+def wgrad_bf16(dy2, x2):
+    """dW = dy2^T @ x2 ((M,N),(M,K) bf16 -> (N,K) bf16) on the hand-written split-M TN GEMM; shapes it does not
+    cover (N or K not a multiple of 128) go to torch.mm."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    lib = L.load()
+    nws = lib.acr_wgrad_ws_floats(M, N, K)
+    if (nws == 0 or dy2.stride(1) != 1 or x2.stride(1) != 1 or dy2.stride(0) % 8 or x2.stride(0) % 8
+            or dy2.data_ptr() % 16 or x2.data_ptr() % 16):
+        return torch.mm(dy2.t(), x2)
+    ws = torch.empty(nws, dtype=torch.float32, device=dy2.device)
+    dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy2.device)
+    L.check(lib.acr_wgrad_bf16(L.ptr(dy2), dy2.stride(0), L.ptr(x2), x2.stride(0), M, N, K, L.ptr(ws), L.ptr(dw),
+                               L.stream_ptr()), "acr_wgrad_bf16")
+    return dw
+
+
 class LinearBf16Fn(Function):
     """y = x W^T + b (+ resid) for the attention block's qkv / proj Linears in the bf16 mode, on the hand-written
     MFMA GEMM for forward and input gradient; the weight gradient (a reduction over all tokens) stays on
     hipBLASLt through torch.mm."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, resid, hip_dx=True):
-        ctx.hip_dx = hip_dx
+    def forward(ctx, x, weight, bias, resid, hip_dx=True, hip_dw=True, hip_fwd=True):
+        ctx.hip_dx, ctx.hip_dw = hip_dx, hip_dw
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         r2 = resid.reshape(-1, weight.shape[0]) if resid is not None else None
-        y = linear_bf16(x2, weight, bias, r2)
+        if hip_fwd:
+            y = linear_bf16(x2, weight, bias, r2)
+        else:                                               # library GEMM forward, hand-written backward pieces
+            y = torch.nn.functional.linear(x2, weight, bias)
+            if r2 is not None:
+                y = y + r2
         ctx.save_for_backward(x2, weight)
         ctx.has_bias, ctx.has_resid = bias is not None, resid is not None
         return y.reshape(*shp[:-1], weight.shape[0])
@@ -221,18 +243,18 @@ class LinearBf16Fn(Function):
                 dx = torch.mm(dy2, weight)
             dx = dx.reshape(*dy.shape[:-1], weight.shape[1])
         if ctx.needs_input_grad[1]:
-            dw = torch.mm(dy2.t(), x2)
+            dw = wgrad_bf16(dy2, x2) if ctx.hip_dw else torch.mm(dy2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum_bf16(dy2)
-        return dx, dw, db, (dy if ctx.has_resid else None), None
+        return dx, dw, db, (dy if ctx.has_resid else None), None, None, None
 
 
-def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True):
+def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hip_fwd=True):
     """nn.Linear forward; bf16 CUDA tensors with K % 64 == 0 take the hand-written GEMM (resid fused).
     ``hip_dx`` = False leaves the input gradient on hipBLASLt (shapes where the library kernel is faster)."""
     if (use_hip and x.is_cuda and x.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16
             and lin.weight.shape[1] % 64 == 0 and x.is_contiguous()):
-        return LinearBf16Fn.apply(x, lin.weight, lin.bias, resid, hip_dx)
+        return LinearBf16Fn.apply(x, lin.weight, lin.bias, resid, hip_dx, hip_dw, hip_fwd)
     y = torch.nn.functional.linear(x, lin.weight, lin.bias)
     return y if resid is None else resid + y
 

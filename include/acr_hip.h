@@ -94,6 +94,13 @@ int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, cons
                     const void* resid, int64_t ldr, void* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
                     void* stream);
 
+/* Weight gradient of a projection: dw[N,K] = dy[M,N]^T . x[M,K] (bf16, fp32 accumulate), contraction over the M tokens
+ * split over workgroups with fp32 partial slabs summed in a fixed order (deterministic).  N, K multiples of 128.
+ * ws: caller-owned fp32 scratch of acr_wgrad_ws_floats(M, N, K) floats (0 = shape not supported). */
+size_t acr_wgrad_ws_floats(int32_t M, int32_t N, int32_t K);
+int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int32_t M, int32_t N, int32_t K,
+                   float* ws, void* dw, void* stream);
+
 /* Bias gradient of a projection: out[n] = sum_m dy[m, n], bf16 in/out, fp32 two-stage deterministic accumulation.
  * ws: caller-owned fp32 scratch of acr_colsum_ws_floats(M, N) floats.  N and ld multiples of 8. */
 size_t acr_colsum_ws_floats(int32_t M, int32_t N);

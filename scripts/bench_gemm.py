@@ -24,3 +24,17 @@ for (N, K, name) in ((2304, 768, "qkv fwd"), (768, 768, "proj fwd / dx"), (768, 
     fl = 2.0 * M * N * K
     print("%-14s M=%d N=%4d K=%4d  mine %7.1f us (%6.1f TF)  hipBLASLt %7.1f us (%6.1f TF)  relerr %.2e" % (
         name, M, N, K, t_mine, fl / t_mine / 1e6, t_torch, fl / t_torch / 1e6, err))
+
+print("--- weight gradients dW = dY^T X (M = %d) ---" % M)
+for (N, K, name) in ((2304, 768, "qkv dW"), (768, 768, "proj dW"), (3072, 768, "fc1 dW"), (768, 3072, "fc2 dW")):
+    g = torch.Generator().manual_seed(1)
+    dy = torch.randn(M, N, generator=g).to(dev).bfloat16()
+    x = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    dw = ops.wgrad_bf16(dy, x)
+    ref = dy.float().t() @ x.float()
+    err = (dw.float() - ref).abs().max().item() / ref.abs().max().item()
+    t_mine = t(lambda: ops.wgrad_bf16(dy, x))
+    t_torch = t(lambda: torch.mm(dy.t(), x))
+    fl = 2.0 * M * N * K
+    print("%-14s N=%4d K=%4d  mine %7.1f us (%6.1f TF)  hipBLASLt %7.1f us (%6.1f TF)  relerr %.2e" % (
+        name, N, K, t_mine, fl / t_mine / 1e6, t_torch, fl / t_torch / 1e6, err))
