@@ -269,8 +269,10 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x, stack=None, layer=0):
-        x = self.attn(self.norm1(x), stack, layer, resid=x)
-        return self.mlp(self.norm2(x), resid=x)
+        x = self.attn(ops.layer_norm(x, self.norm1, self.hip_norm), stack, layer, resid=x)
+        return self.mlp(ops.layer_norm(x, self.norm2, self.hip_norm), resid=x)
+
+    hip_norm = True         # bf16 mode: LayerNorm on acr_layernorm_*_bf16
 
 
 class VisionTransformer(nn.Module):

@@ -259,6 +259,48 @@ def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hi
     return y if resid is None else resid + y
 
 
+class LayerNormFn(Function):
+    """LayerNorm over the last dim of a bf16 (.., C) tensor on acr_layernorm_{fwd,bwd}_bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        M = x2.shape[0]
+        lib = L.load()
+        y = torch.empty_like(x2)
+        stats = torch.empty(2 * M, dtype=torch.float32, device=x.device)
+        L.check(lib.acr_layernorm_fwd_bf16(L.ptr(x2), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), M, C, eps,
+                                           L.stream_ptr()), "acr_layernorm_fwd_bf16")
+        ctx.save_for_backward(x2, weight, stats)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, stats = ctx.saved_tensors
+        M, C = x2.shape
+        lib = L.load()
+        dy2 = dy.reshape(M, C)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = torch.empty_like(x2)
+        ws = torch.empty(lib.acr_layernorm_ws_floats(M, C), dtype=torch.float32, device=x2.device)
+        dg = torch.empty(C, dtype=torch.bfloat16, device=x2.device)
+        db = torch.empty(C, dtype=torch.bfloat16, device=x2.device)
+        L.check(lib.acr_layernorm_bwd_bf16(L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats), L.ptr(dx), L.ptr(ws),
+                                           L.ptr(dg), L.ptr(db), M, C, L.stream_ptr()), "acr_layernorm_bwd_bf16")
+        return dx.reshape(dy.shape), dg, db, None
+
+
+def layer_norm(x, ln, use_hip=True):
+    """nn.LayerNorm forward; contiguous bf16 CUDA rows with C % 256 == 0 (<= 1024) take the HIP kernels."""
+    C = x.shape[-1]
+    if (use_hip and x.is_cuda and x.dtype == torch.bfloat16 and ln.weight.dtype == torch.bfloat16 and x.is_contiguous()
+            and C % 256 == 0 and C <= 1024):
+        return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
+    return torch.nn.functional.layer_norm(x, (C,), ln.weight, ln.bias, ln.eps)
+
+
 GN_ACT = {"none": 0, "relu": 1, "add_relu": 2}
 
 

@@ -106,6 +106,15 @@ int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int3
 size_t acr_colsum_ws_floats(int32_t M, int32_t N);
 int acr_colsum_bf16(const void* dy, int64_t ld, int32_t M, int32_t N, float* ws, void* out, void* stream);
 
+/* ---- LayerNorm of the transformer blocks (models/vision_transformer.py:219-222,299), bf16 (M, C) rows ----
+ * C a multiple of 256, <= 1024.  stats: (M*2) fp32 [mean, rstd].  Backward writes dx, dgamma, dbeta in one pass over
+ * x and dy; ws: fp32 scratch of acr_layernorm_ws_floats(M, C) floats (per-wave partials, summed in wave order). */
+size_t acr_layernorm_ws_floats(int32_t M, int32_t C);
+int acr_layernorm_fwd_bf16(const void* x, const void* gamma, const void* beta, void* y, float* stats, int32_t M,
+                           int32_t C, float eps, void* stream);
+int acr_layernorm_bwd_bf16(const void* dy, const void* x, const void* gamma, const float* stats, void* dx, float* ws,
+                           void* dgamma, void* dbeta, int32_t M, int32_t C, void* stream);
+
 /* ---- ResNetV2 stem: fused GroupNorm(32) [+ residual] [+ ReLU], bf16 NCHW ----
  * models/layers/norm_act.py:69-85 (GroupNormAct), models/resnetv2.py:205-215 (norm3 -> act3(x + shortcut)).
  * act: 0 = none, 1 = ReLU, 2 = ReLU(gn(x) + resid).  x/resid/y: (N,C,H,W) contiguous, HW = H*W (multiple of 8),

@@ -304,3 +304,29 @@ def test_weight_std_all_fused():
         (ref * gi.double()).sum().backward()
         assert (o.double() - ref).abs().max() <= 1e-2 * ref.abs().max()
         assert (w.grad.double() - wd.grad).abs().max() <= 2e-2 * wd.grad.abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("M,C", [(1, 256), (37, 768), (25120, 768), (130, 1024)])
+def test_layernorm_bf16(M, C):
+    """HIP LayerNorm forward/backward (one-pass backward with dgamma/dbeta) vs torch layer_norm in fp64."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(dev).bfloat16().requires_grad_(True)
+    ln = torch.nn.LayerNorm(C, eps=1e-6).to(dev).bfloat16()
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+        ln.bias.copy_(0.3 * torch.randn(C, generator=g))
+    y = ops.layer_norm(x, ln)
+    assert y.grad_fn is not None and "LayerNormFn" in type(y.grad_fn).__name__
+    dy = torch.randn(M, C, generator=g).to(dev).bfloat16()
+    (y.float() * dy.float()).sum().backward()
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = ln.weight.detach().double().requires_grad_(True), ln.bias.detach().double().requires_grad_(True)
+    ref = F.layer_norm(xd, (C,), wd, bd, 1e-6)
+    (ref * dy.double()).sum().backward()
+    assert (y.double() - ref).abs().max() <= 1.2e-2 * ref.abs().max()
+    assert (x.grad.double() - xd.grad).abs().max() <= 2e-2 * xd.grad.abs().max()
+    assert (ln.weight.grad.double() - wd.grad).abs().max() <= 1e-2 * wd.grad.abs().max() + 1e-2
+    assert (ln.bias.grad.double() - bd.grad).abs().max() <= 1e-2 * bd.grad.abs().max() + 1e-2
