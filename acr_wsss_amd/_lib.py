@@ -51,6 +51,10 @@ SIGNATURES = {
                                  c_void_p]),
     "acr_colsum_ws_floats": (c_size_t, [c_int32, c_int32]),
     "acr_colsum_bf16": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "acr_conv1x1_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "acr_conv1x1_wgrad_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "acr_conv1x1_wgrad_bf16": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                         c_void_p]),
     "acr_layernorm_ws_floats": (c_size_t, [c_int32, c_int32]),
     "acr_layernorm_fwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float,
                                          c_void_p]),

@@ -53,7 +53,11 @@ class StdConv2dSame(nn.Conv2d):
         if self.dynamic_pad:
             x = pad_same(x, self.kernel_size[0], self.stride[0])
         w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
+        if self.hip_1x1 and ops.conv1x1_fusable(x, w_hat, self.stride[0]):
+            return ops.conv1x1(x, w_hat)                    # NCHW 1x1 conv = per-sample MFMA GEMM, no layout transposes
         return F.conv2d(x, w_hat, None, self.stride, self.padding)
+
+    hip_1x1 = True
 
     _w_hat = None           # set for one forward by ResNetV2 when all weights are standardised in one fused launch
 

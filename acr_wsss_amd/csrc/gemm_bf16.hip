@@ -597,3 +597,269 @@ extern "C" int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_
                        nk, (bf16_t*)dw);
     return acr_check_launch("acr_wgrad_bf16");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions of the ResNetV2 stem in NCHW (models/resnetv2.py:186-190 conv1/conv3/downsample, stride 1).
+// MIOpen runs them as NCHW->NHWC transpose + GEMM + transpose back (3x the bytes; 10 of the 64 ms step).  In NCHW a
+// 1x1 convolution IS a GEMM per sample: Y[n] (Cout x HW) = W (Cout x Cin) . X[n] (Cin x HW) with the pixel index
+// contiguous, i.e. the B operand is contraction-strided -- exactly what the transpose-read fragments of the TN kernel
+// handle.  So: A = weight tile [128 co][64 ci] (128-byte rows, chunk swizzle, ds_read_b128 fragments), B = activation
+// tile [64 ci][128 pixels] (256-byte rows, quarter swizzle, ds_read_b64_tr_b16 fragments), both by LDS-DMA, no layout
+// change anywhere.  The same kernel computes the input gradient (A = W^T).  The weight gradient
+// dW[co][ci] = sum_n sum_p dY[n][co][p] X[n][ci][p] has the contraction index contiguous in both operands ("NT"),
+// summed over samples and pixel chunks with fp32 slabs (deterministic).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void c1_stage_b(bf16_t* ldsbuf, const bf16_t* xs, int64_t row_stride, int k0, int p0,
+                                           int64_t max_off, int wave, int lane) {
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rbase = (wave * 4 + i) * 4;
+        const int row = rbase + (lane >> 4);
+        const int lc = (lane & 15) ^ ((row & 3) << 2);
+        int64_t off = (int64_t)(k0 + row) * row_stride + p0 + lc * 8;
+        off = off < max_off ? off : max_off;                 // pixel tiles past HW run into the next row: keep it in bounds
+        __builtin_amdgcn_global_load_lds((glb_vp)(xs + off), (lds_vp)(ldsbuf + rbase * 128), 16, 0, 0);
+    }
+}
+
+// A fragment in the k-slot order of wg_frag: half h, element j <-> k = 16 s + 8 (j >> 2) + 4 h + (j & 3)
+__device__ __forceinline__ bf16x8 c1_frag_a(const bf16_t* ldsbuf, int row, int s, int h) {
+    const int sw = (row >> 1) & 7;
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(ldsbuf + row * 64 + (((2 * s) ^ sw) << 3) + 4 * h);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(ldsbuf + row * 64 + (((2 * s + 1) ^ sw) << 3) + 4 * h);
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
+__global__ __launch_bounds__(256) void conv1x1_nn_kernel(const bf16_t* __restrict__ W, int64_t ldw,
+                                                         const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, int M,
+                                                         int K, int HW, int nsamp) {
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[4 * GL_TILE];      // [A0 | B0 | A1 | B1]
+    const int ntm = (M + 127) >> 7, ntp = (HW + 127) >> 7;
+    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = id % ntm; id /= ntm;
+    const int tp = id % ntp;
+    const int n = id / ntp;
+    const int m0 = tm * 128, p0 = tp * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const bf16_t* xs = X + (int64_t)n * K * HW;
+    const int64_t max_off = (int64_t)(nsamp - n) * K * HW - 8;              // last 16-byte chunk of the tensor, from xs
+    const int nk = K >> 6;
+    glds_stage(smem, W, ldw, m0, M, 0, wave, lane);
+    c1_stage_b(smem + GL_TILE, xs, HW, 0, p0, max_off, wave, lane);
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt, cur ^= 1) {
+        if (kt + 1 < nk) {
+            glds_stage(smem + (cur ^ 1) * 2 * GL_TILE, W, ldw, m0, M, (kt + 1) * 64, wave, lane);
+            c1_stage_b(smem + (cur ^ 1) * 2 * GL_TILE + GL_TILE, xs, HW, (kt + 1) * 64, p0, max_off, wave, lane);
+        }
+        const bf16_t* as = smem + cur * 2 * GL_TILE;
+        const bf16_t* bs = as + GL_TILE;
+        const int ra = wm * 64 + r;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 a0 = c1_frag_a(as, ra, ks, hh), a1 = c1_frag_a(as, ra + 32, ks, hh);
+            const bf16x8 b0 = wg_frag(bs, ks, 2 * wn, lane), b1 = wg_frag(bs, ks, 2 * wn + 1, lane);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // acc[mt][nt][reg] = Y[n][m0 + 64 wm + 32 mt + krow(reg,hh)][p0 + 64 wn + 32 nt + r]; LDS-staged 16-byte stores
+    float* stile = reinterpret_cast<float*>(smem) + wave * 4096;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                stile[(mt * 32 + acr_krow(reg, hh)) * 64 + nt * 32 + r] = acc[mt][nt][reg];
+    bf16_t* ys = Y + (int64_t)n * M * HW;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;
+        const int lrow = idx >> 3, c8 = (idx & 7) * 8;
+        const int row = m0 + wm * 64 + lrow, col = p0 + wn * 64 + c8;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8 + 4);
+        if (row < M && col < HW) {
+            bf16x8 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
+                        (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+            *reinterpret_cast<bf16x8*>(ys + (int64_t)row * HW + col) = o;
+        }
+    }
+}
+
+// dW[co][ci] = sum over (sample, 64-pixel chunk) of dY[n][co][p] X[n][ci][p]; both operands pixel-contiguous (NT).
+__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
+                                                            float* __restrict__ slabs, int M, int N, int HW, int nsamp,
+                                                            int nsplit, int steps_per_split) {
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[4 * GL_TILE];
+    const int ntn = (N + 127) >> 7;
+    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id % nsplit; id /= nsplit;
+    const int tn = id % ntn, tm = id / ntn;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int kps = (HW + 63) >> 6;                          // k-steps per sample
+    const int total = nsamp * kps;
+    const int st0 = split * steps_per_split, st1 = min(st0 + steps_per_split, total);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto stage = [&](bf16_t* buf, int stp) {
+        const int n = stp / kps, k0 = (stp - n * kps) * 64;
+        // rows clamp to the last channel; columns past HW run into the next row (still inside the tensor except at its
+        // very end, which the row clamp + pointer clamp below keep in bounds) and are zeroed in LDS before use
+        const bf16_t* ya = dY + (int64_t)n * M * HW;
+        const bf16_t* xb = X + (int64_t)n * N * HW;
+        typedef __attribute__((address_space(3))) void* lds_vp;
+        typedef const __attribute__((address_space(1))) void* glb_vp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rbase = (wave * 4 + i) * 8;
+            const int row = rbase + (lane >> 3);
+            const int lc = (lane & 7) ^ ((row >> 1) & 7);
+            const int col = min(k0 + lc * 8, HW - 8);                        // keep the 16-byte chunk inside the row
+            __builtin_amdgcn_global_load_lds((glb_vp)(ya + (int64_t)min(m0 + row, M - 1) * HW + col),
+                                             (lds_vp)(buf + rbase * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(xb + (int64_t)min(n0 + row, N - 1) * HW + col),
+                                             (lds_vp)(buf + GL_TILE + rbase * 64), 16, 0, 0);
+        }
+    };
+    if (st0 < st1) {
+        stage(smem, st0);
+        __syncthreads();
+        int cur = 0;
+        for (int stp = st0; stp < st1; ++stp, cur ^= 1) {
+            if (stp + 1 < st1) stage(smem + (cur ^ 1) * 2 * GL_TILE, stp + 1);
+            bf16_t* as = smem + cur * 2 * GL_TILE;
+            const bf16_t* bs = as + GL_TILE;
+            const int k0 = (stp % kps) * 64;
+            if (k0 + 64 > HW) {
+                // ragged last chunk of a sample: chunks whose pixels are >= HW were clamped to the row's last chunk;
+                // zero them in the dY tile so they contribute nothing
+                for (int idx = tid; idx < 128 * 8; idx += 256) {
+                    const int row = idx >> 3, pc = idx & 7;
+                    const int lc = pc ^ ((row >> 1) & 7);
+                    if (k0 + lc * 8 >= HW) {
+                        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                        *reinterpret_cast<bf16x8*>(as + row * 64 + pc * 8) = z;
+                    }
+                }
+                __syncthreads();
+            }
+            const int ra = wm * 64 + r, rb = wn * 64 + r;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 2 * ks + hh;
+                const bf16x8 a0 = glds_frag(as, ra, c), a1 = glds_frag(as, ra + 32, c);
+                const bf16x8 b0 = glds_frag(bs, rb, c), b1 = glds_frag(bs, rb + 32, c);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    float* slab = slabs + (int64_t)split * M * N;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = m0 + wm * 64 + mt * 32 + acr_krow(reg, hh);
+                const int col = n0 + wn * 64 + nt * 32 + r;
+                if (row < M && col < N) slab[(int64_t)row * N + col] = acc[mt][nt][reg];
+            }
+}
+
+// Slab reduction for small weights (few outputs, many splits): 16 float4 outputs x 16 split groups per block, each
+// group sums its splits in order, the 16 partials are combined in fixed order through LDS (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ slabs, int nsplit, int64_t nk,
+                                                                 bf16_t* __restrict__ out) {
+    __shared__ f32x4 part[16][17];
+    const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int64_t i = ((int64_t)blockIdx.x * 16 + o) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < nk)
+        for (int sp = g; sp < nsplit; sp += 16) s += *reinterpret_cast<const f32x4*>(slabs + (int64_t)sp * nk + i);
+    part[g][o] = s;
+    __syncthreads();
+    if (g == 0 && i < nk) {
+        f32x4 t = part[0][o];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += part[k][o];
+        acr_store4<bf16_t>(out + i, t);
+    }
+}
+
+static int c1_split(int M, int N, int HW, int nsamp) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int s = 512 / tiles;
+    const int total = nsamp * ((HW + 63) / 64);
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    if (s > total) s = total;
+    return s;
+}
+
+extern "C" int acr_conv1x1_bf16(const void* w, int64_t ldw, const void* x, void* y, int32_t nsamp, int32_t cout,
+                                int32_t cin, int32_t hw, void* stream) {
+    ACR_CHECK_ARG(w && x && y, "acr_conv1x1_bf16: null pointer");
+    ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin >= 64 && (cin % 64) == 0 && hw >= 8 && (hw % 8) == 0 && (ldw % 8) == 0 && ldw >= cin,
+                  "acr_conv1x1_bf16: need cin %% 64 == 0, hw %% 8 == 0 (cout=%d cin=%d hw=%d)", cout, cin, hw);
+    ACR_CHECK_ARG(((uintptr_t)w & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "acr_conv1x1_bf16: 16-byte alignment");
+    const int64_t tiles = (int64_t)((cout + 127) / 128) * ((hw + 127) / 128) * nsamp;
+    ACR_CHECK_ARG(tiles < (1ll << 31), "acr_conv1x1_bf16: grid too large");
+    hipLaunchKernelGGL(conv1x1_nn_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, ldw,
+                       (const bf16_t*)x, (bf16_t*)y, cout, cin, hw, nsamp);
+    return acr_check_launch("acr_conv1x1_bf16");
+}
+
+extern "C" size_t acr_conv1x1_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t hw) {
+    return (size_t)c1_split(cout, cin, hw, nsamp) * (size_t)cout * (size_t)cin;
+}
+
+extern "C" int acr_conv1x1_wgrad_bf16(const void* dy, const void* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw,
+                                      float* ws, void* dw, void* stream) {
+    ACR_CHECK_ARG(dy && x && ws && dw, "acr_conv1x1_wgrad_bf16: null pointer");
+    ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && hw >= 8 && (hw % 8) == 0 && ((int64_t)cout * cin) % 4 == 0,
+                  "acr_conv1x1_wgrad_bf16: need hw %% 8 == 0 and cout*cin %% 4 == 0");
+    ACR_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0, "acr_conv1x1_wgrad_bf16: 16-byte alignment");
+    const int nsplit = c1_split(cout, cin, hw, nsamp);
+    const int total = nsamp * ((hw + 63) / 64);
+    const int sps = (total + nsplit - 1) / nsplit;
+    const int tiles = ((cout + 127) / 128) * ((cin + 127) / 128);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(tiles * nsplit), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, ws,
+                       cout, cin, hw, nsamp, nsplit, sps);
+    const int64_t nk = (int64_t)cout * cin;
+    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)((nk / 4 + 15) / 16)), dim3(256), 0, st, (const float*)ws,
+                       nsplit, nk, (bf16_t*)dw);
+    return acr_check_launch("acr_conv1x1_wgrad_bf16");
+}

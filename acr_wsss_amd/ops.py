@@ -259,6 +259,55 @@ def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hi
     return y if resid is None else resid + y
 
 
+def conv1x1_fusable(x, weight, stride):
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    N, C, H, W = x.shape
+    co, ci = weight.shape[0], weight.shape[1]
+    return (stride == 1 and weight.shape[2] == 1 and weight.shape[3] == 1 and ci % 64 == 0 and co % 64 == 0
+            and (H * W) % 8 == 0)
+
+
+class Conv1x1Fn(Function):
+    """Stride-1 1x1 convolution in NCHW on the hand-written GEMM kernels (forward, input and weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        N, C, H, W = x.shape
+        co = weight.shape[0]
+        w2 = weight.reshape(co, C)
+        y = torch.empty((N, co, H, W), dtype=x.dtype, device=x.device)
+        L.check(L.load().acr_conv1x1_bf16(L.ptr(w2), w2.stride(0), L.ptr(x), L.ptr(y), N, co, C, H * W, L.stream_ptr()),
+                "acr_conv1x1_bf16")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, C, H, W = x.shape
+        co = weight.shape[0]
+        lib = L.load()
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.reshape(co, C).t().contiguous()                       # (cin, cout): dX = W^T . dY
+            dx = torch.empty_like(x)
+            L.check(lib.acr_conv1x1_bf16(L.ptr(wt), wt.stride(0), L.ptr(dy), L.ptr(dx), N, C, co, H * W, L.stream_ptr()),
+                    "acr_conv1x1_bf16")
+        if ctx.needs_input_grad[1]:
+            ws = torch.empty(lib.acr_conv1x1_wgrad_ws_floats(N, co, C, H * W), dtype=torch.float32, device=x.device)
+            dw = torch.empty((co, C, 1, 1), dtype=weight.dtype, device=x.device)
+            L.check(lib.acr_conv1x1_wgrad_bf16(L.ptr(dy), L.ptr(x), N, co, C, H * W, L.ptr(ws), L.ptr(dw), L.stream_ptr()),
+                    "acr_conv1x1_wgrad_bf16")
+        return dx, dw
+
+
+def conv1x1(x, weight):
+    return Conv1x1Fn.apply(x, weight)
+
+
 class LayerNormFn(Function):
     """LayerNorm over the last dim of a bf16 (.., C) tensor on acr_layernorm_{fwd,bwd}_bf16."""
 

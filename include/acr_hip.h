@@ -106,6 +106,16 @@ int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int3
 size_t acr_colsum_ws_floats(int32_t M, int32_t N);
 int acr_colsum_bf16(const void* dy, int64_t ld, int32_t M, int32_t N, float* ws, void* out, void* stream);
 
+/* ---- 1x1 convolutions of the ResNetV2 stem, NCHW bf16, stride 1 (models/resnetv2.py:186-190 conv1/conv3/downsample) ----
+ * y[n][co][p] = sum_ci w[co][ci] x[n][ci][p] as one MFMA GEMM per sample without any layout change; the same entry
+ * point gives the input gradient with w = W^T (cin/cout swapped).  cin %% 64 == 0, hw = H*W %% 8 == 0.
+ * acr_conv1x1_wgrad_bf16: dw[co][ci] = sum_n sum_p dy[n][co][p] x[n][ci][p] (fp32 slabs in ws, fixed-order reduction). */
+int acr_conv1x1_bf16(const void* w, int64_t ldw, const void* x, void* y, int32_t nsamp, int32_t cout, int32_t cin,
+                     int32_t hw, void* stream);
+size_t acr_conv1x1_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t hw);
+int acr_conv1x1_wgrad_bf16(const void* dy, const void* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw,
+                           float* ws, void* dw, void* stream);
+
 /* ---- LayerNorm of the transformer blocks (models/vision_transformer.py:219-222,299), bf16 (M, C) rows ----
  * C a multiple of 256, <= 1024.  stats: (M*2) fp32 [mean, rstd].  Backward writes dx, dgamma, dbeta in one pass over
  * x and dy; ws: fp32 scratch of acr_layernorm_ws_floats(M, C) floats (per-wave partials, summed in wave order). */

@@ -330,3 +330,26 @@ def test_layernorm_bf16(M, C):
     assert (x.grad.double() - xd.grad).abs().max() <= 2e-2 * xd.grad.abs().max()
     assert (ln.weight.grad.double() - wd.grad).abs().max() <= 1e-2 * wd.grad.abs().max() + 1e-2
     assert (ln.bias.grad.double() - bd.grad).abs().max() <= 1e-2 * bd.grad.abs().max() + 1e-2
+
+
+@pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 64, 8, 8), (3, 64, 256, 16, 24), (2, 256, 64, 28, 28),
+                                             (2, 1024, 256, 28, 28), (2, 128, 512, 56, 56), (1, 64, 256, 112, 112)])
+def test_conv1x1_bf16(N, cin, cout, H, W):
+    """NCHW 1x1 convolution on the GEMM kernels: forward, input gradient, weight gradient vs fp64 conv2d; covers pixel
+    tiles that run past H*W (28x28 = 784 = 6.125 tiles) and the ragged 64-pixel chunk of the weight gradient."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g).to(dev).bfloat16().requires_grad_(True)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * cin ** -0.5).to(dev).bfloat16().requires_grad_(True)
+    assert ops.conv1x1_fusable(x, w, 1)
+    y = ops.conv1x1(x, w)
+    dy = torch.randn(N, cout, H, W, generator=g).to(dev).bfloat16()
+    (y.float() * dy.float()).sum().backward()
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    ref = F.conv2d(xd, wd)
+    (ref * dy.double()).sum().backward()
+    assert (y.double() - ref).abs().max() <= 1e-2 * ref.abs().max()
+    assert (x.grad.double() - xd.grad).abs().max() <= 1.5e-2 * xd.grad.abs().max()
+    assert (w.grad.double() - wd.grad).abs().max() <= 1e-2 * wd.grad.abs().max()
