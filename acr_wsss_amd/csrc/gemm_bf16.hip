@@ -397,7 +397,7 @@ extern "C" int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_
 // The stock reduction runs this tall-matrix column sum at ~1.3 TB/s (30 us for 25120 x 768); here each workgroup
 // streams a 256-row slab with 16-byte loads (8 columns per lane) and the slab partials are summed in slab order.
 // ---------------------------------------------------------------------------------------------------------------
-#define CS_ROWS 256
+#define CS_ROWS 128
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ dy, int64_t ld, int M, int N,
                                                              float* __restrict__ part) {
     const int nvec = N >> 3;                                // 8-column vectors per row
@@ -423,11 +423,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nslab, int N,
                                                            bf16_t* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    // 16 columns x 16 slab groups per block; groups sum their slabs in order, then a fixed-order combine through LDS
+    __shared__ float sh[16][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + c;
     float s = 0.f;
-    for (int i = 0; i < nslab; ++i) s += part[(int64_t)i * N + n];
-    out[n] = (bf16_t)s;
+    if (n < N)
+        for (int i = g; i < nslab; i += 16) s += part[(int64_t)i * N + n];
+    sh[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float t = sh[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += sh[k][c];
+        out[n] = (bf16_t)t;
+    }
 }
 
 extern "C" size_t acr_colsum_ws_floats(int32_t M, int32_t N) { return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * (size_t)N; }
@@ -439,7 +449,7 @@ extern "C" int acr_colsum_bf16(const void* dy, int64_t ld, int32_t M, int32_t N,
     const int nslab = (M + CS_ROWS - 1) / CS_ROWS;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N / 8 + 63) / 64, nslab), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dy, ld, M, N, ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
                        nslab, N, (bf16_t*)out);
     return acr_check_launch("acr_colsum_bf16");
 }

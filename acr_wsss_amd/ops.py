@@ -259,6 +259,37 @@ def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hi
     return y if resid is None else resid + y
 
 
+class MaxPoolSameFn(Function):
+    """3x3/2 max-pool with TF-SAME -inf padding (pad_top, pad_left given, ph/pw = total padding)."""
+
+    @staticmethod
+    def forward(ctx, x, pt, pl, ph, pw):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        Ho, Wo = (H + ph - 3) // 2 + 1, (W + pw - 3) // 2 + 1
+        y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device)
+        amax = torch.empty((N, C, Ho, Wo), dtype=torch.uint8, device=x.device)
+        L.check(L.load().acr_maxpool3x3s2_fwd_bf16(L.ptr(x), L.ptr(y), L.ptr(amax), N * C, H, W, Ho, Wo, pt, pl, L.stream_ptr()),
+                "acr_maxpool3x3s2_fwd_bf16")
+        ctx.save_for_backward(amax)
+        ctx.geom = (N, C, H, W, Ho, Wo, pt, pl)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (amax,) = ctx.saved_tensors
+        N, C, H, W, Ho, Wo, pt, pl = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device)
+        L.check(L.load().acr_maxpool3x3s2_bwd_bf16(L.ptr(dy), L.ptr(amax), L.ptr(dx), N * C, H, W, Ho, Wo, pt, pl, L.stream_ptr()),
+                "acr_maxpool3x3s2_bwd_bf16")
+        return dx, None, None, None, None
+
+
+def maxpool3x3s2_same(x, pt, pl, ph, pw):
+    return MaxPoolSameFn.apply(x, pt, pl, ph, pw)
+
+
 def conv1x1_fusable(x, weight, stride):
     if not (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()):
         return False

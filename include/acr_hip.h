@@ -116,6 +116,14 @@ size_t acr_conv1x1_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int
 int acr_conv1x1_wgrad_bf16(const void* dy, const void* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw,
                            float* ws, void* dw, void* stream);
 
+/* ---- 3x3 stride-2 max-pool of the stem with TF-SAME -inf padding folded in (models/resnetv2.py:322-328) ----
+ * x (nc, h, w) -> y (nc, ho, wo); amax = 1-byte window argmax (i*3+j, first maximum like ATen) kept for the backward,
+ * which gathers (no atomics).  Window (ho, wo) starts at (2 ho - pad_top, 2 wo - pad_left). */
+int acr_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* amax, int64_t nc, int32_t h, int32_t w, int32_t ho,
+                              int32_t wo, int32_t pad_top, int32_t pad_left, void* stream);
+int acr_maxpool3x3s2_bwd_bf16(const void* dy, const uint8_t* amax, void* dx, int64_t nc, int32_t h, int32_t w,
+                              int32_t ho, int32_t wo, int32_t pad_top, int32_t pad_left, void* stream);
+
 /* ---- LayerNorm of the transformer blocks (models/vision_transformer.py:219-222,299), bf16 (M, C) rows ----
  * C a multiple of 256, <= 1024.  stats: (M*2) fp32 [mean, rstd].  Backward writes dx, dgamma, dbeta in one pass over
  * x and dy; ws: fp32 scratch of acr_layernorm_ws_floats(M, C) floats (per-wave partials, summed in wave order). */

@@ -353,3 +353,26 @@ def test_conv1x1_bf16(N, cin, cout, H, W):
     assert (y.double() - ref).abs().max() <= 1e-2 * ref.abs().max()
     assert (x.grad.double() - xd.grad).abs().max() <= 1.5e-2 * xd.grad.abs().max()
     assert (w.grad.double() - wd.grad).abs().max() <= 1e-2 * wd.grad.abs().max()
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (2, 5, 9, 11), (1, 64, 224, 224), (2, 4, 7, 16)])
+def test_maxpool_same_bf16(shape):
+    """SAME-padded 3x3/2 max-pool (forward value, argmax routing of the gradient) vs F.pad(-inf)+max_pool2d; values are made
+    distinct so the argmax is unique and the comparison is exact."""
+    from acr_wsss_amd import ops
+    from acr_wsss_amd.backbone import _same_pad, pad_same
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    n = math.prod(shape)
+    x = (torch.randperm(n, generator=g).float().reshape(shape) % 251 - 125.0) / 4.0      # bf16-exact, few ties
+    x = x.to(dev).bfloat16().requires_grad_(True)
+    ph, pw = _same_pad(shape[2], 3, 2), _same_pad(shape[3], 3, 2)
+    y = ops.maxpool3x3s2_same(x, ph // 2, pw // 2, ph, pw)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = F.max_pool2d(pad_same(xr, 3, 2, value=-float("inf")), 3, 2)
+    assert y.shape == yr.shape and torch.equal(y, yr)
+    dy = torch.randn(y.shape, generator=g).to(dev).bfloat16()
+    y.backward(dy)
+    yr.backward(dy)
+    assert torch.allclose(x.grad.float(), xr.grad.float(), atol=2e-2, rtol=2e-2)
