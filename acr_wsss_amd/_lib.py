@@ -51,7 +51,7 @@ SIGNATURES = {
                                  c_void_p]),
     "acr_colsum_ws_floats": (c_size_t, [c_int32, c_int32]),
     "acr_colsum_bf16": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
-    "acr_conv1x1_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "acr_conv1x1_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "acr_conv1x1_wgrad_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "acr_conv1x1_wgrad_bf16": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                          c_void_p]),
@@ -63,7 +63,7 @@ SIGNATURES = {
     "acr_layernorm_fwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float,
                                          c_void_p]),
     "acr_layernorm_bwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_int32, c_int32, c_void_p]),
+                                         c_void_p, c_int32, c_int32, c_void_p]),
     "acr_groupnorm_fwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                          c_int32, c_float, c_int32, c_void_p]),
     "acr_groupnorm_bwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -57,6 +57,14 @@ class StdConv2dSame(nn.Conv2d):
             return ops.conv1x1(x, w_hat)                    # NCHW 1x1 conv = per-sample MFMA GEMM, no layout transposes
         return F.conv2d(x, w_hat, None, self.stride, self.padding)
 
+    def forward_skip(self, x):
+        """(conv(x), x_skip): x_skip is what a parallel branch (the shortcut) should read -- on the HIP 1x1 path its
+        gradient is then added inside the input-gradient GEMM."""
+        w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
+        if self.hip_1x1 and x.requires_grad and ops.conv1x1_fusable(x, w_hat, self.stride[0]):
+            return ops.conv1x1_skip(x, w_hat)
+        return self.forward(x), x
+
     hip_1x1 = True
 
     _w_hat = None           # set for one forward by ResNetV2 when all weights are standardised in one fused launch
@@ -115,8 +123,9 @@ class Bottleneck(nn.Module):
         self.norm3 = GroupNormAct(cout, apply_act=False)
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else self.downsample(x)
-        x = self.norm1(self.conv1(x))
+        x, skip = self.conv1.forward_skip(x)
+        shortcut = skip if self.downsample is None else self.downsample(skip)
+        x = self.norm1(x)
         x = self.norm2(self.conv2(x))
         return self.norm3(self.conv3(x), shortcut)          # relu(gn(conv3) + shortcut), fused on the bf16 path
 
@@ -278,8 +287,10 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x, stack=None, layer=0):
-        x = self.attn(ops.layer_norm(x, self.norm1, self.hip_norm), stack, layer, resid=x)
-        return self.mlp(ops.layer_norm(x, self.norm2, self.hip_norm), resid=x)
+        h, skip = ops.layer_norm_skip(x, self.norm1, self.hip_norm)         # skip aliases x (gradient fused in LN bwd)
+        x = self.attn(h, stack, layer, resid=skip)
+        h, skip = ops.layer_norm_skip(x, self.norm2, self.hip_norm)
+        return self.mlp(h, resid=skip)
 
     hip_norm = True         # bf16 mode: LayerNorm on acr_layernorm_*_bf16
 

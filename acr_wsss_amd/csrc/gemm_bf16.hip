@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "acr_common.h"
+#include <type_traits>
 
 typedef __bf16 bf16_t;
 #define GBP 72
@@ -232,127 +233,181 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_dma_kernel(const bf16_t* __r
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// 256x128x64 variant, 8 waves (4 x 2, each 64x64), THREE LDS stages filled by LDS-DMA two K-steps ahead.
-// One K-step of MFMAs (~1k cycles for the two waves of a SIMD) does not cover a loaded HBM/L2 round trip, so the
-// 2-stage kernel above waits on every step; here the wait before the barrier is a COUNTED s_waitcnt vmcnt(6) that
-// leaves the newest stage's 6 DMA instructions in flight, and the barrier is a raw s_barrier (a __syncthreads()
-// would drain vmcnt(0)).  48 KiB per stage -> 144 KiB, one workgroup (8 waves, 2 per SIMD) per CU.
+// 256x256x64 variant: 4 waves (2 x 2), each owning a 128x128 accumulator (16 MFMA tiles, 256 accumulator registers).
+// The 128x128 kernel above gives every wave a 64x64 tile: per 16-deep K slice it reads 4 fragments (4 KiB) from LDS
+// for 4 MFMAs, which with two workgroups per CU is 125 B/clk -- the LDS port's whole 128 B/clk, so MFMA utilisation
+// is capped near 50 %.  A 128x128 wave tile reads 8 fragments for 16 MFMAs (half the LDS bytes per flop, ~62 B/clk
+// at full MFMA rate).  Two 64-deep stages of 64 KiB (128-byte rows = whole cache lines per DMA row, same chunk
+// swizzle as above); the outputs of the fragment-read asm are early-clobber: the reads land asynchronously, so an
+// output tuple must never share a register with the address operand of a later read in the same statement.
 // ---------------------------------------------------------------------------------------------------------------
-#define G3_BM 256
-#define G3_STAGE (G3_BM * 64 + 128 * 64)          // elements per stage: A tile then B tile
-
-__device__ __forceinline__ void glds_stage_rows(bf16_t* ldsbuf, const bf16_t* g, int64_t ld, int row0, int nrows, int k0,
-                                                int wave, int lane, int ninstr) {
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    typedef const __attribute__((address_space(1))) void* glb_vp;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i < ninstr) {
-            const int rbase = (wave * ninstr + i) * 8;
-            const int row = rbase + (lane >> 3);
-            const int lc = (lane & 7) ^ ((row >> 1) & 7);
-            const bf16_t* src = g + (int64_t)min(row0 + row, nrows - 1) * ld + k0 + lc * 8;
-            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(ldsbuf + rbase * 64), 16, 0, 0);
-        }
-    }
-}
+#define GB_BM 256
+#define GB_BN 256
+#define GB_BK 64
+#define GB_STAGE ((GB_BM + GB_BN) * GB_BK)        // elements per stage: A tile (256 x 64) then B tile (256 x 64) = 64 KiB
 
 template <bool BIAS, bool RESID>
-__global__ __launch_bounds__(512) void gemm_nt_bf16_dma3_kernel(const bf16_t* __restrict__ A, int64_t lda,
-                                                                const bf16_t* __restrict__ B, int64_t ldb,
-                                                                const bf16_t* __restrict__ bias,
-                                                                const bf16_t* __restrict__ R, int64_t ldr,
-                                                                bf16_t* __restrict__ Y, int64_t ldy, int M, int N, int K) {
-    __shared__ __attribute__((aligned(1024))) bf16_t smem[3 * G3_STAGE];
-    const int ntn = (N + 127) >> 7;
+__global__ __launch_bounds__(256) void gemm_nt_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                               const bf16_t* __restrict__ B, int64_t ldb,
+                                                               const bf16_t* __restrict__ bias,
+                                                               const bf16_t* __restrict__ R, int64_t ldr,
+                                                               bf16_t* __restrict__ Y, int64_t ldy, int M, int N, int K) {
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[2 * GB_STAGE];
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    const int ntn = (N + GB_BN - 1) / GB_BN;
     const int id = acr_xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id / ntn, tn = id % ntn;
-    const int m0 = tm * G3_BM, n0 = tn * 128;
+    const int m0 = tm * GB_BM, n0 = tn * GB_BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
-    const int nk = K >> 6;
-    // prologue: tiles 0 and 1 in flight, wait for tile 0 only
-    glds_stage_rows(smem, A, lda, m0, M, 0, wave, lane, 4);
-    glds_stage_rows(smem + G3_BM * 64, B, ldb, n0, N, 0, wave, lane, 2);
-    if (nk > 1) {
-        glds_stage_rows(smem + G3_STAGE, A, lda, m0, M, 64, wave, lane, 4);
-        glds_stage_rows(smem + G3_STAGE + G3_BM * 64, B, ldb, n0, N, 64, wave, lane, 2);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    int st = 0, st2 = 2;                                    // stage of tile kt, stage of tile kt+2
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 2 < nk) {
-            glds_stage_rows(smem + st2 * G3_STAGE, A, lda, m0, M, (kt + 2) * 64, wave, lane, 4);
-            glds_stage_rows(smem + st2 * G3_STAGE + G3_BM * 64, B, ldb, n0, N, (kt + 2) * 64, wave, lane, 2);
-        }
-        const bf16_t* as = smem + st * G3_STAGE;
-        const bf16_t* bs = as + G3_BM * 64;
-        const int ra = wm * 64 + r, rb = wn * 64 + r;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int c = 2 * ks + hh;
-            const bf16x8 a0 = glds_frag(as, ra, c), a1 = glds_frag(as, ra + 32, c);
-            const bf16x8 b0 = glds_frag(bs, rb, c), b1 = glds_frag(bs, rb + 32, c);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        // tile kt+1 must have landed (its 6 DMA instructions are older than tile kt+2's 6); every wave has consumed
-        // stage `st` (its fragment reads were waited for by the MFMAs) before anyone refills it next step
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        st = (st == 2) ? 0 : st + 1;
-        st2 = (st2 == 2) ? 0 : st2 + 1;
-    }
-    float* stile = reinterpret_cast<float*>(smem) + wave * 4096;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                stile[(mt * 32 + acr_krow(reg, hh)) * 64 + nt * 32 + r] = acc[mt][nt][reg];
+    const int nk = K / GB_BK;
+    // DMA sources: instruction i of this wave fills rows (wave*8 + i)*8 .. +7 of the A tile (and of the B tile);
+    // rows are 128 bytes (one cache line), chunk c of row r sits at physical chunk c ^ ((r >> 1) & 7)
+    uint32_t aoff[8], boff[8];                              // per-lane byte offsets; the K advance goes into the uniform base
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int idx = lane + 64 * i;
-        const int lrow = idx >> 3, c8 = (idx & 7) * 8;
-        const int row = m0 + wm * 64 + lrow, col = n0 + wn * 64 + c8;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8 + 4);
-        if (row < M && col < N) {
-            float y[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if (BIAS) {
-                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bias + col);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] += (float)bv[e];
-            }
-            if (RESID) {
-                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * ldr + col);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] += (float)rv[e];
-            }
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)y[e];
-            *reinterpret_cast<bf16x8*>(Y + (int64_t)row * ldy + col) = o;
-        }
+        const int row = (wave * 8 + i) * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        aoff[i] = (uint32_t)(((int64_t)min(m0 + row, M - 1) * lda + lc * 8) * 2);
+        boff[i] = (uint32_t)(((int64_t)min(n0 + row, N - 1) * ldb + lc * 8) * 2);
     }
+    auto issue = [&](int kt, int stage) {
+        bf16_t* sa = smem + stage * GB_STAGE;
+        const char* ab = reinterpret_cast<const char*>(A + kt * GB_BK);
+        const char* bb = reinterpret_cast<const char*>(B + kt * GB_BK);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((glb_vp)(ab + aoff[i]), (lds_vp)(sa + (wave * 8 + i) * 8 * GB_BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((glb_vp)(bb + boff[i]), (lds_vp)(sa + GB_BM * GB_BK + (wave * 8 + i) * 8 * GB_BK), 16, 0, 0);
+    };
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    issue(0, 0);
+    // Software pipeline, one 16-deep K slice ahead, fragment reads and their waits in inline asm: the compiler's own
+    // s_waitcnt insertion drains lgkmcnt(0) where a counted wait ("all but the newest batch of 8 reads") is enough.
+    // The barrier that publishes stage kt+1 and frees stage kt sits before the LAST slice's MFMAs of stage kt, so the
+    // barrier, the DMA issue for stage kt+2 and the first fragment reads of stage kt+1 all hide behind 16 MFMAs.
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
+    const int ra = wm * 128 + r, rb = wn * 128 + r;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)smem;
+    const uint32_t swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
+    uint32_t oa[4], ob[4];                                  // byte address of this lane's fragment row for K slice ks
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        oa[ks] = lds0 + ra * 128 + (((2 * ks + hh) ^ swa) << 4);
+        ob[ks] = lds0 + GB_BM * GB_BK * 2 + rb * 128 + (((2 * ks + hh) ^ swb) << 4);
+    }
+#define GB_READ4(dst, addr)                                                                         \
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\t"                        \
+                 "ds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %4 offset:12288"               \
+                 : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(addr))
+#define GB_WAIT8(cnt, x, y)                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                       \
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]))
+#define GB_MFMA16(x, y)                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                 \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i_], y[j_], acc[i_][j_], 0, 0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (nk > 1) issue(1, 1);
+    asm volatile("" ::: "memory");
+    GB_READ4(a0, oa[0]);
+    GB_READ4(b0, ob[0]);
+    // MODE 0: steady state (publish stage kt+1, refill stage kt's buffer with stage kt+2); 1: second to last stage (publish
+    // only); 2: last stage.  The loop is peeled instead of branching inside one body so that each body is a single
+    // straight-line block: the scheduler can then spread the DMA issue over the MFMAs, and the accumulators never
+    // meet at a control-flow merge (a merge made the register allocator spill them).
+    auto stage_body = [&](int kt, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const uint32_t so = (uint32_t)(kt & 1) * (GB_STAGE * 2), so2 = (uint32_t)((kt + 1) & 1) * (GB_STAGE * 2);
+        GB_READ4(a1, oa[1] + so);
+        GB_READ4(b1, ob[1] + so);
+        GB_WAIT8(8, a0, b0);
+        GB_MFMA16(a0, b0);                                  // slice 0
+        GB_READ4(a0, oa[2] + so);
+        GB_READ4(b0, ob[2] + so);
+        GB_WAIT8(8, a1, b1);
+        GB_MFMA16(a1, b1);                                  // slice 1
+        GB_READ4(a1, oa[3] + so);
+        GB_READ4(b1, ob[3] + so);
+        GB_WAIT8(8, a0, b0);
+        GB_MFMA16(a0, b0);                                  // slice 2
+        GB_WAIT8(0, a1, b1);                                // last fragments of stage kt are in registers
+        if (MODE <= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of stage kt+1 has landed
+            asm volatile("s_barrier" ::: "memory");             // ... everyone's; and nobody reads stage kt any more
+            GB_READ4(a0, oa[0] + so2);
+            GB_READ4(b0, ob[0] + so2);
+        }
+        if (MODE == 0) issue(kt + 2, kt & 1);
+        GB_MFMA16(a1, b1);                                  // slice 3
+        if (MODE == 0) {
+            // spread the 16 DMA instructions of stage kt+2 one per MFMA: an in-order wave issues a DMA (m0 setup + load)
+            // inside the 24 free issue cycles of a 32-cycle MFMA instead of as a block during which the matrix pipe drains
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one VMEM read (the LDS-DMA)
+            }
+        }
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) stage_body(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < nk) { stage_body(kt, std::integral_constant<int, 1>{}); ++kt; }
+    stage_body(kt, std::integral_constant<int, 2>{});
+#undef GB_READ4
+#undef GB_WAIT8
+#undef GB_MFMA16
+    __syncthreads();                                        // all fragment reads done before LDS is reused below
+    // Epilogue through LDS, one 64x64 quadrant of the wave's 128x128 tile at a time (wave-private 16 KiB).
+    float* stile = reinterpret_cast<float*>(smem) + wave * 4096;
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        stile[(mt * 32 + acr_krow(reg, hh)) * 64 + nt * 32 + r] = acc[qm * 2 + mt][qn * 2 + nt][reg];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = lane + 64 * i;
+                const int lrow = idx >> 3, c8 = (idx & 7) * 8;
+                const int row = m0 + wm * 128 + qm * 64 + lrow, col = n0 + wn * 128 + qn * 64 + c8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8 + 4);
+                if (row < M && col < N) {
+                    float y[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (BIAS) {
+                        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bias + col);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[e] += (float)bv[e];
+                    }
+                    if (RESID) {
+                        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * ldr + col);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[e] += (float)rv[e];
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)y[e];
+                    *reinterpret_cast<bf16x8*>(Y + (int64_t)row * ldy + col) = o;
+                }
+            }
+        }
 }
 
 extern "C" int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const void* bias,
@@ -366,9 +421,9 @@ extern "C" int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_
     const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
     ACR_CHECK_ARG(tiles < (1ll << 31), "acr_linear_bf16: grid too large");
     const dim3 grid((unsigned)tiles);
-    const dim3 grid3((unsigned)(((M + G3_BM - 1) / G3_BM) * ((N + 127) / 128)));
+    const dim3 grid3((unsigned)(((M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN)));
     hipStream_t st = (hipStream_t)stream;
-    static const int env_variant = getenv("ACR_GEMM_VARIANT") ? atoi(getenv("ACR_GEMM_VARIANT")) : 2;   // 2: 128x128 2-stage (fastest measured), 3: 256x128 3-stage
+    static const int env_variant = getenv("ACR_GEMM_VARIANT") ? atoi(getenv("ACR_GEMM_VARIANT")) : 2;   // 2: 128x128x64 2-stage, 3: 256x256x32 4-stage
     // LDS-DMA kernel stores 8-column (16-byte) groups: needs N, ldy, ldr multiples of 8 and 16-byte aligned y/bias/resid
     const bool vec_ok = (N % 8) == 0 && (ldy % 8) == 0 && (ldr % 8) == 0 && ((uintptr_t)y & 15) == 0 &&
                         ((uintptr_t)bias & 15) == 0 && ((uintptr_t)resid & 15) == 0;
@@ -379,7 +434,7 @@ extern "C" int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_
         hipLaunchKernelGGL((gemm_nt_bf16_kernel<BI, RE>), grid, dim3(256), 0, st, (const bf16_t*)a, lda,               \
                            (const bf16_t*)b, ldb, (const bf16_t*)bias, (const bf16_t*)resid, ldr, (bf16_t*)y, ldy, M, N, K); \
     else if (env_variant == 3)                                                                                        \
-        hipLaunchKernelGGL((gemm_nt_bf16_dma3_kernel<BI, RE>), grid3, dim3(512), 0, st, (const bf16_t*)a, lda,         \
+        hipLaunchKernelGGL((gemm_nt_bf16_big_kernel<BI, RE>), grid3, dim3(256), 0, st, (const bf16_t*)a, lda,         \
                            (const bf16_t*)b, ldb, (const bf16_t*)bias, (const bf16_t*)resid, ldr, (bf16_t*)y, ldy, M, N, K); \
     else                                                                                                              \
         hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<BI, RE>), grid, dim3(256), 0, st, (const bf16_t*)a, lda,           \
@@ -644,8 +699,9 @@ __device__ __forceinline__ bf16x8 c1_frag_a(const bf16_t* ldsbuf, int row, int s
 }
 
 __global__ __launch_bounds__(256) void conv1x1_nn_kernel(const bf16_t* __restrict__ W, int64_t ldw,
-                                                         const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, int M,
-                                                         int K, int HW, int nsamp) {
+                                                         const bf16_t* __restrict__ X, bf16_t* __restrict__ Y,
+                                                         const bf16_t* __restrict__ addend, int M, int K, int HW,
+                                                         int nsamp) {
     __shared__ __attribute__((aligned(1024))) bf16_t smem[4 * GL_TILE];      // [A0 | B0 | A1 | B1]
     const int ntm = (M + 127) >> 7, ntp = (HW + 127) >> 7;
     int id = acr_xcd_remap(blockIdx.x, gridDim.x);
@@ -708,8 +764,14 @@ __global__ __launch_bounds__(256) void conv1x1_nn_kernel(const bf16_t* __restric
         const f32x4 lo = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8 + 4);
         if (row < M && col < HW) {
-            bf16x8 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
-                        (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+            f32x4 l2 = lo, h2 = hi;
+            if (addend) {                                   // gradient arriving over the skip connection, summed in fp32
+                const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addend + (int64_t)n * M * HW + (int64_t)row * HW + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { l2[e] += (float)ad[e]; h2[e] += (float)ad[4 + e]; }
+            }
+            bf16x8 o = {(bf16_t)l2[0], (bf16_t)l2[1], (bf16_t)l2[2], (bf16_t)l2[3],
+                        (bf16_t)h2[0], (bf16_t)h2[1], (bf16_t)h2[2], (bf16_t)h2[3]};
             *reinterpret_cast<bf16x8*>(ys + (int64_t)row * HW + col) = o;
         }
     }
@@ -838,16 +900,17 @@ static int c1_split(int M, int N, int HW, int nsamp) {
     return s;
 }
 
-extern "C" int acr_conv1x1_bf16(const void* w, int64_t ldw, const void* x, void* y, int32_t nsamp, int32_t cout,
-                                int32_t cin, int32_t hw, void* stream) {
+extern "C" int acr_conv1x1_bf16(const void* w, int64_t ldw, const void* x, const void* addend, void* y, int32_t nsamp,
+                                int32_t cout, int32_t cin, int32_t hw, void* stream) {
     ACR_CHECK_ARG(w && x && y, "acr_conv1x1_bf16: null pointer");
     ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin >= 64 && (cin % 64) == 0 && hw >= 8 && (hw % 8) == 0 && (ldw % 8) == 0 && ldw >= cin,
                   "acr_conv1x1_bf16: need cin %% 64 == 0, hw %% 8 == 0 (cout=%d cin=%d hw=%d)", cout, cin, hw);
-    ACR_CHECK_ARG(((uintptr_t)w & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "acr_conv1x1_bf16: 16-byte alignment");
+    ACR_CHECK_ARG(((uintptr_t)w & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)addend & 15) == 0,
+                  "acr_conv1x1_bf16: 16-byte alignment");
     const int64_t tiles = (int64_t)((cout + 127) / 128) * ((hw + 127) / 128) * nsamp;
     ACR_CHECK_ARG(tiles < (1ll << 31), "acr_conv1x1_bf16: grid too large");
     hipLaunchKernelGGL(conv1x1_nn_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, ldw,
-                       (const bf16_t*)x, (bf16_t*)y, cout, cin, hw, nsamp);
+                       (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)addend, cout, cin, hw, nsamp);
     return acr_check_launch("acr_conv1x1_bf16");
 }
 

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                      const bf16_t* __restrict__ gamma, const float* __restrict__ stats,
-                                                     bf16_t* __restrict__ dx, float* __restrict__ part, int M, int C) {
+                                                     const bf16_t* __restrict__ dskip, bf16_t* __restrict__ dx,
+                                                     float* __restrict__ part, int M, int C) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * LN_WAVES + (threadIdx.x >> 6), nw = gridDim.x * LN_WAVES;
     const float inv_c = 1.f / (float)C;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rstd * (g[i][e] - c1 - xh[i][e] * c2);
+            if (dskip) o += acr_load4<bf16_t>(dskip + (int64_t)row * C + (i * 64 + lane) * 4);   // skip-path gradient
             acr_store4<bf16_t>(dx + (int64_t)row * C + (i * 64 + lane) * 4, o);
         }
     }
@@ -169,14 +171,16 @@ extern "C" int acr_layernorm_fwd_bf16(const void* x, const void* gamma, const vo
     return acr_check_launch("acr_layernorm_fwd_bf16");
 }
 
-extern "C" int acr_layernorm_bwd_bf16(const void* dy, const void* x, const void* gamma, const float* stats, void* dx,
-                                      float* ws, void* dgamma, void* dbeta, int32_t M, int32_t C, void* stream) {
+extern "C" int acr_layernorm_bwd_bf16(const void* dy, const void* x, const void* gamma, const float* stats,
+                                      const void* dskip, void* dx, float* ws, void* dgamma, void* dbeta, int32_t M,
+                                      int32_t C, void* stream) {
     ACR_CHECK_ARG(dy && x && gamma && stats && dx && ws && dgamma && dbeta, "acr_layernorm_bwd_bf16: null pointer");
     int rc = ln_check("acr_layernorm_bwd_bf16", M, C);
     if (rc) return rc;
     const dim3 grid(ln_grid(M));
     hipStream_t st = (hipStream_t)stream;
-    LN_DISPATCH(ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gamma, stats, (bf16_t*)dx, ws, M, C)
+    LN_DISPATCH(ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gamma, stats, (const bf16_t*)dskip,
+                (bf16_t*)dx, ws, M, C)
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(2 * C / 32), dim3(256), 0, st, (const float*)ws, ln_grid(M), C,
                        (bf16_t*)dgamma, (bf16_t*)dbeta);
     return acr_check_launch("acr_layernorm_bwd_bf16");

@@ -3,6 +3,7 @@
 These are the only places where the Python host surface meets the HIP library.  Tensors are torch
 allocations (device memory + stream plumbing); all arithmetic of the hot path happens in the kernels.
 """
+import os
 import torch
 from torch.autograd import Function
 
@@ -300,7 +301,10 @@ def conv1x1_fusable(x, weight, stride):
 
 
 class Conv1x1Fn(Function):
-    """Stride-1 1x1 convolution in NCHW on the hand-written GEMM kernels (forward, input and weight gradient)."""
+    """Stride-1 1x1 convolution in NCHW on the hand-written GEMM kernels (forward, input and weight gradient).
+
+    Returns (y, x_skip) with x_skip aliasing x: the bottleneck's shortcut consumes x_skip, so the gradient arriving over
+    the shortcut is added in the epilogue of the input-gradient GEMM (no separate accumulation pass)."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -308,25 +312,30 @@ class Conv1x1Fn(Function):
         co = weight.shape[0]
         w2 = weight.reshape(co, C)
         y = torch.empty((N, co, H, W), dtype=x.dtype, device=x.device)
-        L.check(L.load().acr_conv1x1_bf16(L.ptr(w2), w2.stride(0), L.ptr(x), L.ptr(y), N, co, C, H * W, L.stream_ptr()),
+        L.check(L.load().acr_conv1x1_bf16(L.ptr(w2), w2.stride(0), L.ptr(x), None, L.ptr(y), N, co, C, H * W, L.stream_ptr()),
                 "acr_conv1x1_bf16")
         ctx.save_for_backward(x, weight)
-        return y
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip):
         x, weight = ctx.saved_tensors
         N, C, H, W = x.shape
         co = weight.shape[0]
         lib = L.load()
+        if dy is None:
+            return dskip, None
         if not dy.is_contiguous():
             dy = dy.contiguous()
+        if dskip is not None and (not dskip.is_contiguous() or dskip.dtype != x.dtype):
+            dskip = dskip.to(x.dtype).contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
             wt = weight.reshape(co, C).t().contiguous()                       # (cin, cout): dX = W^T . dY
             dx = torch.empty_like(x)
-            L.check(lib.acr_conv1x1_bf16(L.ptr(wt), wt.stride(0), L.ptr(dy), L.ptr(dx), N, C, co, H * W, L.stream_ptr()),
-                    "acr_conv1x1_bf16")
+            L.check(lib.acr_conv1x1_bf16(L.ptr(wt), wt.stride(0), L.ptr(dy), L.ptr(dskip), L.ptr(dx), N, C, co, H * W,
+                                         L.stream_ptr()), "acr_conv1x1_bf16")
         if ctx.needs_input_grad[1]:
             ws = torch.empty(lib.acr_conv1x1_wgrad_ws_floats(N, co, C, H * W), dtype=torch.float32, device=x.device)
             dw = torch.empty((co, C, 1, 1), dtype=weight.dtype, device=x.device)
@@ -336,11 +345,22 @@ class Conv1x1Fn(Function):
 
 
 def conv1x1(x, weight):
+    return Conv1x1Fn.apply(x, weight)[0]
+
+
+def conv1x1_skip(x, weight):
+    """(conv(x), x_skip): see Conv1x1Fn."""
+    if not SKIP_FUSION:
+        return Conv1x1Fn.apply(x, weight)[0], x
     return Conv1x1Fn.apply(x, weight)
 
 
 class LayerNormFn(Function):
-    """LayerNorm over the last dim of a bf16 (.., C) tensor on acr_layernorm_{fwd,bwd}_bf16."""
+    """LayerNorm over the last dim of a bf16 (.., C) tensor on acr_layernorm_{fwd,bwd}_bf16.
+
+    Returns (LN(x), x_skip): x_skip aliases x and is what the residual connection should consume, so that the gradient
+    arriving over the skip path reaches this node's backward and is added inside the LayerNorm backward kernel instead of
+    by a separate autograd accumulation pass (blocks: x + f(LN(x)), models/vision_transformer.py:224-226)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
@@ -353,32 +373,56 @@ class LayerNormFn(Function):
         L.check(lib.acr_layernorm_fwd_bf16(L.ptr(x2), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), M, C, eps,
                                            L.stream_ptr()), "acr_layernorm_fwd_bf16")
         ctx.save_for_backward(x2, weight, stats)
-        return y.reshape(x.shape)
+        ctx.set_materialize_grads(False)
+        return y.reshape(x.shape), x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip):
         x2, weight, stats = ctx.saved_tensors
         M, C = x2.shape
+        if dy is None:
+            return dskip, None, None, None
         lib = L.load()
         dy2 = dy.reshape(M, C)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        ds2 = None
+        if dskip is not None:
+            ds2 = dskip.reshape(M, C)
+            if not ds2.is_contiguous() or ds2.dtype != x2.dtype:
+                ds2 = ds2.to(x2.dtype).contiguous()
         dx = torch.empty_like(x2)
         ws = torch.empty(lib.acr_layernorm_ws_floats(M, C), dtype=torch.float32, device=x2.device)
         dg = torch.empty(C, dtype=torch.bfloat16, device=x2.device)
         db = torch.empty(C, dtype=torch.bfloat16, device=x2.device)
-        L.check(lib.acr_layernorm_bwd_bf16(L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats), L.ptr(dx), L.ptr(ws),
-                                           L.ptr(dg), L.ptr(db), M, C, L.stream_ptr()), "acr_layernorm_bwd_bf16")
+        L.check(lib.acr_layernorm_bwd_bf16(L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats), L.ptr(ds2), L.ptr(dx),
+                                           L.ptr(ws), L.ptr(dg), L.ptr(db), M, C, L.stream_ptr()), "acr_layernorm_bwd_bf16")
         return dx.reshape(dy.shape), dg, db, None
+
+
+def layer_norm_fusable(x, ln):
+    C = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.bfloat16 and ln.weight.dtype == torch.bfloat16 and x.is_contiguous()
+            and C % 256 == 0 and C <= 1024)
 
 
 def layer_norm(x, ln, use_hip=True):
     """nn.LayerNorm forward; contiguous bf16 CUDA rows with C % 256 == 0 (<= 1024) take the HIP kernels."""
-    C = x.shape[-1]
-    if (use_hip and x.is_cuda and x.dtype == torch.bfloat16 and ln.weight.dtype == torch.bfloat16 and x.is_contiguous()
-            and C % 256 == 0 and C <= 1024):
+    if use_hip and layer_norm_fusable(x, ln):
+        return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)[0]
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
+
+
+SKIP_FUSION = os.environ.get("ACR_SKIP_FUSION", "1") != "0"      # A/B switch for the fused skip-gradient adds
+
+
+def layer_norm_skip(x, ln, use_hip=True):
+    """(LN(x), x_skip) -- see LayerNormFn; on the stock path x_skip is x itself."""
+    if use_hip and layer_norm_fusable(x, ln):
+        if not SKIP_FUSION:
+            return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)[0], x
         return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
-    return torch.nn.functional.layer_norm(x, (C,), ln.weight, ln.bias, ln.eps)
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps), x
 
 
 GN_ACT = {"none": 0, "relu": 1, "add_relu": 2}

@@ -109,9 +109,10 @@ int acr_colsum_bf16(const void* dy, int64_t ld, int32_t M, int32_t N, float* ws,
 /* ---- 1x1 convolutions of the ResNetV2 stem, NCHW bf16, stride 1 (models/resnetv2.py:186-190 conv1/conv3/downsample) ----
  * y[n][co][p] = sum_ci w[co][ci] x[n][ci][p] as one MFMA GEMM per sample without any layout change; the same entry
  * point gives the input gradient with w = W^T (cin/cout swapped).  cin %% 64 == 0, hw = H*W %% 8 == 0.
+ * addend (nullable, shaped like y): added to the result in fp32 -- the gradient arriving over the block's shortcut.
  * acr_conv1x1_wgrad_bf16: dw[co][ci] = sum_n sum_p dy[n][co][p] x[n][ci][p] (fp32 slabs in ws, fixed-order reduction). */
-int acr_conv1x1_bf16(const void* w, int64_t ldw, const void* x, void* y, int32_t nsamp, int32_t cout, int32_t cin,
-                     int32_t hw, void* stream);
+int acr_conv1x1_bf16(const void* w, int64_t ldw, const void* x, const void* addend, void* y, int32_t nsamp, int32_t cout,
+                     int32_t cin, int32_t hw, void* stream);
 size_t acr_conv1x1_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t hw);
 int acr_conv1x1_wgrad_bf16(const void* dy, const void* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw,
                            float* ws, void* dw, void* stream);
@@ -126,12 +127,14 @@ int acr_maxpool3x3s2_bwd_bf16(const void* dy, const uint8_t* amax, void* dx, int
 
 /* ---- LayerNorm of the transformer blocks (models/vision_transformer.py:219-222,299), bf16 (M, C) rows ----
  * C a multiple of 256, <= 1024.  stats: (M*2) fp32 [mean, rstd].  Backward writes dx, dgamma, dbeta in one pass over
- * x and dy; ws: fp32 scratch of acr_layernorm_ws_floats(M, C) floats (per-wave partials, summed in wave order). */
+ * x and dy; ws: fp32 scratch of acr_layernorm_ws_floats(M, C) floats (per-wave partials, summed in wave order).
+ * dskip (nullable, (M, C) bf16): gradient arriving over the residual connection x -> x + f(LN(x)); it is added to dx
+ * in fp32 before the single bf16 rounding, which replaces autograd's separate accumulation pass. */
 size_t acr_layernorm_ws_floats(int32_t M, int32_t C);
 int acr_layernorm_fwd_bf16(const void* x, const void* gamma, const void* beta, void* y, float* stats, int32_t M,
                            int32_t C, float eps, void* stream);
-int acr_layernorm_bwd_bf16(const void* dy, const void* x, const void* gamma, const float* stats, void* dx, float* ws,
-                           void* dgamma, void* dbeta, int32_t M, int32_t C, void* stream);
+int acr_layernorm_bwd_bf16(const void* dy, const void* x, const void* gamma, const float* stats, const void* dskip,
+                           void* dx, float* ws, void* dgamma, void* dbeta, int32_t M, int32_t C, void* stream);
 
 /* ---- ResNetV2 stem: fused GroupNorm(32) [+ residual] [+ ReLU], bf16 NCHW ----
  * models/layers/norm_act.py:69-85 (GroupNormAct), models/resnetv2.py:205-215 (norm3 -> act3(x + shortcut)).
