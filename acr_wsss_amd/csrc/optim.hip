@@ -1,0 +1,68 @@
+// Fused optimizer step of the bf16-weights / fp32-masters training mode: one launch over every parameter tensor.
+// Reference semantics: tool/torchutils.py:10-31 PolyOptimizer = torch SGD whose momentum slot holds wt_dec (5e-4),
+// weight decay 0, dampening 0, no Nesterov:   buf = mu * buf + g ;  w = w - lr * buf   (fp32), then the bf16 working
+// copy of w is refreshed.  The stock path is 5 multi-tensor launches (cast g, mul, add, add, cast w) moving 32 B per
+// parameter; this is one pass: 2 (g) + 4+4 (buf) + 4+4 (w) + 2 (bf16 w) = 20 B per parameter, HBM-bound.
+#include "acr_common.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+
+#define SGD_CHUNK 8192
+
+__global__ __launch_bounds__(256) void sgd_step_kernel(const acr_sgd_tensor* __restrict__ tab, const int32_t* __restrict__ blk_tensor,
+                                                       const int32_t* __restrict__ blk_chunk, float lr, float mu) {
+    const acr_sgd_tensor t = tab[blk_tensor[blockIdx.x]];
+    if (!t.grad) return;
+    const int64_t c0 = (int64_t)blk_chunk[blockIdx.x] * SGD_CHUNK;
+    const int64_t c1 = min(c0 + SGD_CHUNK, t.n);
+    const bf16_t* g = (const bf16_t*)t.grad;
+    bf16_t* p = (bf16_t*)t.param;
+    const bool vec = ((((uintptr_t)g | (uintptr_t)p) & 15) == 0) && ((((uintptr_t)t.master | (uintptr_t)t.mom) & 15) == 0);
+    if (vec) {
+        for (int64_t i = c0 + threadIdx.x * 8; i + 8 <= c1; i += 256 * 8) {
+            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + i);
+            f32x4 b0 = *reinterpret_cast<const f32x4*>(t.mom + i), b1 = *reinterpret_cast<const f32x4*>(t.mom + i + 4);
+            f32x4 w0 = *reinterpret_cast<const f32x4*>(t.master + i), w1 = *reinterpret_cast<const f32x4*>(t.master + i + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                b0[e] = mu * b0[e] + (float)gv[e];
+                b1[e] = mu * b1[e] + (float)gv[4 + e];
+                w0[e] = fmaf(-lr, b0[e], w0[e]);
+                w1[e] = fmaf(-lr, b1[e], w1[e]);
+                o[e] = (bf16_t)w0[e];
+                o[4 + e] = (bf16_t)w1[e];
+            }
+            *reinterpret_cast<f32x4*>(t.mom + i) = b0;
+            *reinterpret_cast<f32x4*>(t.mom + i + 4) = b1;
+            *reinterpret_cast<f32x4*>(t.master + i) = w0;
+            *reinterpret_cast<f32x4*>(t.master + i + 4) = w1;
+            *reinterpret_cast<bf16x8*>(p + i) = o;
+        }
+        const int64_t tail = c0 + ((c1 - c0) & ~(int64_t)7);
+        for (int64_t i = tail + threadIdx.x; i < c1; i += 256) {
+            const float b = mu * t.mom[i] + (float)g[i];
+            const float w = fmaf(-lr, b, t.master[i]);
+            t.mom[i] = b; t.master[i] = w; p[i] = (bf16_t)w;
+        }
+    } else {
+        for (int64_t i = c0 + threadIdx.x; i < c1; i += 256) {
+            const float b = mu * t.mom[i] + (float)g[i];
+            const float w = fmaf(-lr, b, t.master[i]);
+            t.mom[i] = b; t.master[i] = w; p[i] = (bf16_t)w;
+        }
+    }
+}
+
+extern "C" int32_t acr_sgd_chunk_elems(void) { return SGD_CHUNK; }
+
+extern "C" int acr_sgd_step_bf16(const void* table, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t nblocks,
+                                 float lr, float momentum, void* stream) {
+    ACR_CHECK_ARG(table && blk_tensor && blk_chunk && nblocks > 0, "acr_sgd_step_bf16: null pointer / empty launch");
+    hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const acr_sgd_tensor*)table,
+                       blk_tensor, blk_chunk, lr, momentum);
+    return acr_check_launch("acr_sgd_step_bf16");
+}

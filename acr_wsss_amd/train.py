@@ -87,6 +87,8 @@ class MasterWeights:
 
     @torch.no_grad()
     def step(self):
+        if self._fused_ok():
+            return self._fused_step()
         live = [(m, p) for m, p in zip(self.masters, self.model_params) if p.grad is not None]
         for m, _ in live:
             if m.grad is None:
@@ -98,6 +100,61 @@ class MasterWeights:
             torch._foreach_copy_([m.grad for m, _ in live], [p.grad for _, p in live])
         self.optimizer.step()
         torch._foreach_copy_([p for p in self.model_params], self.masters)
+
+    # ---- fused path: one HIP launch updates momentum, fp32 master and bf16 working copy of every parameter ----
+    fused = True
+
+    def _fused_ok(self):
+        if not (self.fused and isinstance(self.optimizer, PolyOptimizer) and self.masters and self.masters[0].is_cuda):
+            return False
+        g = self.optimizer.param_groups
+        return (len(g) == 1 and g[0].get("dampening", 0) == 0 and not g[0].get("nesterov", False)
+                and g[0].get("weight_decay", 0) == 0 and not g[0].get("maximize", False)
+                and all(p.grad is None or (p.grad.dtype == torch.bfloat16 and p.grad.is_contiguous()) for p in self.model_params))
+
+    def _fused_step(self):
+        import numpy as np
+        from . import _lib as L
+        lib = L.load()
+        opt = self.optimizer
+        dev = self.masters[0].device
+        if getattr(self, "_sgd_tab", None) is None:
+            chunk = lib.acr_sgd_chunk_elems()
+            bt, bc = [], []
+            for i, m in enumerate(self.masters):
+                nch = (m.numel() + chunk - 1) // chunk
+                bt.append(np.full(nch, i, dtype=np.int32))
+                bc.append(np.arange(nch, dtype=np.int32))
+            self._sgd_bt = torch.from_numpy(np.concatenate(bt)).to(dev)
+            self._sgd_bc = torch.from_numpy(np.concatenate(bc)).to(dev)
+            self._sgd_host = torch.zeros((len(self.masters), 5), dtype=torch.int64).pin_memory()
+            self._sgd_tab = torch.zeros((len(self.masters), 5), dtype=torch.int64, device=dev)
+            for i, (m, p) in enumerate(zip(self.masters, self.model_params)):
+                st = opt.state[m]
+                if "momentum_buffer" not in st or st["momentum_buffer"] is None:
+                    st["momentum_buffer"] = torch.zeros_like(m)        # mu*0 + g == torch's first-step clone(g)
+                self._sgd_host[i, 1] = m.data_ptr()
+                self._sgd_host[i, 2] = st["momentum_buffer"].data_ptr()
+                self._sgd_host[i, 4] = m.numel()
+        host = self._sgd_host
+        # the pinned table is re-filled every step: the previous step's copy must have been consumed
+        if getattr(self, "_sgd_evt", None) is not None:
+            self._sgd_evt.synchronize()
+        hn = host.numpy()
+        hn[:, 0] = [0 if p.grad is None else p.grad.data_ptr() for p in self.model_params]
+        hn[:, 3] = [p.data_ptr() for p in self.model_params]
+        self._sgd_tab.copy_(host, non_blocking=True)
+        self._sgd_evt = torch.cuda.Event()
+        self._sgd_evt.record()
+        # PolyOptimizer.step's schedule (tool/torchutils.py:23-27)
+        if opt.global_step < opt.max_step:
+            lr_mult = (1 - opt.global_step / opt.max_step) ** opt.momentum
+            for i in range(len(opt.param_groups)):
+                opt.param_groups[i]["lr"] = opt._initial_lr[i] * lr_mult * opt.lr_scale
+        grp = opt.param_groups[0]
+        L.check(lib.acr_sgd_step_bf16(L.ptr(self._sgd_tab), L.ptr(self._sgd_bt), L.ptr(self._sgd_bc), self._sgd_bt.numel(),
+                                      float(grp["lr"]), float(grp["momentum"]), L.stream_ptr()), "acr_sgd_step_bf16")
+        opt.global_step += 1
 
 
 def train_step(model, optimizer, img, label, alpha, grad_sync=None, amp_dtype=None):

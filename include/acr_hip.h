@@ -125,6 +125,21 @@ int acr_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* amax, int64_t nc,
 int acr_maxpool3x3s2_bwd_bf16(const void* dy, const uint8_t* amax, void* dx, int64_t nc, int32_t h, int32_t w,
                               int32_t ho, int32_t wo, int32_t pad_top, int32_t pad_left, void* stream);
 
+/* ---- Fused optimizer step, bf16 weights + fp32 masters (tool/torchutils.py:10-31 PolyOptimizer = SGD with
+ * momentum slot = wt_dec, weight decay 0):  mom = momentum*mom + g;  master -= lr*mom;  param = bf16(master).
+ * table: device array of acr_sgd_tensor; block b of the launch updates chunk blk_chunk[b] (acr_sgd_chunk_elems()
+ * elements) of tensor blk_tensor[b].  Entries with grad == NULL are skipped (parameter without gradient). */
+typedef struct acr_sgd_tensor {
+    const void* grad;   /* bf16 (n) or NULL */
+    float* master;      /* fp32 (n) */
+    float* mom;         /* fp32 (n) momentum buffer */
+    void* param;        /* bf16 (n) working copy */
+    int64_t n;
+} acr_sgd_tensor;
+int32_t acr_sgd_chunk_elems(void);
+int acr_sgd_step_bf16(const void* table, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t nblocks, float lr,
+                      float momentum, void* stream);
+
 /* ---- LayerNorm of the transformer blocks (models/vision_transformer.py:219-222,299), bf16 (M, C) rows ----
  * C a multiple of 256, <= 1024.  stats: (M*2) fp32 [mean, rstd].  Backward writes dx, dgamma, dbeta in one pass over
  * x and dy; ws: fp32 scratch of acr_layernorm_ws_floats(M, C) floats (per-wave partials, summed in wave order).
