@@ -40,11 +40,14 @@ class GradSync:
         for grp in groups:
             b = _Bucket()
             b.params = grp
-            b.flat = torch.zeros(sum(p.numel() for p in grp), dtype=grp[0].dtype, device=grp[0].device)
+            # every slot starts on a 64-element (>= 128-byte) boundary: gradient views stay 16-byte aligned for the
+            # vectorised consumers (fused optimizer step); the padding is zero and rides along in the all-reduce
+            pad = lambda n: (n + 63) // 64 * 64
+            b.flat = torch.zeros(sum(pad(p.numel()) for p in grp), dtype=grp[0].dtype, device=grp[0].device)
             b.views, off = [], 0
             for p in grp:
                 b.views.append(b.flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+                off += pad(p.numel())
                 self._of[p] = b
                 p.register_post_accumulate_grad_hook(self._hook)
             b.pending, b.work = 0, None
