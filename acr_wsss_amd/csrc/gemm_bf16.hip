@@ -629,10 +629,193 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     acr_store4<bf16_t>(out + i, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256x256 output tile variant of the weight-gradient GEMM: 4 waves (2 x 2), each a 128x128 accumulator.  The weight
+// gradient is the ideal case for the big tile: few output tiles, a 25 120-long contraction split over ~256 workgroups
+// (one per CU, ~45 steps each), so prologue/epilogue amortise and there is no tile quantisation.  Per 16-row slice a wave
+// reads 8 fragments for 16 MFMAs (the 128x128-tile kernel above: 4 for 4), which takes the LDS off the critical path.
+// LDS per stage: dY tile [2 halves][64 m][128 n] + X tile [2 halves][64 m][128 k] = 64 KiB, two stages; each half has
+// exactly the layout of the kernel above, so wg_stage / wg_frag are shared.
+// ---------------------------------------------------------------------------------------------------------------
+#define WB_ROWS 32                         // contraction rows per ring stage
+#define WB_HALF (WB_ROWS * 128)            // elements of one [32 m][128 cols] half tile
+#define WB_STAGE (4 * WB_HALF)             // [dY half0 | dY half1 | X half0 | X half1] = 32 KiB
+
+__device__ __forceinline__ void wb_stage_half(bf16_t* ldsbuf, const bf16_t* g, int64_t ld, int m0, int M, int col0,
+                                              int wave, int lane) {
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rbase = (wave * 2 + i) * 4;                // 4 rows (1 KiB) per DMA instruction, 8 instructions = 32 rows
+        const int row = rbase + (lane >> 4);
+        const int lc = (lane & 15) ^ ((row & 3) << 2);
+        const bf16_t* src = g + (int64_t)min(m0 + row, M - 1) * ld + col0 + lc * 8;
+        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(ldsbuf + rbase * 128), 16, 0, 0);
+    }
+}
+
+// Ring of FOUR 32-row stages (32 KiB each) filled three stages ahead, 8 DMA instructions per stage and thread, spread
+// one per 4 MFMAs.  Three findings shaped this kernel (fc1's dW, 25120 x 3072 x 768, same launch geometry):
+//  * the compiler puts s_waitcnt vmcnt(0) in front of ds_read_b64_tr_b16 *builtins* that follow an LDS-DMA in the same
+//    block (it cannot disambiguate the DMA's LDS write from the read), which serialises DMA and compute: MFMA+reads
+//    alone 116 us, DMA alone 61 us, together 181 us.  Fragment reads here are inline asm with counted lgkmcnt waits;
+//  * a stage's DMAs issued as one burst park the in-order wave in the memory pipe's issue queue, so they are spread
+//    over the step's MFMAs (1 KiB per 128 cycles per wave = the consumption rate);
+//  * split-major tile order: the ~32 consecutive ids on one XCD are the tiles of ONE token range (L2 reuse).
+// The barrier that publishes stage it+1 sits between the two 16-row slices of stage it, so the barrier and the first
+// fragment reads of the next stage hide behind 16 MFMAs.  vmcnt bookkeeping at that barrier: stage it+2 (8) and the
+// first half of stage it+3 (4) may stay in flight -> s_waitcnt vmcnt(12).
+__global__ __launch_bounds__(256) void gemm_tn_bf16_big_kernel(const bf16_t* __restrict__ dY, int64_t ldy,
+                                                               const bf16_t* __restrict__ X, int64_t ldx,
+                                                               float* __restrict__ slabs, int M, int N, int K, int nsplit,
+                                                               int steps_per_split) {
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[4 * WB_STAGE];
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    const int ntk = K >> 8, ntiles = (N >> 8) * ntk;
+    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id / ntiles; id -= split * ntiles;
+    const int tk = id % ntk, tn = id / ntk;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int total_steps = (M + WB_ROWS - 1) / WB_ROWS;
+    const int st0 = split * steps_per_split, st1 = min(st0 + steps_per_split, total_steps);
+    const int n = st1 - st0;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float* slab = slabs + (int64_t)split * N * K;
+    if (n > 0) {
+        // DMA sources: instruction q (0..7) of a stage: operand q>>2 (dY, X), 128-column half (q>>1)&1, row group q&1
+        uint32_t doff[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = (wave * 2 + (q & 1)) * 4 + (lane >> 4);
+            const int lc = (lane & 15) ^ ((row & 3) << 2);
+            const int col = ((q >> 2) ? tk : tn) * 256 + ((q >> 1) & 1) * 128 + lc * 8;
+            doff[q] = (uint32_t)(((int64_t)row * ((q >> 2) ? ldx : ldy) + col) * 2);
+        }
+        auto dma = [&](int it, int q) {                      // one DMA instruction of stage `it` (all rows < M: see host)
+            const int64_t m0 = (int64_t)(st0 + it) * WB_ROWS;
+            const char* base = (q >> 2) ? reinterpret_cast<const char*>(X + m0 * ldx) : reinterpret_cast<const char*>(dY + m0 * ldy);
+            bf16_t* dst = smem + (it & 3) * WB_STAGE + (q >> 1) * WB_HALF + (wave * 2 + (q & 1)) * 4 * 128;
+            __builtin_amdgcn_global_load_lds((glb_vp)(base + doff[q]), (lds_vp)dst, 16, 0, 0);
+        };
+        // fragment addresses (bytes): row 16 s + 4 h + (i >> 2) of the wave's half tile, 32-column block t at
+        // chunk (4 t ^ 4 x) with x = row & 3 -- see wg_frag; slice and +8-row offsets are immediates
+        const int li = lane & 15, x = (li >> 2) & 3;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)smem;
+        const uint32_t lowb = (uint32_t)((4 * hh + (li >> 2)) * 256 + ((2 * ((lane >> 4) & 1) + ((li & 3) >> 1)) << 4) + ((li & 1) << 3));
+        uint32_t fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            fa[t] = lds0 + wi * (WB_HALF * 2) + lowb + ((t ^ x) << 6);
+            fb[t] = lds0 + (2 + wj) * (WB_HALF * 2) + lowb + ((t ^ x) << 6);
+        }
+        bf16x4 x0l[8], x0h[8], x1l[8], x1h[8];              // [0..3] = dY fragments, [4..7] = X fragments
+#define WB_RD(lo, hi, addr, OFF)                                                                                     \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                         \
+                 : "=&v"(lo), "=&v"(hi) : "v"(addr), "i"(OFF), "i"((OFF) + 2048))
+#define WB_READ8(L, H, so, OFF)                                                                                      \
+    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                               \
+        WB_RD(L[t_], H[t_], fa[t_] + (so), OFF);                                                                     \
+        WB_RD(L[4 + t_], H[4 + t_], fb[t_] + (so), OFF);                                                             \
+    }
+#define WB_WAIT(cnt, L, H)                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                       \
+                 : "+v"(L[0]), "+v"(L[1]), "+v"(L[2]), "+v"(L[3]), "+v"(L[4]), "+v"(L[5]), "+v"(L[6]), "+v"(L[7]),   \
+                   "+v"(H[0]), "+v"(H[1]), "+v"(H[2]), "+v"(H[3]), "+v"(H[4]), "+v"(H[5]), "+v"(H[6]), "+v"(H[7]))
+#define WB_MFMA16(L, H)                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                 \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                       \
+            __builtin_shufflevector(L[i_], H[i_], 0, 1, 2, 3, 4, 5, 6, 7),                                           \
+            __builtin_shufflevector(L[4 + j_], H[4 + j_], 0, 1, 2, 3, 4, 5, 6, 7), acc[i_][j_], 0, 0, 0)
+#define WB_SPREAD4                                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                           \
+    }
+        // MODE 0: steady state (issues stage it+3); 1: a later stage exists but nothing left to issue; 2: last stage
+        auto body = [&](int it, auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            const uint32_t so = (uint32_t)(it & 3) * (WB_STAGE * 2), so2 = (uint32_t)((it + 1) & 3) * (WB_STAGE * 2);
+            WB_READ8(x1l, x1h, so, 4096);                   // slice 1 of stage it
+            WB_WAIT(15, x0l, x0h);                          // <= 15 outstanding: the 16 older reads (slice 0) are done
+            if (MODE == 0) {
+                dma(it + 3, 0); dma(it + 3, 1); dma(it + 3, 2); dma(it + 3, 3);
+            }
+            WB_MFMA16(x0l, x0h);
+            if (MODE == 0) { WB_SPREAD4 }
+            WB_WAIT(0, x1l, x1h);                           // this wave holds every fragment of stage it
+            if (MODE <= 1) {
+                if (MODE == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // stage it+1 landed (see header)
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                WB_READ8(x0l, x0h, so2, 0);                 // slice 0 of stage it+1
+            }
+            if (MODE == 0) {
+                dma(it + 3, 4); dma(it + 3, 5); dma(it + 3, 6); dma(it + 3, 7);
+            }
+            WB_MFMA16(x1l, x1h);
+            if (MODE == 0) { WB_SPREAD4 }
+        };
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dma(0, q);
+        if (n > 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dma(1, q);
+        }
+        if (n > 2) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dma(2, q);
+        }
+        if (n > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (n > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        WB_READ8(x0l, x0h, 0u, 0);
+        int it = 0;
+        for (; it + 3 < n; ++it) body(it, std::integral_constant<int, 0>{});
+        for (; it + 1 < n; ++it) body(it, std::integral_constant<int, 1>{});
+        body(it, std::integral_constant<int, 2>{});
+#undef WB_RD
+#undef WB_READ8
+#undef WB_WAIT
+#undef WB_MFMA16
+#undef WB_SPREAD4
+    }
+    // acc[i][j][reg] = dW[tn*256 + 128 wi + 32 i + krow(reg,hh)][tk*256 + 128 wj + 32 j + r]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int nn = tn * 256 + 128 * wi + 32 * i + acr_krow(reg, hh);
+                const int kk = tk * 256 + 128 * wj + 32 * j + r;
+                slab[(int64_t)nn * K + kk] = acc[i][j][reg];
+            }
+}
+
+static bool wgrad_big_ok(int M, int N, int K) {
+    static const int env = getenv("ACR_WGRAD_VARIANT") ? atoi(getenv("ACR_WGRAD_VARIANT")) : 2;      // 1: 128x128 tiles, 2: 256x256
+    // the 256x256 kernel has no ragged-row path: token counts that are not a multiple of its 32-row stage (and small
+    // problems that would not fill the chip) stay on the 128x128 kernel
+    return env == 2 && (N % 256) == 0 && (K % 256) == 0 && (M % WB_ROWS) == 0 && M >= 4096;
+}
+
 static int wgrad_split(int M, int N, int K) {
-    const int tiles = (N / 128) * (K / 128);
-    int s = 512 / tiles;                                     // ~2 resident workgroups per CU
-    const int total_steps = (M + 63) / 64;
+    const bool big = wgrad_big_ok(M, N, K);
+    const int tiles = big ? (N / 256) * (K / 256) : (N / 128) * (K / 128);
+    int s = (big ? 256 : 512) / tiles;                       // one 256x256 or ~2 128x128 workgroups per CU
+    const int total_steps = big ? (M + WB_ROWS - 1) / WB_ROWS : (M + 63) / 64;
     if (s < 1) s = 1;
     if (s > 32) s = 32;
     if (s > total_steps) s = total_steps;
@@ -651,12 +834,15 @@ extern "C" int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_
     ACR_CHECK_ARG((ldy % 8) == 0 && (ldx % 8) == 0 && ldy >= N && ldx >= K && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0,
                   "acr_wgrad_bf16: row pitches must be multiples of 8 elements and operands 16-byte aligned");
     const int nsplit = wgrad_split(M, N, K);
-    const int total_steps = (M + 63) / 64;
+    const int total_steps = wgrad_big_ok(M, N, K) ? (M + WB_ROWS - 1) / WB_ROWS : (M + 63) / 64;
     const int sps = (total_steps + nsplit - 1) / nsplit;
-    const int tiles = (N / 128) * (K / 128);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tiles * nsplit), dim3(256), 0, st, (const bf16_t*)dy, ldy, (const bf16_t*)x,
-                       ldx, ws, M, N, K, nsplit, sps);
+    if (wgrad_big_ok(M, N, K))
+        hipLaunchKernelGGL(gemm_tn_bf16_big_kernel, dim3((N / 256) * (K / 256) * nsplit), dim3(256), 0, st, (const bf16_t*)dy, ldy,
+                           (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps);
+    else
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((N / 128) * (K / 128) * nsplit), dim3(256), 0, st, (const bf16_t*)dy, ldy,
+                           (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps);
     const int64_t nk = (int64_t)N * K;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsplit,
                        nk, (bf16_t*)dw);
