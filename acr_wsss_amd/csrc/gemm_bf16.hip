@@ -233,18 +233,24 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_dma_kernel(const bf16_t* __r
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// 256x256x64 variant: 4 waves (2 x 2), each owning a 128x128 accumulator (16 MFMA tiles, 256 accumulator registers).
-// The 128x128 kernel above gives every wave a 64x64 tile: per 16-deep K slice it reads 4 fragments (4 KiB) from LDS
-// for 4 MFMAs, which with two workgroups per CU is 125 B/clk -- the LDS port's whole 128 B/clk, so MFMA utilisation
-// is capped near 50 %.  A 128x128 wave tile reads 8 fragments for 16 MFMAs (half the LDS bytes per flop, ~62 B/clk
-// at full MFMA rate).  Two 64-deep stages of 64 KiB (128-byte rows = whole cache lines per DMA row, same chunk
-// swizzle as above); the outputs of the fragment-read asm are early-clobber: the reads land asynchronously, so an
-// output tuple must never share a register with the address operand of a later read in the same statement.
+// 256x256 tile variant: 4 waves (2 x 2), each owning a 128x128 accumulator (16 MFMA tiles, 256 accumulator registers).
+// The 128x128 kernel above gives every wave a 64x64 tile (4 fragment reads per 4 MFMAs) and relies on a second
+// workgroup per CU to hide its DMA waits.  Here: 8 fragment reads per 16 MFMAs, ONE workgroup per CU, and everything is
+// hidden inside the wave's own instruction stream (same recipe as gemm_tn_bf16_big_kernel below, where it is derived):
+//  * ring of FOUR 32-deep K stages (32 KiB each), filled three stages ahead, counted vmcnt waits;
+//  * the 8 DMA instructions of a stage are spread one per 4 MFMAs (a burst parks the in-order wave in the memory
+//    pipe's issue queue while the matrix pipe drains);
+//  * fragment reads are inline asm with counted lgkmcnt waits, one 16-deep slice ahead of the MFMAs; the asm outputs
+//    are early-clobber: the reads land asynchronously, so an output tuple must never share a register with the address
+//    operand of a later read in the same statement;
+//  * the barrier that publishes stage kt+1 sits between the two slices of stage kt.
+// LDS rows are 64 bytes (4 x 16-byte chunks); chunk c of row r sits at physical chunk c ^ ((r >> 2) & 3), so the 16
+// rows of a ds_read_b128 lane group cover 16 distinct 16-byte slots of the 256-byte bank row.
 // ---------------------------------------------------------------------------------------------------------------
 #define GB_BM 256
 #define GB_BN 256
-#define GB_BK 64
-#define GB_STAGE ((GB_BM + GB_BN) * GB_BK)        // elements per stage: A tile (256 x 64) then B tile (256 x 64) = 64 KiB
+#define GB_BK 32
+#define GB_STAGE ((GB_BM + GB_BN) * GB_BK)        // elements per stage: A tile (256 x 32) then B tile (256 x 32) = 32 KiB
 
 template <bool BIAS, bool RESID>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_big_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ bias,
                                                                const bf16_t* __restrict__ R, int64_t ldr,
                                                                bf16_t* __restrict__ Y, int64_t ldy, int M, int N, int K) {
-    __shared__ __attribute__((aligned(1024))) bf16_t smem[2 * GB_STAGE];
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[4 * GB_STAGE];
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef const __attribute__((address_space(1))) void* glb_vp;
     const int ntn = (N + GB_BN - 1) / GB_BN;
@@ -264,26 +270,19 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_big_kernel(const bf16_t* __r
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
     const int nk = K / GB_BK;
-    // DMA sources: instruction i of this wave fills rows (wave*8 + i)*8 .. +7 of the A tile (and of the B tile);
-    // rows are 128 bytes (one cache line), chunk c of row r sits at physical chunk c ^ ((r >> 1) & 7)
-    uint32_t aoff[8], boff[8];                              // per-lane byte offsets; the K advance goes into the uniform base
+    // DMA instruction q (0..7) of a stage: operand q >> 2 (A, B), rows ((wave * 4 + (q & 3)) * 16 .. +15 of its tile
+    uint32_t doff[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = (wave * 8 + i) * 8 + (lane >> 3);
-        const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        aoff[i] = (uint32_t)(((int64_t)min(m0 + row, M - 1) * lda + lc * 8) * 2);
-        boff[i] = (uint32_t)(((int64_t)min(n0 + row, N - 1) * ldb + lc * 8) * 2);
+    for (int q = 0; q < 8; ++q) {
+        const int row = (wave * 4 + (q & 3)) * 16 + (lane >> 2);
+        const int lc = (lane & 3) ^ ((row >> 2) & 3);
+        doff[q] = (q >> 2) ? (uint32_t)(((int64_t)min(n0 + row, N - 1) * ldb + lc * 8) * 2)
+                           : (uint32_t)(((int64_t)min(m0 + row, M - 1) * lda + lc * 8) * 2);
     }
-    auto issue = [&](int kt, int stage) {
-        bf16_t* sa = smem + stage * GB_STAGE;
-        const char* ab = reinterpret_cast<const char*>(A + kt * GB_BK);
-        const char* bb = reinterpret_cast<const char*>(B + kt * GB_BK);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_global_load_lds((glb_vp)(ab + aoff[i]), (lds_vp)(sa + (wave * 8 + i) * 8 * GB_BK), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_global_load_lds((glb_vp)(bb + boff[i]), (lds_vp)(sa + GB_BM * GB_BK + (wave * 8 + i) * 8 * GB_BK), 16, 0, 0);
+    auto dma = [&](int kt, int q) {
+        const char* base = (q >> 2) ? reinterpret_cast<const char*>(B + kt * GB_BK) : reinterpret_cast<const char*>(A + kt * GB_BK);
+        bf16_t* dst = smem + (kt & 3) * GB_STAGE + (q >> 2) * (GB_BM * GB_BK) + (wave * 4 + (q & 3)) * 16 * GB_BK;
+        __builtin_amdgcn_global_load_lds((glb_vp)(base + doff[q]), (lds_vp)dst, 16, 0, 0);
     };
     f32x16 acc[4][4];
 #pragma unroll
@@ -292,24 +291,17 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_big_kernel(const bf16_t* __r
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    issue(0, 0);
-    // Software pipeline, one 16-deep K slice ahead, fragment reads and their waits in inline asm: the compiler's own
-    // s_waitcnt insertion drains lgkmcnt(0) where a counted wait ("all but the newest batch of 8 reads") is enough.
-    // The barrier that publishes stage kt+1 and frees stage kt sits before the LAST slice's MFMAs of stage kt, so the
-    // barrier, the DMA issue for stage kt+2 and the first fragment reads of stage kt+1 all hide behind 16 MFMAs.
     bf16x8 a0[4], b0[4], a1[4], b1[4];
     const int ra = wm * 128 + r, rb = wn * 128 + r;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)smem;
-    const uint32_t swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
-    uint32_t oa[4], ob[4];                                  // byte address of this lane's fragment row for K slice ks
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        oa[ks] = lds0 + ra * 128 + (((2 * ks + hh) ^ swa) << 4);
-        ob[ks] = lds0 + GB_BM * GB_BK * 2 + rb * 128 + (((2 * ks + hh) ^ swb) << 4);
-    }
+    const uint32_t swa = (ra >> 2) & 3, swb = (rb >> 2) & 3;
+    // byte address of this lane's fragment row for K slice ks: row * 64 + ((2 ks + hh) ^ sw) * 16; +32 rows = +2048 B
+    const uint32_t oa0 = lds0 + ra * 64 + ((hh ^ swa) << 4), oa1 = lds0 + ra * 64 + (((2 + hh) ^ swa) << 4);
+    const uint32_t ob0 = lds0 + GB_BM * GB_BK * 2 + rb * 64 + ((hh ^ swb) << 4);
+    const uint32_t ob1 = lds0 + GB_BM * GB_BK * 2 + rb * 64 + (((2 + hh) ^ swb) << 4);
 #define GB_READ4(dst, addr)                                                                         \
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\t"                        \
-                 "ds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %4 offset:12288"               \
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\t"                        \
+                 "ds_read_b128 %2, %4 offset:4096\n\tds_read_b128 %3, %4 offset:6144"                \
                  : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(addr))
 #define GB_WAIT8(cnt, x, y)                                                                                          \
     asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                       \
@@ -317,57 +309,62 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_big_kernel(const bf16_t* __r
 #define GB_MFMA16(x, y)                                                                                              \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                 \
         acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i_], y[j_], acc[i_][j_], 0, 0, 0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    if (nk > 1) issue(1, 1);
-    asm volatile("" ::: "memory");
-    GB_READ4(a0, oa[0]);
-    GB_READ4(b0, ob[0]);
-    // MODE 0: steady state (publish stage kt+1, refill stage kt's buffer with stage kt+2); 1: second to last stage (publish
-    // only); 2: last stage.  The loop is peeled instead of branching inside one body so that each body is a single
-    // straight-line block: the scheduler can then spread the DMA issue over the MFMAs, and the accumulators never
-    // meet at a control-flow merge (a merge made the register allocator spill them).
-    auto stage_body = [&](int kt, auto mode_tag) {
+#define GB_SPREAD4                                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                           \
+    }
+    // MODE 0: steady state (issues stage kt+3); 1: a later stage exists but nothing left to issue; 2: last stage.  The
+    // loop is peeled so that each body is straight-line code: the scheduler groups can interleave it, and the
+    // accumulators never meet at a control-flow merge (a merge made the register allocator spill them).
+    auto body = [&](int kt, auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
-        const uint32_t so = (uint32_t)(kt & 1) * (GB_STAGE * 2), so2 = (uint32_t)((kt + 1) & 1) * (GB_STAGE * 2);
-        GB_READ4(a1, oa[1] + so);
-        GB_READ4(b1, ob[1] + so);
+        const uint32_t so = (uint32_t)(kt & 3) * (GB_STAGE * 2), so2 = (uint32_t)((kt + 1) & 3) * (GB_STAGE * 2);
+        GB_READ4(a1, oa1 + so);                             // slice 1 of stage kt
+        GB_READ4(b1, ob1 + so);
         GB_WAIT8(8, a0, b0);
-        GB_MFMA16(a0, b0);                                  // slice 0
-        GB_READ4(a0, oa[2] + so);
-        GB_READ4(b0, ob[2] + so);
-        GB_WAIT8(8, a1, b1);
-        GB_MFMA16(a1, b1);                                  // slice 1
-        GB_READ4(a1, oa[3] + so);
-        GB_READ4(b1, ob[3] + so);
-        GB_WAIT8(8, a0, b0);
-        GB_MFMA16(a0, b0);                                  // slice 2
-        GB_WAIT8(0, a1, b1);                                // last fragments of stage kt are in registers
+        if (MODE == 0) { dma(kt + 3, 0); dma(kt + 3, 1); dma(kt + 3, 2); dma(kt + 3, 3); }
+        GB_MFMA16(a0, b0);
+        if (MODE == 0) { GB_SPREAD4 }
+        GB_WAIT8(0, a1, b1);                                // this wave holds every fragment of stage kt
         if (MODE <= 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of stage kt+1 has landed
-            asm volatile("s_barrier" ::: "memory");             // ... everyone's; and nobody reads stage kt any more
-            GB_READ4(a0, oa[0] + so2);
-            GB_READ4(b0, ob[0] + so2);
+            // stage kt+1 must have landed; stage kt+2 (8) and the first half of stage kt+3 (4) may stay in flight
+            if (MODE == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            GB_READ4(a0, oa0 + so2);                        // slice 0 of stage kt+1
+            GB_READ4(b0, ob0 + so2);
         }
-        if (MODE == 0) issue(kt + 2, kt & 1);
-        GB_MFMA16(a1, b1);                                  // slice 3
-        if (MODE == 0) {
-            // spread the 16 DMA instructions of stage kt+2 one per MFMA: an in-order wave issues a DMA (m0 setup + load)
-            // inside the 24 free issue cycles of a 32-cycle MFMA instead of as a block during which the matrix pipe drains
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one VMEM read (the LDS-DMA)
-            }
-        }
+        if (MODE == 0) { dma(kt + 3, 4); dma(kt + 3, 5); dma(kt + 3, 6); dma(kt + 3, 7); }
+        GB_MFMA16(a1, b1);
+        if (MODE == 0) { GB_SPREAD4 }
     };
-    int kt = 0;
-    for (; kt + 2 < nk; ++kt) stage_body(kt, std::integral_constant<int, 0>{});
-    if (kt + 1 < nk) { stage_body(kt, std::integral_constant<int, 1>{}); ++kt; }
-    stage_body(kt, std::integral_constant<int, 2>{});
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma(0, q);
+    if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dma(1, q);
+    }
+    if (nk > 2) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dma(2, q);
+    }
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    GB_READ4(a0, oa0);
+    GB_READ4(b0, ob0);
+    {
+        int kt = 0;
+        for (; kt + 3 < nk; ++kt) body(kt, std::integral_constant<int, 0>{});
+        for (; kt + 1 < nk; ++kt) body(kt, std::integral_constant<int, 1>{});
+        body(kt, std::integral_constant<int, 2>{});
+    }
 #undef GB_READ4
 #undef GB_WAIT8
 #undef GB_MFMA16
+#undef GB_SPREAD4
     __syncthreads();                                        // all fragment reads done before LDS is reused below
     // Epilogue through LDS, one 64x64 quadrant of the wave's 128x128 tile at a time (wave-private 16 KiB).
     float* stile = reinterpret_cast<float*>(smem) + wave * 4096;
