@@ -545,6 +545,24 @@ __device__ __forceinline__ bf16x8 wg_frag(const bf16_t* tile, int s, int blk, in
     return r;
 }
 
+// The same fragment through inline asm.  hipcc puts s_waitcnt vmcnt(0) in front of a ds_read_b64_tr_b16 BUILTIN that
+// follows an LDS-DMA in the same block (it cannot tell the DMA's LDS write from the read), which drains the prefetch
+// of the next tile before the current one is used.  The asm reads are invisible to that analysis; the caller waits with
+// wg_frag_wait (lgkmcnt(0), tied to the registers) before the first MFMA.  Early-clobber outputs: the reads land
+// asynchronously, an output must not share a register with the address of the second read.
+__device__ __forceinline__ void wg_frag_issue(const bf16_t* tile, int s, int blk, int lane, bf16x4& lo, bf16x4& hi) {
+    const int i = lane & 15, h = lane >> 5;
+    const int row = 16 * s + 4 * h + (i >> 2);
+    const int col = 32 * blk + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+    const int sw = ((col >> 3) ^ ((row & 3) << 2)) << 3;
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)(tile + row * 128 + sw + (col & 7));
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(lo), "=&v"(hi) : "v"(addr));
+}
+#define WG_FRAG_WAIT8(L, H)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                             \
+                 : "+v"(L[0]), "+v"(L[1]), "+v"(L[2]), "+v"(L[3]), "+v"(L[4]), "+v"(L[5]), "+v"(L[6]), "+v"(L[7]),  \
+                   "+v"(H[0]), "+v"(H[1]), "+v"(H[2]), "+v"(H[3]), "+v"(H[4]), "+v"(H[5]), "+v"(H[6]), "+v"(H[7]))
+
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ dY, int64_t ldy,
                                                            const bf16_t* __restrict__ X, int64_t ldx,
                                                            float* __restrict__ slabs, int M, int N, int K, int nsplit,
@@ -918,10 +936,18 @@ __global__ __launch_bounds__(256) void conv1x1_nn_kernel(const bf16_t* __restric
         const bf16_t* as = smem + cur * 2 * GL_TILE;
         const bf16_t* bs = as + GL_TILE;
         const int ra = wm * 64 + r;
+        bf16x4 bl[8], bh[8];                                // all 8 activation fragments of the step (asm reads)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            wg_frag_issue(bs, ks, 2 * wn, lane, bl[2 * ks], bh[2 * ks]);
+            wg_frag_issue(bs, ks, 2 * wn + 1, lane, bl[2 * ks + 1], bh[2 * ks + 1]);
+        }
+        WG_FRAG_WAIT8(bl, bh);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 a0 = c1_frag_a(as, ra, ks, hh), a1 = c1_frag_a(as, ra + 32, ks, hh);
-            const bf16x8 b0 = wg_frag(bs, ks, 2 * wn, lane), b1 = wg_frag(bs, ks, 2 * wn + 1, lane);
+            const bf16x8 b0 = __builtin_shufflevector(bl[2 * ks], bh[2 * ks], 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 b1 = __builtin_shufflevector(bl[2 * ks + 1], bh[2 * ks + 1], 0, 1, 2, 3, 4, 5, 6, 7);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);

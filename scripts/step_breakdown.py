@@ -5,8 +5,11 @@ path = sys.argv[1]; nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 marks = [int(r['Start_Timestamp']) for r in rows if 'consistency_fwd' in r['Kernel_Name'] or 'cons_fwd' in r['Kernel_Name']]
-assert len(marks) > nsteps, len(marks)
-t0, t1 = marks[-1 - nsteps], marks[-1]
+# keep only markers that open a real training step (>= 10 ms to the next marker); the roofline probe launches the same
+# kernel back to back at the end of the run
+real = [i for i in range(len(marks) - 1) if marks[i + 1] - marks[i] > 10e6]
+assert len(real) > nsteps + 1, len(real)
+t0, t1 = marks[real[-1 - nsteps]], marks[real[-1]]          # the last interval may run into the probe: leave it out
 d = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     s = int(r['Start_Timestamp'])
