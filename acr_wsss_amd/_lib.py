@@ -69,7 +69,8 @@ SIGNATURES = {
     "acr_groupnorm_fwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                          c_int32, c_float, c_int32, c_void_p]),
     "acr_groupnorm_bwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                         c_void_p]),
     "acr_weight_std_bf16": (c_int32, [c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p]),
     "acr_getam_row_accum": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       c_void_p, c_void_p]),

@@ -208,10 +208,23 @@ extern "C" int acr_groupnorm_fwd_bf16(const void* x, const void* resid, const vo
     return acr_check_launch("acr_groupnorm_fwd_bf16");
 }
 
+// dgamma[c] = sum_n dgamma_part[n][c] (same for dbeta), samples summed in order, one bf16 rounding at the end
+__global__ __launch_bounds__(256) void gn_param_reduce_kernel(const float* __restrict__ gpart, const float* __restrict__ bpart,
+                                                              int N, int C, bf16_t* __restrict__ dgamma,
+                                                              bf16_t* __restrict__ dbeta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C) return;
+    const float* src = (i < C) ? gpart + i : bpart + (i - C);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += src[(int64_t)n * C];
+    if (i < C) dgamma[i] = (bf16_t)s;
+    else dbeta[i - C] = (bf16_t)s;
+}
+
 extern "C" int acr_groupnorm_bwd_bf16(const void* dy, const void* x, const void* resid, const void* gamma,
                                       const void* beta, const float* stats, void* dx, void* dresid,
-                                      float* dgamma_part, float* dbeta_part, int32_t N, int32_t C, int32_t HW,
-                                      int32_t act, void* stream) {
+                                      float* dgamma_part, float* dbeta_part, void* dgamma, void* dbeta, int32_t N,
+                                      int32_t C, int32_t HW, int32_t act, void* stream) {
     ACR_CHECK_ARG(dy && x && gamma && beta && stats && dx && dgamma_part && dbeta_part &&
                       (act != GN_ACT_ADD_RELU || (resid && dresid)),
                   "acr_groupnorm_bwd_bf16: null pointer");
@@ -222,5 +235,8 @@ extern "C" int acr_groupnorm_bwd_bf16(const void* dy, const void* x, const void*
     hipStream_t st = (hipStream_t)stream;
     GN_DISPATCH(gn_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)resid, (const bf16_t*)gamma,
                 (const bf16_t*)beta, stats, (bf16_t*)dx, (bf16_t*)dresid, dgamma_part, dbeta_part, C, HW, cg)
+    if (dgamma && dbeta)
+        hipLaunchKernelGGL(gn_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, (const float*)dgamma_part,
+                           (const float*)dbeta_part, N, C, (bf16_t*)dgamma, (bf16_t*)dbeta);
     return acr_check_launch("acr_groupnorm_bwd_bf16");
 }

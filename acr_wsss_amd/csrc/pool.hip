@@ -57,6 +57,44 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* __restri
     dx[p] = (bf16_t)g;
 }
 
+// 8 consecutive pixels of one input row per thread (one 16-byte store): the windows touching them are <= 6 columns x 2
+// rows of outputs, whose argmax bytes and gradients are read once into registers.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8p;
+__global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(const bf16_t* __restrict__ dy, const uint8_t* __restrict__ amax,
+                                                              bf16_t* __restrict__ dx, int64_t total8, int H, int W, int Ho,
+                                                              int Wo, int pt, int pl) {
+    const int64_t t8 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t8 >= total8) return;
+    const int W8 = W >> 3;
+    const int w0 = (int)(t8 % W8) * 8;
+    const int64_t t = t8 / W8;
+    const int h = (int)(t % H);
+    const int64_t nc = t / H;
+    const bf16_t* dyp = dy + nc * Ho * Wo;
+    const uint8_t* ap = amax + nc * Ho * Wo;
+    const int ho_lo = max((h + pt - 1) >> 1, 0), ho_hi = min((h + pt) >> 1, Ho - 1);
+    const int wo_first = max((w0 + pl - 1) >> 1, 0), wo_last = min((w0 + 7 + pl) >> 1, Wo - 1);   // <= 6 columns
+    float g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+        const int i = h - (2 * ho - pt);                     // row of the pixel inside window ho
+        for (int wo = wo_first; wo <= wo_last; ++wo) {
+            const int a = ap[ho * Wo + wo];
+            if (a / 3 == i) {
+                const int e = (2 * wo - pl) + (a - 3 * i) - w0;      // which of my 8 pixels this window's maximum is
+                if (e >= 0 && e < 8) {
+                    const float v = (float)dyp[ho * Wo + wo];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) g[k] += (k == e) ? v : 0.f;
+                }
+            }
+        }
+    }
+    bf16x8p o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (bf16_t)g[k];
+    *reinterpret_cast<bf16x8p*>(dx + (nc * H + h) * W + w0) = o;
+}
+
 extern "C" int acr_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* amax, int64_t nc, int32_t h, int32_t w, int32_t ho,
                                          int32_t wo, int32_t pad_top, int32_t pad_left, void* stream) {
     ACR_CHECK_ARG(x && y && amax, "acr_maxpool3x3s2_fwd_bf16: null pointer");
@@ -77,6 +115,12 @@ extern "C" int acr_maxpool3x3s2_bwd_bf16(const void* dy, const uint8_t* amax, vo
                   "acr_maxpool3x3s2_bwd_bf16: bad geometry");
     const int64_t total = nc * h * w;
     ACR_CHECK_ARG((total + 255) / 256 < (1ll << 31), "acr_maxpool3x3s2_bwd_bf16: too large");
+    if ((w % 8) == 0 && ((uintptr_t)dx & 15) == 0) {
+        const int64_t total8 = total / 8;
+        hipLaunchKernelGGL(maxpool_bwd_vec_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dy, amax, (bf16_t*)dx, total8, h, w, ho, wo, pad_top, pad_left);
+        return acr_check_launch("acr_maxpool3x3s2_bwd_bf16");
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dy, amax, (bf16_t*)dx, total, h, w, ho, wo, pad_top, pad_left);
     return acr_check_launch("acr_maxpool3x3s2_bwd_bf16");

@@ -463,11 +463,11 @@ class GroupNormActFn(Function):
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.act == 2 else None
         part = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
+        dgb = torch.empty((2, C), dtype=torch.bfloat16, device=x.device)      # summed over samples inside the call
         L.check(lib.acr_groupnorm_bwd_bf16(L.ptr(dy), L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(stats),
-                                           L.ptr(dx), L.ptr(dres), L.ptr(part[0]), L.ptr(part[1]), N, C, H * W, ctx.act,
-                                           L.stream_ptr()), "acr_groupnorm_bwd_bf16")
-        sums = part.sum(dim=1)                              # fixed-order reduction over samples
-        return dx, sums[0].to(weight.dtype), sums[1].to(bias.dtype), dres, None, None
+                                           L.ptr(dx), L.ptr(dres), L.ptr(part[0]), L.ptr(part[1]), L.ptr(dgb[0]),
+                                           L.ptr(dgb[1]), N, C, H * W, ctx.act, L.stream_ptr()), "acr_groupnorm_bwd_bf16")
+        return dx, dgb[0], dgb[1], dres, None, None
 
 
 def groupnorm_act(x, weight, bias, act="relu", resid=None, eps=1e-5):

@@ -155,13 +155,13 @@ int acr_layernorm_bwd_bf16(const void* dy, const void* x, const void* gamma, con
  * models/layers/norm_act.py:69-85 (GroupNormAct), models/resnetv2.py:205-215 (norm3 -> act3(x + shortcut)).
  * act: 0 = none, 1 = ReLU, 2 = ReLU(gn(x) + resid).  x/resid/y: (N,C,H,W) contiguous, HW = H*W (multiple of 8),
  * C a multiple of 32; stats: (N*32*2) fp32 [mean, rstd] written by forward, read by backward.
- * Backward writes dx (and dresid for act 2) plus per-sample partials dgamma_part/dbeta_part (N,C) fp32 that the
- * caller sums over N. */
+ * Backward writes dx (and dresid for act 2) plus per-sample partials dgamma_part/dbeta_part (N,C) fp32; with
+ * dgamma/dbeta (bf16 (C), nullable as a pair) it also sums them over the samples, in sample order. */
 int acr_groupnorm_fwd_bf16(const void* x, const void* resid, const void* gamma, const void* beta, void* y,
                            float* stats, int32_t N, int32_t C, int32_t HW, float eps, int32_t act, void* stream);
 int acr_groupnorm_bwd_bf16(const void* dy, const void* x, const void* resid, const void* gamma, const void* beta,
                            const float* stats, void* dx, void* dresid, float* dgamma_part, float* dbeta_part,
-                           int32_t N, int32_t C, int32_t HW, int32_t act, void* stream);
+                           void* dgamma, void* dbeta, int32_t N, int32_t C, int32_t HW, int32_t act, void* stream);
 
 /* Weight standardisation of all StdConv2dSame weights of the stem in one launch (models/layers/std_conv.py:56-59).
  * desc_dev: device array of n_conv records {uint64 p0,p1,p2,p3; int32 cout, n, ch_start, pad} sorted by ch_start
