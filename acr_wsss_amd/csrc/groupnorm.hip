@@ -212,13 +212,25 @@ extern "C" int acr_groupnorm_fwd_bf16(const void* x, const void* resid, const vo
 __global__ __launch_bounds__(256) void gn_param_reduce_kernel(const float* __restrict__ gpart, const float* __restrict__ bpart,
                                                               int N, int C, bf16_t* __restrict__ dgamma,
                                                               bf16_t* __restrict__ dbeta) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
-    const float* src = (i < C) ? gpart + i : bpart + (i - C);
+    // 32 columns x 8 sample groups per block: group s sums samples s, s+8, ... in order, the 8 partials are combined in
+    // fixed order through LDS (a single thread walking all N samples is a chain of N dependent L2 round trips)
+    __shared__ float sh[8][33];
+    const int cl = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;                      // over 2*C columns
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s += src[(int64_t)n * C];
-    if (i < C) dgamma[i] = (bf16_t)s;
-    else dbeta[i - C] = (bf16_t)s;
+    if (i < 2 * C) {
+        const float* src = (i < C) ? gpart + i : bpart + (i - C);
+        for (int n = sg; n < N; n += 8) s += src[(int64_t)n * C];
+    }
+    sh[sg][cl] = s;
+    __syncthreads();
+    if (sg == 0 && i < 2 * C) {
+        float t = sh[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sh[k][cl];
+        if (i < C) dgamma[i] = (bf16_t)t;
+        else dbeta[i - C] = (bf16_t)t;
+    }
 }
 
 extern "C" int acr_groupnorm_bwd_bf16(const void* dy, const void* x, const void* resid, const void* gamma,
@@ -236,7 +248,7 @@ extern "C" int acr_groupnorm_bwd_bf16(const void* dy, const void* x, const void*
     GN_DISPATCH(gn_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)resid, (const bf16_t*)gamma,
                 (const bf16_t*)beta, stats, (bf16_t*)dx, (bf16_t*)dresid, dgamma_part, dbeta_part, C, HW, cg)
     if (dgamma && dbeta)
-        hipLaunchKernelGGL(gn_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, (const float*)dgamma_part,
+        hipLaunchKernelGGL(gn_param_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, (const float*)dgamma_part,
                            (const float*)dbeta_part, N, C, (bf16_t*)dgamma, (bf16_t*)dbeta);
     return acr_check_launch("acr_groupnorm_bwd_bf16");
 }

@@ -113,6 +113,21 @@ def roofline_probe(args, dev):
                                         args.size // 16, L.ptr(ws), L.ptr(out2), st), "k3")
     t_k3 = time_kernel(k3)
     k3_bytes = 4.0 * B * Lyr * T * T
+    # second MFMA kernel of the step by time: the weight-gradient GEMM dW = dY^T X (fc1's shape), bf16 mode only
+    wg = None
+    if args.dtype == "bf16":
+        Mtok, Nw, Kw = B * T, 3072, 768
+        dyw = torch.randn(Mtok, Nw, generator=g).to(dev).bfloat16()
+        xw = torch.randn(Mtok, Kw, generator=g).to(dev).bfloat16()
+        wsw = torch.empty(lib.acr_wgrad_ws_floats(Mtok, Nw, Kw), dtype=torch.float32, device=dev)
+        dww = torch.empty(Nw, Kw, dtype=torch.bfloat16, device=dev)
+
+        def wgrad():
+            L.check(lib.acr_wgrad_bf16(L.ptr(dyw), Nw, L.ptr(xw), Kw, Mtok, Nw, Kw, L.ptr(wsw), L.ptr(dww), st), "wgrad")
+        t_wg = time_kernel(wgrad)
+        wg = {"bound": "mfma", "achieved": round(2.0 * Mtok * Nw * Kw / t_wg / 1e12, 2), "peak": PEAK_MFMA["bf16"] / 1e12,
+              "unit": "TFLOP/s", "frac": round(2.0 * Mtok * Nw * Kw / t_wg / PEAK_MFMA["bf16"], 4),
+              "launch_ms": round(t_wg * 1e3, 3), "shape": "dW(3072x768) over %d tokens, incl. slab reduction" % Mtok}
     peak = PEAK_MFMA[args.dtype] if args.dtype == "f32" else PEAK_MFMA["bf16"]
     ach = fl_bwd / t_bwd / 1e12
     # HBM traffic of the same launches from the committed rocprofv3 PMC passes (bench.py --probe-only under
@@ -131,6 +146,7 @@ def roofline_probe(args, dev):
         "attn_fwd": {"achieved": round(fl_fwd / t_fwd / 1e12, 2), "launch_ms": round(t_fwd * 1e3, 3)},
         "consistency_fwd": {"bound": "hbm", "achieved": round(k3_bytes / t_k3 / 1e9, 1), "peak": 8000.0,
                             "unit": "GB/s", "frac": round(k3_bytes / t_k3 / 8e12, 4), "launch_ms": round(t_k3 * 1e3, 3)},
+        "wgrad_gemm": wg,
     }
 
 
