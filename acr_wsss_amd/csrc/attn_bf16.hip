@@ -418,9 +418,16 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
                                                            const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                            const bf16_t* __restrict__ d_o,
                                                            const float* __restrict__ lse2,
-                                                           const float* __restrict__ delta,
+                                                           float* __restrict__ delta,
                                                            const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
                                                            bf16_t* __restrict__ dq) {
+    // With G (the head-mean gradient) the flash-backward row term is delta_i = D_i + rho_i/H, D_i = rowsum(dO o O),
+    // rho_i = sum_j P_ij G_ij.  rho needs a full sweep over the keys -- a separate kernel cost 120 us per layer.  Here the
+    // sweep is this one: dS_ij = P_ij (dP_ij + G_ij/H - D_i) - (rho_i/H) P_ij is linear in rho_i, so
+    //     dQ_i = X_i - (rho_i/H) Y_i,   X_i = sum_j P_ij (dP_ij + G_ij/H - D_i) K_j,   Y_i = sum_j P_ij K_j,
+    // with X, Y and rho accumulated side by side (one extra product) and combined in fp32 at the end; the kernel takes
+    // D in `delta` and overwrites it with the full delta for the dK/dV sweep that follows.  rho/H is ~1e-6 of the
+    // other terms (G = +-alpha/count), so the subtraction cancels nothing and the correction stays in fp32.
     __shared__ __attribute__((aligned(16))) bf16_t kt[2][64 * BP];
     __shared__ __attribute__((aligned(16))) bf16_t vt[2][64 * BP];
     const int nqt = (g.T + 63) >> 6;
@@ -454,6 +461,8 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
     tile_lstore<128>(vt[0], vr, 0, g.T, tid);
     __syncthreads();
     f32x16 dq0 = {0}, dq1 = {0};
+    f32x16 y0 = {0}, y1 = {0};                              // HAS_G only
+    float rho = 0.f;
     int cur = 0;
     // one step = 64 keys.  EDGE steps (the partial last tile, and the step that prefetches it) carry the clamps and
     // the key masks; all other steps are straight-line code without a single compare/select.
@@ -479,20 +488,31 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
             f32x16 s = {0}, dp = {0};
             mma_rowop_bf(s, ktc, qreg, lane);               // S^T raw [key = krow][query = r]
             mma_rowop_bf(dp, vtc, doreg, lane);             // dP^T
-            f32x16 ds;
+            f32x16 ds, pv;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 float p = fast_exp2(fmaf(s[reg], c, -l2));
-                float t = HAS_G ? fmaf(gq[kb][reg >> 2][reg & 3], invH, dp[reg]) : dp[reg];
+                float gv = HAS_G ? gq[kb][reg >> 2][reg & 3] : 0.f;
+                float t = dp[reg];
                 if (EDGE) {                                 // pad columns of G may hold anything: select, don't multiply
                     const bool kv = k0 + 32 * kb + acr_krow(reg, hh) < g.T;
                     p = kv ? p : 0.f;
                     t = kv ? t : 0.f;
+                    gv = kv ? gv : 0.f;
+                }
+                if (HAS_G) {
+                    t = fmaf(gv, invH, t);
+                    rho = fmaf(p, gv, rho);
+                    pv[reg] = p;
                 }
                 ds[reg] = p * (t - dl);
             }
             mma_accop_a_bf(dq0, ds, ktc, 0, lane);          // dQ[query = krow][d = 32*blk + r]
             mma_accop_a_bf(dq1, ds, ktc, 1, lane);
+            if (HAS_G) {
+                mma_accop_a_bf(y0, pv, ktc, 0, lane);       // Y[query = krow][d]
+                mma_accop_a_bf(y1, pv, ktc, 1, lane);
+            }
         }
         ACR_MEMBAR();
         tile_lstore<128>(kt[cur ^ 1], kr, k0 + 64, g.T, tid);
@@ -503,9 +523,19 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
     int k0 = 0;
     for (; k0 + 128 <= g.T; k0 += 64) step(k0, std::false_type{});
     for (; k0 < g.T; k0 += 64) step(k0, std::true_type{});
+    if (HAS_G) {
+        rho += __shfl_xor(rho, 32);                         // both halves of a lane pair hold keys of the same query row
+        rho *= invH;                                        // lane r (either half): rho_{q0+r} / H
+        if (hh == 0 && qok) delta[((int64_t)b * g.H + h) * g.T + q0 + r] = dl + rho;      // full delta for dK/dV
+    }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int qq = q0 + acr_krow(reg, hh);
+        if (HAS_G) {                                        // accumulator rows are krow(reg, hh): fetch that row's rho
+            const float rr = __shfl(rho, acr_krow(reg, hh));
+            dq0[reg] = fmaf(-rr, y0[reg], dq0[reg]);
+            dq1[reg] = fmaf(-rr, y1[reg], dq1[reg]);
+        }
         if (qq < g.T) {
             bf16_t* p = dq + base + (int64_t)qq * g.st;
             p[r] = (bf16_t)(dq0[reg] * g.scale);
@@ -673,14 +703,15 @@ void acr_attn_bwd_bf16(const acr_attn_desc* d, const void* q, const void* k, con
     AttnGeomB g = geom_b(d);
     const int nqt = (d->T + 63) / 64;
     const dim3 grid(d->B * d->H * nqt);
+    // delta kernel: D_i = rowsum(dO o O) only; with G the dQ sweep adds rho_i/H and rewrites delta before dK/dV reads it
+    hipLaunchKernelGGL((attn_delta_bf16_kernel<false>), grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)o, (const bf16_t*)d_o, lse2, (const float*)nullptr, (int64_t)0, (int64_t)0, delta);
 #define ACR_BWD_LAUNCH(HG)                                                                                          \
-    hipLaunchKernelGGL((attn_delta_bf16_kernel<HG>), grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,  \
-                       (const bf16_t*)o, (const bf16_t*)d_o, lse2, gm, gm_sb, gm_st, delta);                                \
+    hipLaunchKernelGGL((attn_dq_bf16_kernel<HG>), grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,     \
+                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, gm, gm_sb, gm_st, (bf16_t*)dq);             \
     hipLaunchKernelGGL((attn_dkdv_bf16_kernel<HG>), grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,   \
                        (const bf16_t*)v, (const bf16_t*)d_o, lse2, (const float*)delta, gm, gm_sb, gm_st, (bf16_t*)dk, \
-                       (bf16_t*)dv);                                                                                 \
-    hipLaunchKernelGGL((attn_dq_bf16_kernel<HG>), grid, dim3(128), 0, st, g, (const bf16_t*)q, (const bf16_t*)k,     \
-                       (const bf16_t*)v, (const bf16_t*)d_o, lse2, (const float*)delta, gm, gm_sb, gm_st, (bf16_t*)dq);
+                       (bf16_t*)dv);
     if (gm) { ACR_BWD_LAUNCH(true) } else { ACR_BWD_LAUNCH(false) }
 #undef ACR_BWD_LAUNCH
 }
