@@ -1,0 +1,24 @@
+"""Library-GEMM selection for the three MLP GEMMs that stay on hipBLASLt (fc1 forward, fc1 / fc2 input gradients).
+
+hipBLASLt's default heuristic picks 130-150 us kernels for these shapes at the bench geometry; its own exhaustive search
+(PyTorch TunableOp, run once on an MI355X: ``PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 python bench.py``)
+finds 108-119 us ones.  The result file is shipped; this module only switches TunableOp on in *lookup* mode (no tuning at
+run time).  A file recorded for another PyTorch / hipBLASLt / GPU is rejected by TunableOp's validators and the default
+heuristic stays in charge."""
+import os
+import torch
+
+TUNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+
+
+def enable_tuned_gemms(path=TUNED_FILE):
+    """Returns True when the tuned selections were loaded."""
+    if os.environ.get("ACR_TUNED_GEMMS", "1") == "0" or not torch.cuda.is_available() or not os.path.exists(path):
+        return False
+    try:
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(False)
+        torch.cuda.tunable.record_untuned_enable(False)
+        return bool(torch.cuda.tunable.read_file(path))
+    except Exception:                                      # TunableOp unavailable in this build: keep the default heuristic
+        return False

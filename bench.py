@@ -211,6 +211,8 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    from acr_wsss_amd.tuning import enable_tuned_gemms
+    tuned = enable_tuned_gemms()                           # shipped hipBLASLt selections for the three library GEMMs
     if args.probe_only:
         print(json.dumps(roofline_probe(args, dev)), flush=True)
         return
@@ -282,6 +284,7 @@ def main():
             "loss": round(loss_val, 5),
             "step_mfma_frac": round(value * FLOP_PER_IMG_448 * (args.size / 448.0) ** 2 / (world * PEAK_MFMA[args.dtype]), 4),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            "tuned_library_gemms": bool(tuned),
         }
         if world == 1 and not args.no_roofline:
             out["roofline"] = roofline_probe(args, dev)
