@@ -356,7 +356,13 @@ class VisionTransformer(nn.Module):
         if isinstance(self.patch_embed, HybridEmbed):
             x = self.patch_embed.backbone(x, taps)
         res_features = x
-        x = self.patch_embed.proj(x).flatten(2).transpose(1, 2)
+        pe = self.patch_embed.proj
+        if (isinstance(self.patch_embed, HybridEmbed) and StdConv2dSame.hip_1x1 and pe.bias is not None
+                and ops.conv1x1_fusable(x, pe.weight, pe.stride[0])):
+            x = ops.conv1x1(x, pe.weight) + pe.bias.view(1, -1, 1, 1)      # 1024 -> 768 projection on the NCHW GEMM kernels
+        else:
+            x = pe(x)
+        x = x.flatten(2).transpose(1, 2)
         toks = [self.cls_token.expand(b, -1, -1)]
         if self.dist_token is not None:
             toks.append(self.dist_token.expand(b, -1, -1))

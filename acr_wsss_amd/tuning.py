@@ -22,3 +22,27 @@ def enable_tuned_gemms(path=TUNED_FILE):
         return bool(torch.cuda.tunable.read_file(path))
     except Exception:                                      # TunableOp unavailable in this build: keep the default heuristic
         return False
+
+
+MIOPEN_DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+
+
+def use_shipped_miopen_db():
+    """Point MIOpen's *user* find-db at a private copy of the shipped one (recorded on an MI355X for the stem's
+    convolution shapes at the bench geometry).  Call before the first convolution.  Without it every fresh machine spends
+    ~30 s of the first step benchmarking solvers; with a db recorded for another MIOpen build the files are simply not
+    matched (their names carry arch + version) and nothing changes.  No effect when MIOPEN_USER_DB_PATH is already set."""
+    import shutil
+    import tempfile
+    if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(MIOPEN_DB_DIR):
+        return None
+    dst = os.path.join(tempfile.gettempdir(), "acr_miopen_db_%d_%s" % (os.getuid(), os.environ.get("LOCAL_RANK", "0")))
+    try:
+        os.makedirs(dst, exist_ok=True)
+        for f in os.listdir(MIOPEN_DB_DIR):
+            if not os.path.exists(os.path.join(dst, f)):
+                shutil.copy(os.path.join(MIOPEN_DB_DIR, f), os.path.join(dst, f))
+    except OSError:
+        return None
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    return dst

@@ -211,8 +211,11 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    from acr_wsss_amd.tuning import enable_tuned_gemms
+    from acr_wsss_amd.tuning import enable_tuned_gemms, use_shipped_miopen_db
+    use_shipped_miopen_db()                                # before the first convolution
     tuned = enable_tuned_gemms()                           # shipped hipBLASLt selections for the three library GEMMs
+    if os.environ.get("ACR_MIOPEN_FIND", "0") == "1":      # experiment: let MIOpen benchmark its solvers per conv shape
+        torch.backends.cudnn.benchmark = True
     if args.probe_only:
         print(json.dumps(roofline_probe(args, dev)), flush=True)
         return
