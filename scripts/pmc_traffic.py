@@ -1,0 +1,30 @@
+"""Builds profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes over `bench.py --probe-only`:
+     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dirF> -o p -- python3 bench.py --probe-only
+     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dirW> -o p -- python3 bench.py --probe-only
+   usage: pmc_traffic.py <dirF>/p_counter_collection.csv <dirW>/p_counter_collection.csv out.json
+   Units/corrections per MI355X_MICROARCH.md (HBM): counters are KB; FETCH_SIZE x2 on gfx950."""
+import csv, json, sys, collections
+
+def per_kernel(path, counter):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter:
+            d[r['Kernel_Name']].append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in d.items()}
+
+names = {"attn_fwd": "attn_fwd_bf16", "attn_pmean": "attn_tile_qk_bf16_kernel<0>", "attn_delta": "attn_delta_bf16",
+         "attn_dkdv": "attn_dkdv_bf16", "attn_dq": "attn_dq_bf16", "cons_fwd": "cons_fwd", "wgrad_gemm": "gemm_tn_bf16_big",
+         "wgrad_reduce": "wgrad_reduce_kernel"}
+F = per_kernel(sys.argv[1], "FETCH_SIZE"); W = per_kernel(sys.argv[2], "WRITE_SIZE")
+def pick(d, pat):
+    ks = [k for k in d if pat in k or pat.replace("<0>", "ILi0E") in k]
+    return sum(d[k] for k in ks) if ks else 0.0
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --probe-only; B=32 views,H=12,T=785,bf16",
+       "correction": "FETCH_SIZE KB x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM) x1024; WRITE_SIZE KB x1024",
+       "kernels": {}}
+for k, pat in names.items():
+    out["kernels"][k] = {"fetch_bytes": int(pick(F, pat) * 2 * 1024), "write_bytes": int(pick(W, pat) * 1024)}
+kk = out["kernels"]
+out["acr_attn_bwd_bytes_per_launch"] = sum(kk[n]["fetch_bytes"] + kk[n]["write_bytes"] for n in ("attn_delta", "attn_dkdv", "attn_dq"))
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
