@@ -13,6 +13,7 @@ SURVEY 7 scopes them; the attention core -- softmax(q k^T) v with the head-mean 
 consumes, and its backward -- is ``ops.attention_core`` (hand-written gfx950 kernels, include/acr_hip.h).
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -215,7 +216,9 @@ class Mlp(nn.Module):
         # fc1: forward and input gradient on hipBLASLt (faster on this short-K / wide-N shape), weight and bias gradient
         # on the hand-written split-M TN GEMM / column-sum kernels (scripts/bench_gemm.py)
         h = self.act(ops.linear_or_hip(x, self.fc1, None, Attention.hip_linear, hip_dx=False, hip_fwd=False))
-        return ops.linear_or_hip(h, self.fc2, resid, Attention.hip_linear, hip_dx=False)
+        return ops.linear_or_hip(h, self.fc2, resid, Attention.hip_linear, hip_dx=False, hip_fwd=Mlp.fc2_hip_fwd)
+
+    fc2_hip_fwd = os.environ.get("ACR_FC2_HIP", "1") != "0"     # A/B: fc2 forward on the hand-written GEMM (fused residual)
 
 
 class Attention(nn.Module):

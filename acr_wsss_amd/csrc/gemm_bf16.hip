@@ -656,20 +656,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #define WB_HALF (WB_ROWS * 128)            // elements of one [32 m][128 cols] half tile
 #define WB_STAGE (4 * WB_HALF)             // [dY half0 | dY half1 | X half0 | X half1] = 32 KiB
 
-__device__ __forceinline__ void wb_stage_half(bf16_t* ldsbuf, const bf16_t* g, int64_t ld, int m0, int M, int col0,
-                                              int wave, int lane) {
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    typedef const __attribute__((address_space(1))) void* glb_vp;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rbase = (wave * 2 + i) * 4;                // 4 rows (1 KiB) per DMA instruction, 8 instructions = 32 rows
-        const int row = rbase + (lane >> 4);
-        const int lc = (lane & 15) ^ ((row & 3) << 2);
-        const bf16_t* src = g + (int64_t)min(m0 + row, M - 1) * ld + col0 + lc * 8;
-        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(ldsbuf + rbase * 128), 16, 0, 0);
-    }
-}
-
 // Ring of FOUR 32-row stages (32 KiB each) filled three stages ahead, 8 DMA instructions per stage and thread, spread
 // one per 4 MFMAs.  Three findings shaped this kernel (fc1's dW, 25120 x 3072 x 768, same launch geometry):
 //  * the compiler puts s_waitcnt vmcnt(0) in front of ds_read_b64_tr_b16 *builtins* that follow an LDS-DMA in the same

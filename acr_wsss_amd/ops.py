@@ -225,7 +225,7 @@ class LinearBf16Fn(Function):
         else:                                               # library GEMM forward, hand-written backward pieces
             y = torch.nn.functional.linear(x2, weight, bias)
             if r2 is not None:
-                y = y + r2
+                y.add_(r2)
         ctx.save_for_backward(x2, weight)
         ctx.has_bias, ctx.has_resid = bias is not None, resid is not None
         return y.reshape(*shp[:-1], weight.shape[0])

@@ -163,3 +163,26 @@ def test_infer_list_sharding():
     for r in range(world):
         seen += list(range(r, n, world))
     assert sorted(seen) == list(range(n))
+
+
+def test_tuning_helpers_are_inert_without_a_gpu(tmp_path, monkeypatch):
+    """tuning.py: the shipped hipBLASLt selections are only *looked up* (never tuned) and need a GPU; the MIOpen user db
+    is copied to a private directory and never overrides a path the user already set."""
+    import os
+    from acr_wsss_amd import tuning
+    assert os.path.exists(tuning.TUNED_FILE) and os.path.isdir(tuning.MIOPEN_DB_DIR)
+    if not torch.cuda.is_available():
+        assert tuning.enable_tuned_gemms() is False
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", str(tmp_path))
+    assert tuning.use_shipped_miopen_db() is None and os.environ["MIOPEN_USER_DB_PATH"] == str(tmp_path)
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    import tempfile
+    tempfile.tempdir = None
+    dst = tuning.use_shipped_miopen_db()
+    try:
+        assert dst is not None and dst.startswith(str(tmp_path)) and os.environ["MIOPEN_USER_DB_PATH"] == dst
+        assert sorted(os.listdir(dst)) == sorted(os.listdir(tuning.MIOPEN_DB_DIR))
+    finally:
+        os.environ.pop("MIOPEN_USER_DB_PATH", None)
+        tempfile.tempdir = None
