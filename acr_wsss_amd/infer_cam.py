@@ -18,7 +18,8 @@ import torch.nn.functional as F
 from . import ops
 
 
-def infer_cam_image(model, img, label, out_hw, start_layer=10, func="grad", aff=True, scales=(1,), truncate=True):
+def infer_cam_image(model, img, label, out_hw, start_layer=10, func="grad", aff=True, scales=(1,), truncate=True,
+                    batch_flips=True):
     """CAMs of one image.  img (1,3,h,w) normalised fp32 on the GPU; label (1,C) multi-hot; out_hw = (W,H) =
     (image height, image width) as infer_cam.py:138 names them.  Returns (cam_dict, patch_cam_dict):
     {class index: float32 (W,H) numpy array}, min-max normalised over the summed passes (:201-215)."""
@@ -36,30 +37,36 @@ def infer_cam_image(model, img, label, out_hw, start_layer=10, func="grad", aff=
     model.truncate_at = start_layer if truncate else None
     try:
         for scale in scales:
-            for hflip in (1, 2):
-                inp = F.interpolate(img, size=(int(h * scale), int(w * scale)), mode="bilinear", align_corners=False)
-                flipped = hflip % 2 == 1
-                if flipped:
-                    inp = inp.flip(-1)
-                ph, pw = int((h * scale) // 16), int((w * scale) // 16)
+            base = F.interpolate(img, size=(int(h * scale), int(w * scale)), mode="bilinear", align_corners=False)
+            ph, pw = int((h * scale) // 16), int((w * scale) // 16)
+            # the two passes of a scale (h-flipped first, then plain: infer_cam.py:147-153) are independent samples: run
+            # them as ONE batch of 2 -- every per-sample operator (GroupNorm, LayerNorm, attention) is batch-invariant --
+            # and back-propagate both class logits at once; at batch 1 the step is launch-bound, not GPU-bound
+            passes = ((True, False),) if batch_flips else ((True,), (False,))
+            for flips in passes:
+                inp = torch.cat([base.flip(-1) if f else base for f in flips], dim=0)
                 with torch.enable_grad():
                     cls_pred, _, attn, patch_cam = model.forward_cam(inp)
-                    # patch-token CAM: (1,N,C) -> (C,ph,pw) -> bilinear(align_corners=False) * label, un-flip, sum
-                    ops.bilinear_resize(patch_cam[0].detach().float().reshape(ph, pw, C), (W, H), False,
-                                        chan_mul=label[0], hflip=flipped, out=patch_acc, channels_last=True)
-                    rows = []
+                    for i, flipped in enumerate(flips):
+                        # patch-token CAM: (1,N,C) -> (C,ph,pw) -> bilinear(align_corners=False) * label, un-flip, sum
+                        ops.bilinear_resize(patch_cam[i].detach().float().reshape(ph, pw, C), (W, H), False,
+                                            chan_mul=label[0], hflip=flipped, out=patch_acc, channels_last=True)
+                    rows = [[] for _ in flips]
                     for c in classes:
+                        tgt = cls_pred[:, c].sum()                  # samples are independent: one backward serves both
                         if truncate:
-                            torch.autograd.grad(cls_pred[0, c], vit.trunc_input, retain_graph=True)
+                            torch.autograd.grad(tgt, vit.trunc_input, retain_graph=True)
                         else:
                             model.zero_grad()
-                            cls_pred[0, c].backward(retain_graph=True)
-                        cam, _, _ = model.getam(0, start_layer=start_layer, func=func)
-                        rows.append(cam)
-                cams = torch.cat(rows, dim=0).contiguous()                       # (n_cls, N)
-                if aff:
-                    cams = ops.aff_refine(attn[0].detach().contiguous(), cams)    # patch_aff @ cam (:164-165,183-184)
-                ops.bilinear_resize(cams.reshape(len(classes), ph, pw), (W, H), True, hflip=flipped, out=cam_acc)
+                            tgt.backward(retain_graph=True)
+                        for i in range(len(flips)):
+                            cam, _, _ = model.getam(i, start_layer=start_layer, func=func)
+                            rows[i].append(cam)
+                for i, flipped in enumerate(flips):
+                    cams = torch.cat(rows[i], dim=0).contiguous()                    # (n_cls, N)
+                    if aff:
+                        cams = ops.aff_refine(attn[i].detach().contiguous(), cams)    # patch_aff @ cam (:164-165,183-184)
+                    ops.bilinear_resize(cams.reshape(len(classes), ph, pw), (W, H), True, hflip=flipped, out=cam_acc)
     finally:
         model.truncate_at = old_trunc
     cmin, cmax = cam_acc.amin((1, 2), keepdim=True), cam_acc.amax((1, 2), keepdim=True)

@@ -7,8 +7,10 @@ from acr_wsss_amd.infer_cam import infer_cam_image
 dev = "cuda:0"
 torch.manual_seed(0)
 m = ACR(20, "vitb_hybrid", use_pretrain=False).to(dev).eval()
+dt = torch.bfloat16 if len(sys.argv) > 1 and sys.argv[1] == "bf16" else torch.float32
+m = m.to(dt)
 g = torch.Generator().manual_seed(0)
-img = torch.randn(1, 3, 384, 384, generator=g).to(dev)
+img = torch.randn(1, 3, 384, 384, generator=g).to(dev).to(dt)
 lab = torch.zeros(1, 20); lab[0, 3] = 1; lab[0, 11] = 1
 for scales in ((1,), (0.5, 1.0, 1.5, 2.0)):
     for _ in range(2):
