@@ -23,7 +23,9 @@ def _recipe_model(dev):
 
 
 def run_smoke():
-    from recipe import make_inputs  # noqa: F401  (path set by _recipe_model)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)                                # `oracle` lives at the repo root
     from .train import acr_loss
     from .infer_cam import infer_cam_image
     from oracle import acr_oracle as O
