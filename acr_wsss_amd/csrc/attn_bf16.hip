@@ -579,6 +579,7 @@ __global__ __launch_bounds__(128, 2) void attn_dkdv_bf16_kernel(AttnGeomB g, con
     const float* drow = delta + ((int64_t)b * g.H + h) * g.T;
     const float* gbase = HAS_G ? gm + (int64_t)b * gm_sb + min(key, g.T - 1) : nullptr;
     const int gst = (int)gm_st;
+    const unsigned gloff = 4u * (unsigned)(min(key, g.T - 1) + 4 * hh * gst);  // lane part of a G address (bytes, 32 bit)
     TileRegs<128> qr, dr;
     float lnext = 0.f, dnext = 0.f;
     tile_gload<128>(qr, q + base, g.st, 0, g.T, tid);
@@ -609,10 +610,19 @@ __global__ __launch_bounds__(128, 2) void attn_dkdv_bf16_kernel(AttnGeomB g, con
             }
             float gv[16];
             if (HAS_G) {
+                if (EDGE) {
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int qq = q0 + 32 * qb + acr_krow(reg, hh);
-                    gv[reg] = gbase[(EDGE ? min(qq, g.T - 1) : qq) * gst];
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int qq = q0 + 32 * qb + acr_krow(reg, hh);
+                        gv[reg] = gbase[min(qq, g.T - 1) * gst];
+                    }
+                } else {
+                    // uniform row base (SGPR pair) + one per-lane 32-bit offset: sixteen saddr-form loads without any
+                    // per-load 64-bit address arithmetic (the per-lane-pointer form cost ~3 VALU per load)
+                    const float* gu = gm + (int64_t)b * gm_sb + (int64_t)(q0 + 32 * qb) * gst;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        gv[reg] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gu + ((reg & 3) + 8 * (reg >> 2)) * gst) + gloff);
                 }
             }
             ACR_MEMBAR();
