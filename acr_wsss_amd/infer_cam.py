@@ -18,64 +18,86 @@ import torch.nn.functional as F
 from . import ops
 
 
-def infer_cam_image(model, img, label, out_hw, start_layer=10, func="grad", aff=True, scales=(1,), truncate=True,
-                    batch_flips=True):
-    """CAMs of one image.  img (1,3,h,w) normalised fp32 on the GPU; label (1,C) multi-hot; out_hw = (W,H) =
-    (image height, image width) as infer_cam.py:138 names them.  Returns (cam_dict, patch_cam_dict):
-    {class index: float32 (W,H) numpy array}, min-max normalised over the summed passes (:201-215)."""
-    W, H = out_hw
-    dev = img.device
-    C = label.shape[1]
-    label = label.to(dev).float()
-    classes = [c for c in range(C) if float(label[0, c]) > 1e-5]
-    b, _, h, w = img.shape
-    assert b == 1, "infer_cam processes one image per step (infer_cam.py:123 chunker(...,1))"
+def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", aff=True, scales=(1,), truncate=True,
+                     batch_flips=True):
+    """CAMs of a batch of same-sized network inputs.  imgs (B,3,h,w) normalised, on the GPU; labels (B,C) multi-hot;
+    out_hws: B pairs (W,H) = (image height, image width) as infer_cam.py:138 names them (each image keeps its own output
+    size).  Returns a list of B (cam_dict, patch_cam_dict): {class index: float32 (W,H) numpy array}, min-max
+    normalised over the summed passes (:201-215).
+
+    Samples never interact on this path (GroupNorm / LayerNorm / attention are per sample), so images -- and, with
+    ``batch_flips``, the flipped and the plain pass of a scale -- share one forward, and one backward per class rank
+    k serves the k-th positive class of every image: d(sum_i logit[i, c_i^k]) / d tokens is block-diagonal in i."""
+    dev = imgs.device
+    B, _, h, w = imgs.shape
+    C = labels.shape[1]
+    labels = labels.to(dev).float()
+    lab_cpu = labels.cpu()
+    classes = [[c for c in range(C) if float(lab_cpu[i, c]) > 1e-5] for i in range(B)]
+    kmax = max((len(c) for c in classes), default=0)
     vit = model.pretrained.model
-    cam_acc = torch.zeros((len(classes), W, H), dtype=torch.float32, device=dev)
-    patch_acc = torch.zeros((C, W, H), dtype=torch.float32, device=dev)
+    cam_acc = [torch.zeros((len(classes[i]), out_hws[i][0], out_hws[i][1]), dtype=torch.float32, device=dev) for i in range(B)]
+    patch_acc = [torch.zeros((C, out_hws[i][0], out_hws[i][1]), dtype=torch.float32, device=dev) for i in range(B)]
     old_trunc = model.truncate_at
     model.truncate_at = start_layer if truncate else None
     try:
         for scale in scales:
-            base = F.interpolate(img, size=(int(h * scale), int(w * scale)), mode="bilinear", align_corners=False)
+            base = F.interpolate(imgs, size=(int(h * scale), int(w * scale)), mode="bilinear", align_corners=False)
             ph, pw = int((h * scale) // 16), int((w * scale) // 16)
             # the two passes of a scale (h-flipped first, then plain: infer_cam.py:147-153) are independent samples: run
-            # them as ONE batch of 2 -- every per-sample operator (GroupNorm, LayerNorm, attention) is batch-invariant --
-            # and back-propagate both class logits at once; at batch 1 the step is launch-bound, not GPU-bound
+            # them as ONE batch -- at small batches the pass is launch-bound, not GPU-bound
             passes = ((True, False),) if batch_flips else ((True,), (False,))
             for flips in passes:
-                inp = torch.cat([base.flip(-1) if f else base for f in flips], dim=0)
+                inp = torch.cat([base.flip(-1) if f else base for f in flips], dim=0)       # sample index = fi * B + i
                 with torch.enable_grad():
                     cls_pred, _, attn, patch_cam = model.forward_cam(inp)
-                    for i, flipped in enumerate(flips):
-                        # patch-token CAM: (1,N,C) -> (C,ph,pw) -> bilinear(align_corners=False) * label, un-flip, sum
-                        ops.bilinear_resize(patch_cam[i].detach().float().reshape(ph, pw, C), (W, H), False,
-                                            chan_mul=label[0], hflip=flipped, out=patch_acc, channels_last=True)
-                    rows = [[] for _ in flips]
-                    for c in classes:
-                        tgt = cls_pred[:, c].sum()                  # samples are independent: one backward serves both
+                    for fi, flipped in enumerate(flips):
+                        for i in range(B):
+                            # patch-token CAM: (1,N,C) -> (C,ph,pw) -> bilinear(align_corners=False) * label, un-flip, sum
+                            ops.bilinear_resize(patch_cam[fi * B + i].detach().float().reshape(ph, pw, C), out_hws[i], False,
+                                                chan_mul=labels[i], hflip=flipped, out=patch_acc[i], channels_last=True)
+                    rows = [[[] for _ in range(B)] for _ in flips]
+                    for k in range(kmax):
+                        live = [i for i in range(B) if k < len(classes[i])]
+                        tgt = sum(cls_pred[fi * B + i, classes[i][k]] for fi in range(len(flips)) for i in live)
                         if truncate:
                             torch.autograd.grad(tgt, vit.trunc_input, retain_graph=True)
                         else:
                             model.zero_grad()
                             tgt.backward(retain_graph=True)
-                        for i in range(len(flips)):
-                            cam, _, _ = model.getam(i, start_layer=start_layer, func=func)
-                            rows[i].append(cam)
-                for i, flipped in enumerate(flips):
-                    cams = torch.cat(rows[i], dim=0).contiguous()                    # (n_cls, N)
-                    if aff:
-                        cams = ops.aff_refine(attn[i].detach().contiguous(), cams)    # patch_aff @ cam (:164-165,183-184)
-                    ops.bilinear_resize(cams.reshape(len(classes), ph, pw), (W, H), True, hflip=flipped, out=cam_acc)
+                        for fi in range(len(flips)):
+                            for i in live:
+                                cam, _, _ = model.getam(fi * B + i, start_layer=start_layer, func=func)
+                                rows[fi][i].append(cam)
+                for fi, flipped in enumerate(flips):
+                    for i in range(B):
+                        if not classes[i]:
+                            continue
+                        cams = torch.cat(rows[fi][i], dim=0).contiguous()                # (n_cls, N)
+                        if aff:
+                            cams = ops.aff_refine(attn[fi * B + i].detach().contiguous(), cams)   # patch_aff @ cam (:164-165,183-184)
+                        ops.bilinear_resize(cams.reshape(len(classes[i]), ph, pw), out_hws[i], True, hflip=flipped,
+                                            out=cam_acc[i])
     finally:
         model.truncate_at = old_trunc
-    cmin, cmax = cam_acc.amin((1, 2), keepdim=True), cam_acc.amax((1, 2), keepdim=True)
-    norm_cam = ((cam_acc - cmin) / (cmax - cmin + 1e-6)).cpu().numpy()
-    pmin, pmax = patch_acc.amin((1, 2), keepdim=True), patch_acc.amax((1, 2), keepdim=True)
-    patch_norm = ((patch_acc - pmin) / (pmax - pmin + 1e-5)).cpu().numpy()
-    cam_dict = {c: norm_cam[i] for i, c in enumerate(classes)}
-    patch_dict = {c: patch_norm[c] for c in classes}
-    return cam_dict, patch_dict
+    out = []
+    for i in range(B):
+        ca, pa = cam_acc[i], patch_acc[i]
+        cmin, cmax = ca.amin((1, 2), keepdim=True), ca.amax((1, 2), keepdim=True)
+        norm_cam = ((ca - cmin) / (cmax - cmin + 1e-6)).cpu().numpy()
+        pmin, pmax = pa.amin((1, 2), keepdim=True), pa.amax((1, 2), keepdim=True)
+        patch_norm = ((pa - pmin) / (pmax - pmin + 1e-5)).cpu().numpy()
+        out.append(({c: norm_cam[j] for j, c in enumerate(classes[i])}, {c: patch_norm[c] for c in classes[i]}))
+    return out
+
+
+def infer_cam_image(model, img, label, out_hw, start_layer=10, func="grad", aff=True, scales=(1,), truncate=True,
+                    batch_flips=True):
+    """CAMs of one image (the unit of infer_cam.py:123 ``chunker(..., 1)``): img (1,3,h,w), label (1,C), out_hw = (W,H).
+    Returns (cam_dict, patch_cam_dict); see infer_cam_images."""
+    assert img.shape[0] == 1, "one image; use infer_cam_images for a batch"
+    return infer_cam_images(model, img, label, [out_hw], start_layer=start_layer, func=func, aff=aff, scales=scales,
+                            truncate=truncate, batch_flips=batch_flips)[0]
 
 
 def seeds_from_cam_dict(cam_dict, threshold, num_cls=21):
@@ -88,18 +110,29 @@ def seeds_from_cam_dict(cam_dict, threshold, num_cls=21):
     return np.argmax(tensor, axis=0).astype(np.uint8)
 
 
-def infer_cam_list(model, items, out_cam=None, rank=0, world=1, **kw):
+def infer_cam_list(model, items, out_cam=None, rank=0, world=1, batch_size=1, **kw):
     """Shard ``items`` -- an indexable of (name, img (1,3,h,w), label (1,C), (W,H)) -- over ranks and write
     ``<out_cam>/<name>.npy`` in the reference's wire format: a pickled {class: float32 (W,H)} dict
-    (infer_cam.py:227-228, read back by evaluation.py:23-25).  Returns {name: cam_dict} of this rank."""
+    (infer_cam.py:227-228, read back by evaluation.py:23-25).  Returns {name: cam_dict} of this rank.
+    ``batch_size`` > 1 groups consecutive images of this rank whose network inputs have the same size."""
     dev = next(model.parameters()).device
     model.eval()
     results = {}
-    for i in range(rank, len(items), world):
-        name, img, label, out_hw = items[i]
-        cam_dict, _ = infer_cam_image(model, img.to(dev), label, out_hw, **kw)
-        if out_cam is not None:
-            os.makedirs(out_cam, exist_ok=True)
-            np.save(os.path.join(out_cam, name + ".npy"), cam_dict)
-        results[name] = cam_dict
+    mine = list(range(rank, len(items), world))
+    pos = 0
+    while pos < len(mine):
+        grp = [mine[pos]]
+        shape = items[mine[pos]][1].shape
+        while len(grp) < batch_size and pos + len(grp) < len(mine) and items[mine[pos + len(grp)]][1].shape == shape:
+            grp.append(mine[pos + len(grp)])
+        pos += len(grp)
+        imgs = torch.cat([items[i][1] for i in grp], dim=0).to(dev)
+        labels = torch.cat([items[i][2] for i in grp], dim=0)
+        outs = infer_cam_images(model, imgs, labels, [items[i][3] for i in grp], **kw)
+        for i, (cam_dict, _) in zip(grp, outs):
+            name = items[i][0]
+            if out_cam is not None:
+                os.makedirs(out_cam, exist_ok=True)
+                np.save(os.path.join(out_cam, name + ".npy"), cam_dict)
+            results[name] = cam_dict
     return results

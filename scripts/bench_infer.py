@@ -20,3 +20,12 @@ for scales in ((1,), (0.5, 1.0, 1.5, 2.0)):
         cam, _ = infer_cam_image(m, img, lab, (375, 500), scales=scales)
     torch.cuda.synchronize(); dt = (time.time() - t0) / n
     print("scales %-22s %.1f ms/image  %.2f img/s  (cam %s, peak mem %.1f GB)" % (scales, dt * 1e3, 1 / dt, cam[3].shape, torch.cuda.max_memory_allocated() / 2**30))
+
+from acr_wsss_amd.infer_cam import infer_cam_images
+for B in (4, 8):
+    imgs = img.repeat(B, 1, 1, 1); labs = lab.repeat(B, 1); sizes = [(375, 500)] * B
+    for _ in range(2): infer_cam_images(m, imgs, labs, sizes)
+    torch.cuda.synchronize(); t0 = time.time(); n = 3
+    for _ in range(n): infer_cam_images(m, imgs, labs, sizes)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / n
+    print("batch %d, scale 1: %.1f ms/batch  %.1f img/s  (peak mem %.1f GB)" % (B, dt * 1e3, B / dt, torch.cuda.max_memory_allocated() / 2**30))
