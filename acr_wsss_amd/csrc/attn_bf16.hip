@@ -45,11 +45,22 @@ struct TileRegs { bf16x8 v[512 / NT]; };
 // -> p = 0, or the output row is simply not stored), so no zero-fill is needed and garbage stays finite.
 template <int NT, bool EDGE = true>
 __device__ __forceinline__ void tile_gload(TileRegs<NT>& t, const bf16_t* g, int64_t st, int row0, int Tn, int tid) {
+    if (!EDGE) {
+        // uniform base (row0 and the per-instruction row step are wave-uniform -> SGPR pair) + ONE 32-bit per-thread byte
+        // offset: saddr-form loads.  The per-slot 64-bit form cost 7 VALU instructions of address arithmetic per load,
+        // ~56 of a sweep step's ~300.
+        const unsigned off0 = (unsigned)(((int64_t)(tid >> 3) * st + (tid & 7) * 8) * 2);
+        const char* ub = reinterpret_cast<const char*>(g + (int64_t)row0 * st);
+#pragma unroll
+        for (int i = 0; i < 512 / NT; ++i)
+            t.v[i] = *reinterpret_cast<const bf16x8*>(ub + (int64_t)(i * (NT >> 3)) * st * 2 + off0);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 512 / NT; ++i) {
         const int slot = tid + i * NT;
         const int row = row0 + (slot >> 3);
-        const int rc = EDGE ? min(row, Tn - 1) : row;
+        const int rc = min(row, Tn - 1);
         t.v[i] = *reinterpret_cast<const bf16x8*>(g + (int64_t)rc * st + (slot & 7) * 8);
     }
 }
@@ -488,7 +499,8 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
             f32x16 s = {0}, dp = {0};
             mma_rowop_bf(s, ktc, qreg, lane);               // S^T raw [key = krow][query = r]
             mma_rowop_bf(dp, vtc, doreg, lane);             // dP^T
-            f32x16 ds, pv;
+            // in place: s becomes dS and dp becomes P.  (Filling fresh f32x16 values element by element makes hipcc
+            // initialise each 16-register tuple with 16 v_mov first: 64 of a step's ~250 VALU instructions.)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 float p = fast_exp2(fmaf(s[reg], c, -l2));
@@ -503,15 +515,15 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
                 if (HAS_G) {
                     t = fmaf(gv, invH, t);
                     rho = fmaf(p, gv, rho);
-                    pv[reg] = p;
+                    dp[reg] = p;
                 }
-                ds[reg] = p * (t - dl);
+                s[reg] = p * (t - dl);
             }
-            mma_accop_a_bf(dq0, ds, ktc, 0, lane);          // dQ[query = krow][d = 32*blk + r]
-            mma_accop_a_bf(dq1, ds, ktc, 1, lane);
+            mma_accop_a_bf(dq0, s, ktc, 0, lane);           // dQ[query = krow][d = 32*blk + r]
+            mma_accop_a_bf(dq1, s, ktc, 1, lane);
             if (HAS_G) {
-                mma_accop_a_bf(y0, pv, ktc, 0, lane);       // Y[query = krow][d]
-                mma_accop_a_bf(y1, pv, ktc, 1, lane);
+                mma_accop_a_bf(y0, dp, ktc, 0, lane);       // Y[query = krow][d]
+                mma_accop_a_bf(y1, dp, ktc, 1, lane);
             }
         }
         ACR_MEMBAR();
@@ -631,19 +643,19 @@ __global__ __launch_bounds__(128, 2) void attn_dkdv_bf16_kernel(AttnGeomB g, con
             f32x16 s = {0}, dp = {0};
             mma_rowop_bf(s, qtc, kreg, lane);               // S raw [query = krow][key = r]
             mma_rowop_bf(dp, dtc, vreg, lane);              // dP
-            f32x16 p, ds;
+            // in place: s becomes P and dp becomes dS (see the dQ sweep: fresh element-wise vectors cost 16 v_mov each)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int kr = 32 * qb + acr_krow(reg, hh);
                 const float pv = fast_exp2(fmaf(s[reg], c, -l2s[cur][kr])) * kmask;   // lse = +inf beyond T -> 0
-                p[reg] = pv;
+                s[reg] = pv;
                 const float t = HAS_G ? fmaf(gv[reg], invH, dp[reg]) : dp[reg];
-                ds[reg] = pv * (t - dls[cur][kr]);
+                dp[reg] = pv * (t - dls[cur][kr]);
             }
-            mma_accop_a_bf(dv0, p, dtc, 0, lane);           // dV[key = krow][d = 32*blk + r]
-            mma_accop_a_bf(dv1, p, dtc, 1, lane);
-            mma_accop_a_bf(dk0, ds, qtc, 0, lane);
-            mma_accop_a_bf(dk1, ds, qtc, 1, lane);
+            mma_accop_a_bf(dv0, s, dtc, 0, lane);           // dV[key = krow][d = 32*blk + r]
+            mma_accop_a_bf(dv1, s, dtc, 1, lane);
+            mma_accop_a_bf(dk0, dp, qtc, 0, lane);
+            mma_accop_a_bf(dk1, dp, qtc, 1, lane);
             if (qb == 0) {                                   // Q tile of the next step can go to LDS already
                 ACR_MEMBAR();
                 tile_lstore<128>(qtile[cur ^ 1], qr, q0 + 64, g.T, tid);
