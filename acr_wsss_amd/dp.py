@@ -5,8 +5,9 @@ The reference wraps the model in DistributedDataParallel (train_acr.py:99) but c
 trains an independent replica.  This module implements the intended semantics: gradients are
 averaged over ranks every step.
 
-MI355X-first choices: gradients live in a few large flat buckets (``.grad`` of every parameter is a view into
-one), so the all-reduce runs in place with no gather/scatter copies; buckets are large (64 MB default: xGMI is
+MI355X-first choices: gradients live in a few large flat buckets (after a bucket's last gradient has arrived, all of
+them are moved in with one multi-tensor launch and ``.grad`` of every parameter becomes a view into the bucket), so the
+all-reduce runs in place and the optimizer reads the reduced values without another copy; buckets are large (64 MB default: xGMI is
 point-to-point, ring all-reduce is per-link bound, so few big collectives beat many small ones) and each is
 launched from the autograd thread the moment its last gradient lands, overlapping with the rest of backward
 (the ResNet stem's gradients arrive last and form the only exposed bucket).  Works unchanged on ``gloo`` (CPU
@@ -57,15 +58,23 @@ class GradSync:
         self._avg = backend == "nccl"                     # RCCL has a native AVG; gloo does not
 
     def prepare(self):
-        """Call after zero_grad and before backward: zero the buckets and point every .grad into them."""
+        """Call after zero_grad and before backward.  Gradients are left to autograd (``.grad = None``: the engine then
+        *moves* each gradient into ``.grad`` instead of launching an add kernel per parameter); when the last gradient of
+        a bucket has arrived they are copied into the bucket with ONE multi-tensor launch and ``.grad`` is re-pointed at
+        the bucket views.  Slots of parameters that never receive a gradient stay zero (zeroed once, at construction)."""
         for b in self.buckets:
-            b.flat.zero_()
             b.pending, b.work = len(b.params), None
-            for p, v in zip(b.params, b.views):
-                p.grad = v
+            for p in b.params:
+                p.grad = None
         self._armed = True
 
     def _launch(self, b):
+        live = [(v, p.grad) for p, v in zip(b.params, b.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        if live:
+            torch._foreach_copy_([v for v, _ in live], [g for _, g in live])
+        for p, v in zip(b.params, b.views):
+            if p.grad is not None:
+                p.grad = v
         if self.world > 1:
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
@@ -76,10 +85,6 @@ class GradSync:
         if not self._armed:
             return
         b = self._of[p]
-        i = next(j for j, q in enumerate(b.params) if q is p)
-        if p.grad is not b.views[i] and p.grad.data_ptr() != b.views[i].data_ptr():
-            b.views[i].copy_(p.grad)                       # autograd replaced .grad instead of accumulating in place
-            p.grad = b.views[i]
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)

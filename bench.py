@@ -242,7 +242,7 @@ def main():
     else:
         opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=100000)
         amp = torch.bfloat16 if args.dtype == "bf16" else None
-    sync = GradSync(model.parameters()) if world > 1 else None
+    sync = GradSync(model.parameters()) if (world > 1 or os.environ.get("ACR_FORCE_GRADSYNC") == "1") else None
 
     def step():
         return train_step(model, opt, img, label, args.alpha, grad_sync=sync, amp_dtype=amp)
