@@ -433,6 +433,173 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_big_kernel(const bf16_t* __r
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 320x256 tile, EIGHT waves (2 x 4, each 160x64: 10 accumulators = 160 registers, two waves per SIMD).  Made for the
+// N = 768 GEMMs of the block (proj / fc2 forward, qkv / proj input gradients) at M = 25 120 tokens: 79 x 3 = 237
+// workgroups = ONE round on 93 % of the CUs, where 128x128 tiles need 2.3 rounds of two-per-CU slots and 256x256 tiles
+// 1.16 rounds.  Same ring recipe as the 256x256 kernel (four 32-deep stages, counted vmcnt, asm fragment reads one
+// slice ahead, DMA spread over the MFMAs, barrier between the slices); two waves per SIMD additionally overlap each
+// other's waits.  A stage is 36 DMA instructions (20 A + 16 B row groups); every wave issues 5, the last four slots
+// re-load B groups 12..15 (same bytes to the same LDS addresses) so that the counted waits are uniform.
+// ---------------------------------------------------------------------------------------------------------------
+#define GW_BM 320
+#define GW_STAGE ((GW_BM + GB_BN) * GB_BK)         // elements per stage = 36 KiB
+
+template <bool BIAS, bool RESID>
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_wide_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                   const bf16_t* __restrict__ B, int64_t ldb,
+                                                                   const bf16_t* __restrict__ bias,
+                                                                   const bf16_t* __restrict__ R, int64_t ldr,
+                                                                   bf16_t* __restrict__ Y, int64_t ldy, int M, int N, int K) {
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[4 * GW_STAGE];
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    const int ntn = (N + GB_BN - 1) / GB_BN;
+    const int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = id / ntn, tn = id % ntn;
+    const int m0 = tm * GW_BM, n0 = tn * GB_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, hh = lane >> 5;
+    const int nk = K / GB_BK;
+    // DMA slot j = wave * 5 + q: j < 20 -> A row group j; 20 <= j < 36 -> B row group j - 20; j >= 36 -> B group j - 24 again
+    uint32_t doff[5];
+    int dgrp[5];                                            // LDS row group inside the stage (A groups 0..19, B groups 20..35)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        int j = wave * 5 + q;
+        if (j >= 36) j -= 4;
+        dgrp[q] = j;
+        const bool isa = j < 20;
+        const int row = (isa ? j : j - 20) * 16 + (lane >> 2);
+        const int lc = (lane & 3) ^ ((row >> 2) & 3);
+        doff[q] = isa ? (uint32_t)(((int64_t)min(m0 + row, M - 1) * lda + lc * 8) * 2)
+                      : (uint32_t)(((int64_t)min(n0 + row, N - 1) * ldb + lc * 8) * 2);
+    }
+    auto dma = [&](int kt, int q) {
+        const char* base = (dgrp[q] < 20) ? reinterpret_cast<const char*>(A + kt * GB_BK) : reinterpret_cast<const char*>(B + kt * GB_BK);
+        bf16_t* dst = smem + (kt & 3) * GW_STAGE + dgrp[q] * 16 * GB_BK;         // A tile then B tile: group g at g * 16 rows
+        __builtin_amdgcn_global_load_lds((glb_vp)(base + doff[q]), (lds_vp)dst, 16, 0, 0);
+    };
+    f32x16 acc[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bf16x8 a0[5], b0[2], a1[5], b1[2];
+    const int ra = wm * 160 + r, rb = wn * 64 + r;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)smem;
+    const uint32_t swa = (ra >> 2) & 3, swb = (rb >> 2) & 3;
+    const uint32_t oa0 = lds0 + ra * 64 + ((hh ^ swa) << 4), oa1 = lds0 + ra * 64 + (((2 + hh) ^ swa) << 4);
+    const uint32_t ob0 = lds0 + GW_BM * GB_BK * 2 + rb * 64 + ((hh ^ swb) << 4);
+    const uint32_t ob1 = lds0 + GW_BM * GB_BK * 2 + rb * 64 + (((2 + hh) ^ swb) << 4);
+#define GW_RD1(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
+#define GW_READ7(xa, xb, aa, ab)                                                                                     \
+    { GW_RD1(xa[0], aa, 0); GW_RD1(xa[1], aa, 2048); GW_RD1(xa[2], aa, 4096); GW_RD1(xa[3], aa, 6144);                \
+      GW_RD1(xa[4], aa, 8192); GW_RD1(xb[0], ab, 0); GW_RD1(xb[1], ab, 2048); }
+#define GW_WAIT(cnt, x, y)                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                       \
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(y[0]), "+v"(y[1]))
+#define GW_MFMA10(x, y)                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                 \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i_], y[j_], acc[i_][j_], 0, 0, 0)
+    auto body = [&](int kt, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const uint32_t so = (uint32_t)(kt & 3) * (GW_STAGE * 2), so2 = (uint32_t)((kt + 1) & 3) * (GW_STAGE * 2);
+        GW_READ7(a1, b1, oa1 + so, ob1 + so);               // slice 1 of stage kt
+        GW_WAIT(7, a0, b0);
+        if (MODE == 0) { dma(kt + 3, 0); dma(kt + 3, 1); dma(kt + 3, 2); }
+        GW_MFMA10(a0, b0);
+        if (MODE == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        GW_WAIT(0, a1, b1);                                 // this wave holds every fragment of stage kt
+        if (MODE <= 1) {
+            // stage kt+1 must have landed; stage kt+2 (5) and the first three DMAs of stage kt+3 may stay in flight
+            if (MODE == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            GW_READ7(a0, b0, oa0 + so2, ob0 + so2);         // slice 0 of stage kt+1
+        }
+        if (MODE == 0) { dma(kt + 3, 3); dma(kt + 3, 4); }
+        GW_MFMA10(a1, b1);
+        if (MODE == 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 5; ++q) dma(0, q);
+    if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) dma(1, q);
+    }
+    if (nk > 2) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) dma(2, q);
+    }
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    GW_READ7(a0, b0, oa0, ob0);
+    {
+        int kt = 0;
+        for (; kt + 3 < nk; ++kt) body(kt, std::integral_constant<int, 0>{});
+        for (; kt + 1 < nk; ++kt) body(kt, std::integral_constant<int, 1>{});
+        body(kt, std::integral_constant<int, 2>{});
+    }
+#undef GW_RD1
+#undef GW_READ7
+#undef GW_WAIT
+#undef GW_MFMA10
+    __syncthreads();                                        // all fragment reads done before LDS is reused below
+    // Epilogue through LDS, 32 rows x 64 columns at a time (wave-private 8 KiB), 16-byte stores
+    float* stile = reinterpret_cast<float*>(smem) + wave * 2048;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) stile[acr_krow(reg, hh) * 64 + nt * 32 + r] = acc[t][nt][reg];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i;
+            const int lrow = idx >> 3, c8 = (idx & 7) * 8;
+            const int row = m0 + wm * 160 + t * 32 + lrow, col = n0 + wn * 64 + c8;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(stile + lrow * 64 + c8 + 4);
+            if (row < M && col < N) {
+                float y[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (BIAS) {
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bias + col);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] += (float)bv[e];
+                }
+                if (RESID) {
+                    const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (int64_t)row * ldr + col);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] += (float)rv[e];
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)y[e];
+                *reinterpret_cast<bf16x8*>(Y + (int64_t)row * ldy + col) = o;
+            }
+        }
+    }
+}
+
 // MT = 5 (320-row tiles, one round of the CUs for the N = 768 shapes) is not instantiated: its 160x128 wave tile needs
 // 320 accumulator registers, more than the 256 AGPRs, and hipcc spills ~450 registers instead of keeping the rest of the
 // accumulators in arch VGPRs (measured: 512 VGPR, 464 spills).  Fixing the quantisation of these shapes needs stream-K.
@@ -450,6 +617,13 @@ extern "C" int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_
     ACR_CHECK_ARG(tiles < (1ll << 31), "acr_linear_bf16: grid too large");
     const dim3 grid((unsigned)tiles);
     const int mt = gb_pick_mt(M, N);
+    // 320x256 tiles (8 waves) whenever they give the chip enough workgroups: at M = 25 120 tokens they take 36 / 86 / 105
+    // / 120 / 142 us on proj, qkv-dX, qkv, fc2, fc1 (820-1030 TF) against 43 / 112 / 126 / 156 / 189 us for the 128x128
+    // kernel; the N = 768 shapes fit ONE round of the CUs (79 x 3 = 237 workgroups).  Small problems keep 128x128 tiles.
+    const int64_t tilesw = (int64_t)((M + GW_BM - 1) / GW_BM) * ((N + GB_BN - 1) / GB_BN);
+    static const bool env_nowide = getenv("ACR_GEMM_NOWIDE") != nullptr;
+    const bool wide_ok = !env_nowide && tilesw >= 200;
+    const dim3 gridw((unsigned)tilesw);
     const dim3 grid3((unsigned)(((M + 64 * mt - 1) / (64 * mt)) * ((N + GB_BN - 1) / GB_BN)));
     hipStream_t st = (hipStream_t)stream;
     static const int env_variant = getenv("ACR_GEMM_VARIANT") ? atoi(getenv("ACR_GEMM_VARIANT")) : 2;   // 2: 128x128x64 2-stage, 3: 256x256x32 4-stage
@@ -461,6 +635,9 @@ extern "C" int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_
 #define ACR_GEMM_LAUNCH(BI, RE)                                                                                       \
     if (use_regstage)                                                                                                 \
         hipLaunchKernelGGL((gemm_nt_bf16_kernel<BI, RE>), grid, dim3(256), 0, st, (const bf16_t*)a, lda,               \
+                           (const bf16_t*)b, ldb, (const bf16_t*)bias, (const bf16_t*)resid, ldr, (bf16_t*)y, ldy, M, N, K); \
+    else if (env_variant == 4 || (env_variant == 2 && wide_ok))                                                       \
+        hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<BI, RE>), gridw, dim3(512), 0, st, (const bf16_t*)a, lda,         \
                            (const bf16_t*)b, ldb, (const bf16_t*)bias, (const bf16_t*)resid, ldr, (bf16_t*)y, ldy, M, N, K); \
     else if (env_variant == 3) {                                                                                      \
             hipLaunchKernelGGL((gemm_nt_bf16_big_kernel<BI, RE, 4>), grid3, dim3(256), 0, st, (const bf16_t*)a, lda,   \
