@@ -215,9 +215,14 @@ class Mlp(nn.Module):
         input gradients stay on hipBLASLt, which is faster on the short-K / wide-N shapes (scripts/bench_gemm.py)."""
         # fc1: forward and input gradient on hipBLASLt (faster on this short-K / wide-N shape), weight and bias gradient
         # on the hand-written split-M TN GEMM / column-sum kernels (scripts/bench_gemm.py)
-        h = self.act(ops.linear_or_hip(x, self.fc1, None, Attention.hip_linear, hip_dx=False, hip_fwd=False))
-        return ops.linear_or_hip(h, self.fc2, resid, Attention.hip_linear, hip_dx=False, hip_fwd=Mlp.fc2_hip_fwd)
+        if Mlp.fused and Attention.hip_linear and isinstance(self.act, nn.GELU) and ops.mlp_fusable(x, self.fc1, self.fc2):
+            return ops.mlp(x, self.fc1, self.fc2, resid)     # GELU / GELU' inside the GEMM epilogues
+        lib = Mlp.mlp_on_lib                                 # A/B: fc1 forward and the MLP input gradients on hipBLASLt
+        h = self.act(ops.linear_or_hip(x, self.fc1, None, Attention.hip_linear, hip_dx=not lib, hip_fwd=not lib))
+        return ops.linear_or_hip(h, self.fc2, resid, Attention.hip_linear, hip_dx=not lib, hip_fwd=Mlp.fc2_hip_fwd)
 
+    fused = os.environ.get("ACR_MLP_FUSED", "1") != "0"
+    mlp_on_lib = os.environ.get("ACR_MLP_LIB", "0") == "1"
     fc2_hip_fwd = os.environ.get("ACR_FC2_HIP", "1") != "0"     # A/B: fc2 forward on the hand-written GEMM (fused residual)
 
 

@@ -445,12 +445,33 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_big_kernel(const bf16_t* __r
 #define GW_BM 320
 #define GW_STAGE ((GW_BM + GB_BN) * GB_BK)         // elements per stage = 36 KiB
 
-template <bool BIAS, bool RESID>
+// EPI 0: y = acc (+bias) (+resid).  EPI 1 (fc1 forward, models/vision_transformer.py:160-161): Y = h = acc + bias and
+// AUX = GELU(h) (exact erf form, computed from the bf16-rounded h like the unfused pair of kernels).  EPI 2 (input
+// gradient of fc2 through the GELU): y = acc * GELU'(AUX) with AUX = the saved h.
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far inside bf16's 2^-9), sharing
+// exp(-x^2/2) with the density term of GELU': one exp, one rcp and five FMAs per element.  With libm's erff + expf the
+// epilogues cost 70-90 us per GEMM -- as much as the separate GELU kernels they replace.
+__device__ __forceinline__ void gw_phi(float x, float& cdf, float& e) {
+    const float ax = fabsf(x);
+    e = __expf(-0.5f * x * x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erf_abs = 1.f - p * t * e;                  // erf(|x| / sqrt 2)
+    cdf = 0.5f * (1.f + copysignf(erf_abs, x));
+}
+__device__ __forceinline__ float gw_gelu(float x) { float c, e; gw_phi(x, c, e); return x * c; }
+__device__ __forceinline__ float gw_dgelu(float x) { float c, e; gw_phi(x, c, e); return fmaf(x * e, 0.39894228040143267794f, c); }
+
+template <bool BIAS, bool RESID, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_wide_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                                    const bf16_t* __restrict__ B, int64_t ldb,
                                                                    const bf16_t* __restrict__ bias,
                                                                    const bf16_t* __restrict__ R, int64_t ldr,
-                                                                   bf16_t* __restrict__ Y, int64_t ldy, int M, int N, int K) {
+                                                                   bf16_t* __restrict__ Y, int64_t ldy, int M, int N, int K,
+                                                                   bf16_t* __restrict__ AUX = nullptr, int64_t ldaux = 0) {
     __shared__ __attribute__((aligned(1024))) bf16_t smem[4 * GW_STAGE];
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef const __attribute__((address_space(1))) void* glb_vp;
@@ -592,9 +613,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_wide_kernel(const bf16_t*
                     for (int e = 0; e < 8; ++e) y[e] += (float)rv[e];
                 }
                 bf16x8 o;
+                if (EPI == 2) {
+                    const bf16x8 hv = *reinterpret_cast<const bf16x8*>(AUX + (int64_t)row * ldaux + col);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] *= gw_dgelu((float)hv[e]);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)y[e];
                 *reinterpret_cast<bf16x8*>(Y + (int64_t)row * ldy + col) = o;
+                if (EPI == 1) {
+                    bf16x8 a8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a8[e] = (bf16_t)gw_gelu((float)o[e]);
+                    *reinterpret_cast<bf16x8*>(AUX + (int64_t)row * ldaux + col) = a8;
+                }
             }
         }
     }
@@ -651,6 +683,42 @@ extern "C" int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_
     else ACR_GEMM_LAUNCH(false, false);
 #undef ACR_GEMM_LAUNCH
     return acr_check_launch("acr_linear_bf16");
+}
+
+static int gw_check(const char* who, const void* a, int64_t lda, const void* b, int64_t ldb, int64_t ldy, int64_t ldaux, int M,
+                    int N, int K) {
+    ACR_CHECK_ARG(M > 0 && N > 0 && K >= 64 && (K % 64) == 0 && (N % 8) == 0, "%s: need K %% 64 == 0 and N %% 8 == 0 (M=%d N=%d K=%d)", who, M, N, K);
+    ACR_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldy % 8) == 0 && (ldaux % 8) == 0 && lda >= K && ldb >= K && ldy >= N && ldaux >= N,
+                  "%s: leading dimensions must cover the rows and be multiples of 8 elements", who);
+    ACR_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, "%s: operands must be 16-byte aligned", who);
+    ACR_CHECK_ARG((int64_t)((M + GW_BM - 1) / GW_BM) * ((N + GB_BN - 1) / GB_BN) < (1ll << 31), "%s: grid too large", who);
+    return ACR_OK;
+}
+
+extern "C" int acr_linear_gelu_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const void* bias, void* h,
+                                    void* act, int64_t ldy, int32_t M, int32_t N, int32_t K, void* stream) {
+    ACR_CHECK_ARG(a && b && bias && h && act, "acr_linear_gelu_bf16: null pointer");
+    int rc = gw_check("acr_linear_gelu_bf16", a, lda, b, ldb, ldy, ldy, M, N, K);
+    if (rc) return rc;
+    ACR_CHECK_ARG(((uintptr_t)h & 15) == 0 && ((uintptr_t)act & 15) == 0 && ((uintptr_t)bias & 15) == 0, "acr_linear_gelu_bf16: 16-byte alignment");
+    const dim3 grid((unsigned)(((M + GW_BM - 1) / GW_BM) * ((N + GB_BN - 1) / GB_BN)));
+    hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<true, false, 1>), grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, lda,
+                       (const bf16_t*)b, ldb, (const bf16_t*)bias, (const bf16_t*)nullptr, (int64_t)0, (bf16_t*)h, ldy, M, N, K,
+                       (bf16_t*)act, ldy);
+    return acr_check_launch("acr_linear_gelu_bf16");
+}
+
+extern "C" int acr_linear_dgelu_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const void* h, int64_t ldh,
+                                     void* y, int64_t ldy, int32_t M, int32_t N, int32_t K, void* stream) {
+    ACR_CHECK_ARG(a && b && h && y, "acr_linear_dgelu_bf16: null pointer");
+    int rc = gw_check("acr_linear_dgelu_bf16", a, lda, b, ldb, ldy, ldh, M, N, K);
+    if (rc) return rc;
+    ACR_CHECK_ARG(((uintptr_t)h & 15) == 0 && ((uintptr_t)y & 15) == 0, "acr_linear_dgelu_bf16: 16-byte alignment");
+    const dim3 grid((unsigned)(((M + GW_BM - 1) / GW_BM) * ((N + GB_BN - 1) / GB_BN)));
+    hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<false, false, 2>), grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, lda,
+                       (const bf16_t*)b, ldb, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (int64_t)0, (bf16_t*)y, ldy, M, N, K,
+                       (bf16_t*)const_cast<void*>(h), ldh);
+    return acr_check_launch("acr_linear_dgelu_bf16");
 }
 
 // ---------------------------------------------------------------------------------------------------------------

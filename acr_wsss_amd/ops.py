@@ -250,6 +250,60 @@ class LinearBf16Fn(Function):
         return dx, dw, db, (dy if ctx.has_resid else None), None, None, None
 
 
+def mlp_fusable(x, fc1, fc2):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and fc1.weight.dtype == torch.bfloat16
+            and fc1.bias is not None and fc2.bias is not None and fc1.weight.shape[1] % 64 == 0
+            and fc1.weight.shape[0] % 64 == 0 and fc2.weight.shape[0] % 64 == 0)
+
+
+class MlpFn(Function):
+    """y = fc2(GELU(fc1(x))) [+ resid] of a transformer block (models/vision_transformer.py:158-164) with the activation
+    inside the GEMM epilogues: fc1 writes h and GELU(h) in one pass, and the input gradient of fc2 comes out already
+    multiplied by GELU'(h).  Replaces the separate GELU forward / backward passes over the (tokens x 3072) activations."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, resid):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        M, K = x2.shape
+        Hd = w1.shape[0]
+        lib = L.load()
+        h = torch.empty((M, Hd), dtype=torch.bfloat16, device=x.device)
+        a = torch.empty((M, Hd), dtype=torch.bfloat16, device=x.device)
+        L.check(lib.acr_linear_gelu_bf16(L.ptr(x2), x2.stride(0), L.ptr(w1), w1.stride(0), L.ptr(b1), L.ptr(h), L.ptr(a), Hd,
+                                         M, Hd, K, L.stream_ptr()), "acr_linear_gelu_bf16")
+        r2 = resid.reshape(-1, w2.shape[0]) if resid is not None else None
+        y = linear_bf16(a, w2, b2, r2)
+        ctx.save_for_backward(x2, h, a, w1, w2)
+        ctx.has_resid = resid is not None
+        return y.reshape(*shp[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h, a, w1, w2 = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        M, Hd = h.shape
+        lib = L.load()
+        dw2 = wgrad_bf16(dy2, a)
+        db2 = colsum_bf16(dy2)
+        w2t = w2.t().contiguous()                             # (hidden, out): dA = dY W2
+        dh = torch.empty_like(h)
+        L.check(lib.acr_linear_dgelu_bf16(L.ptr(dy2), dy2.stride(0), L.ptr(w2t), w2t.stride(0), L.ptr(h), h.stride(0), L.ptr(dh),
+                                          dh.stride(0), M, Hd, dy2.shape[1], L.stream_ptr()), "acr_linear_dgelu_bf16")
+        dw1 = wgrad_bf16(dh, x2)
+        db1 = colsum_bf16(dh)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_bf16(dh, w1.t().contiguous()).reshape(*dy.shape[:-1], w1.shape[1])
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None)
+
+
+def mlp(x, fc1, fc2, resid=None):
+    return MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, resid)
+
+
 def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hip_fwd=True):
     """nn.Linear forward; bf16 CUDA tensors with K % 64 == 0 take the hand-written GEMM (resid fused).
     ``hip_dx`` = False leaves the input gradient on hipBLASLt (shapes where the library kernel is faster)."""

@@ -376,3 +376,31 @@ def test_maxpool_same_bf16(shape):
     y.backward(dy)
     yr.backward(dy)
     assert torch.allclose(x.grad.float(), xr.grad.float(), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("M,D,Hd", [(197 * 2, 192, 768), (785, 768, 3072), (320 * 3 + 17, 128, 256)])
+def test_fused_mlp_bf16(M, D, Hd):
+    """MlpFn (GELU and GELU' inside the GEMM epilogues) against an fp64 fc2(gelu(fc1(x))) + resid: output and all six
+    gradients; tile edges in both dimensions (M not a multiple of 320, hidden/out not multiples of 256)."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + D)
+    fc1 = torch.nn.Linear(D, Hd).to(dev).bfloat16()
+    fc2 = torch.nn.Linear(Hd, D).to(dev).bfloat16()
+    x = (torch.randn(2, M // 2 if M % 2 == 0 else M, D, generator=g)[:1 if M % 2 else 2]).to(dev).bfloat16()
+    x = x.reshape(1, -1, D).contiguous().requires_grad_(True)
+    r = torch.randn(x.shape, generator=g).to(dev).bfloat16().requires_grad_(True)
+    dy = torch.randn(x.shape, generator=g).to(dev).bfloat16()
+    assert ops.mlp_fusable(x, fc1, fc2)
+    y = ops.mlp(x, fc1, fc2, r)
+    (y.float() * dy.float()).sum().backward()
+    got = [y, x.grad, r.grad, fc1.weight.grad, fc1.bias.grad, fc2.weight.grad, fc2.bias.grad]
+    xd, rd = x.detach().double().requires_grad_(True), r.detach().double().requires_grad_(True)
+    p = [t.detach().double().requires_grad_(True) for t in (fc1.weight, fc1.bias, fc2.weight, fc2.bias)]
+    ref = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(xd, p[0], p[1])), p[2], p[3]) + rd
+    (ref * dy.double()).sum().backward()
+    want = [ref, xd.grad, rd.grad, p[0].grad, p[1].grad, p[2].grad, p[3].grad]
+    names = ["y", "dx", "dresid", "dW1", "db1", "dW2", "db2"]
+    for n, a, b in zip(names, got, want):
+        err = (a.double() - b).abs().max().item() / max(b.abs().max().item(), 1e-9)
+        assert err <= 2.5e-2, (n, err)
