@@ -1082,6 +1082,144 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_big_kernel(const bf16_t* __r
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Eight-wave flavour of the 256x256 weight-gradient kernel: waves 2 x 4, each a 128x64 accumulator (8 MFMA tiles = 128
+// registers), TWO waves per SIMD so that one wave's barrier / wait / slab store overlaps the other's MFMAs (what made the
+// 320x256 NT kernel reach 1 PF).  Same ring, same LDS image, same split-major order; 4 DMA instructions per stage and
+// thread, 12 transpose reads per 16-row slice and wave for 8 MFMAs.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_tn_bf16_wide_kernel(const bf16_t* __restrict__ dY, int64_t ldy,
+                                                                   const bf16_t* __restrict__ X, int64_t ldx,
+                                                                   float* __restrict__ slabs, int M, int N, int K, int nsplit,
+                                                                   int steps_per_split) {
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[4 * WB_STAGE];
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    const int ntk = K >> 8, ntiles = (N >> 8) * ntk;
+    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id / ntiles; id -= split * ntiles;
+    const int tk = id % ntk, tn = id / ntk;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 2, wj = wave & 3;                 // output rows (n) 128 wi .., output columns (k) 64 wj ..
+    const int r = lane & 31, hh = lane >> 5;
+    const int total_steps = (M + WB_ROWS - 1) / WB_ROWS;
+    const int st0 = split * steps_per_split, st1 = min(st0 + steps_per_split, total_steps);
+    const int n = st1 - st0;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float* slab = slabs + (int64_t)split * N * K;
+    if (n > 0) {
+        // DMA instruction g = wave * 4 + q (0..31) of a stage: operand g >> 4 (dY, X), 128-column half (g >> 3) & 1,
+        // row group g & 7 (4 rows each)
+        uint32_t doff[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gI = wave * 4 + q;
+            const int row = (gI & 7) * 4 + (lane >> 4);
+            const int lc = (lane & 15) ^ ((row & 3) << 2);
+            const int col = ((gI >> 4) ? tk : tn) * 256 + ((gI >> 3) & 1) * 128 + lc * 8;
+            doff[q] = (uint32_t)(((int64_t)row * ((gI >> 4) ? ldx : ldy) + col) * 2);
+        }
+        auto dma = [&](int it, int q) {                      // one DMA instruction of stage `it` (all rows < M: see host)
+            const int gI = wave * 4 + q;
+            const int64_t m0 = (int64_t)(st0 + it) * WB_ROWS;
+            const char* base = (gI >> 4) ? reinterpret_cast<const char*>(X + m0 * ldx) : reinterpret_cast<const char*>(dY + m0 * ldy);
+            bf16_t* dst = smem + (it & 3) * WB_STAGE + (gI >> 3) * WB_HALF + (gI & 7) * 4 * 128;
+            __builtin_amdgcn_global_load_lds((glb_vp)(base + doff[q]), (lds_vp)dst, 16, 0, 0);
+        };
+        const int li = lane & 15, x = (li >> 2) & 3;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)smem;
+        const uint32_t lowb = (uint32_t)((4 * hh + (li >> 2)) * 256 + ((2 * ((lane >> 4) & 1) + ((li & 3) >> 1)) << 4) + ((li & 1) << 3));
+        uint32_t fa[4], fb[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa[t] = lds0 + wi * (WB_HALF * 2) + lowb + ((t ^ x) << 6);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fb[t] = lds0 + (2 + (wj >> 1)) * (WB_HALF * 2) + lowb + ((((wj & 1) * 2 + t) ^ x) << 6);
+        bf16x4 x0l[6], x0h[6], x1l[6], x1h[6];              // [0..3] = dY fragments, [4..5] = X fragments
+#define W8_RD(lo, hi, addr, OFF)                                                                                     \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                         \
+                 : "=&v"(lo), "=&v"(hi) : "v"(addr), "i"(OFF), "i"((OFF) + 2048))
+#define W8_READ6(L, H, so, OFF)                                                                                      \
+    { _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) { W8_RD(L[t_], H[t_], fa[t_] + (so), OFF); }                   \
+      _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) { W8_RD(L[4 + t_], H[4 + t_], fb[t_] + (so), OFF); } }
+#define W8_WAIT(cnt, L, H)                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                       \
+                 : "+v"(L[0]), "+v"(L[1]), "+v"(L[2]), "+v"(L[3]), "+v"(L[4]), "+v"(L[5]),                           \
+                   "+v"(H[0]), "+v"(H[1]), "+v"(H[2]), "+v"(H[3]), "+v"(H[4]), "+v"(H[5]))
+#define W8_MFMA8(L, H)                                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                 \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                       \
+            __builtin_shufflevector(L[i_], H[i_], 0, 1, 2, 3, 4, 5, 6, 7),                                           \
+            __builtin_shufflevector(L[4 + j_], H[4 + j_], 0, 1, 2, 3, 4, 5, 6, 7), acc[i_][j_], 0, 0, 0)
+#define W8_SPREAD2                                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                           \
+    }
+        auto body = [&](int it, auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            const uint32_t so = (uint32_t)(it & 3) * (WB_STAGE * 2), so2 = (uint32_t)((it + 1) & 3) * (WB_STAGE * 2);
+            W8_READ6(x1l, x1h, so, 4096);                   // slice 1 of stage it
+            W8_WAIT(12, x0l, x0h);                          // the 12 older reads (slice 0) are done
+            if (MODE == 0) { dma(it + 3, 0); dma(it + 3, 1); }
+            W8_MFMA8(x0l, x0h);
+            if (MODE == 0) { W8_SPREAD2 }
+            W8_WAIT(0, x1l, x1h);                           // this wave holds every fragment of stage it
+            if (MODE <= 1) {
+                // stage it+1 landed; stage it+2 (4) and the first half of stage it+3 (2) may stay in flight
+                if (MODE == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                W8_READ6(x0l, x0h, so2, 0);                 // slice 0 of stage it+1
+            }
+            if (MODE == 0) { dma(it + 3, 2); dma(it + 3, 3); }
+            W8_MFMA8(x1l, x1h);
+            if (MODE == 0) { W8_SPREAD2 }
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma(0, q);
+        if (n > 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma(1, q);
+        }
+        if (n > 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma(2, q);
+        }
+        if (n > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        W8_READ6(x0l, x0h, 0u, 0);
+        int it = 0;
+        for (; it + 3 < n; ++it) body(it, std::integral_constant<int, 0>{});
+        for (; it + 1 < n; ++it) body(it, std::integral_constant<int, 1>{});
+        body(it, std::integral_constant<int, 2>{});
+#undef W8_RD
+#undef W8_READ6
+#undef W8_WAIT
+#undef W8_MFMA8
+#undef W8_SPREAD2
+    }
+    // acc[i][j][reg] = dW[tn*256 + 128 wi + 32 i + krow(reg,hh)][tk*256 + 64 wj + 32 j + r]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int nn = tn * 256 + 128 * wi + 32 * i + acr_krow(reg, hh);
+                const int kk = tk * 256 + 64 * wj + 32 * j + r;
+                slab[(int64_t)nn * K + kk] = acc[i][j][reg];
+            }
+}
+
 static bool wgrad_big_ok(int M, int N, int K) {
     static const int env = getenv("ACR_WGRAD_VARIANT") ? atoi(getenv("ACR_WGRAD_VARIANT")) : 2;      // 1: 128x128 tiles, 2: 256x256
     // the 256x256 kernel has no ragged-row path: token counts that are not a multiple of its 32-row stage (and small
@@ -1115,7 +1253,11 @@ extern "C" int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_
     const int total_steps = wgrad_big_ok(M, N, K) ? (M + WB_ROWS - 1) / WB_ROWS : (M + 63) / 64;
     const int sps = (total_steps + nsplit - 1) / nsplit;
     hipStream_t st = (hipStream_t)stream;
-    if (wgrad_big_ok(M, N, K))
+    static const int tn_waves = getenv("ACR_WGRAD_WAVES") ? atoi(getenv("ACR_WGRAD_WAVES")) : 8;     // 4 or 8 waves per workgroup
+    if (wgrad_big_ok(M, N, K) && tn_waves == 8)
+        hipLaunchKernelGGL(gemm_tn_bf16_wide_kernel, dim3((N / 256) * (K / 256) * nsplit), dim3(512), 0, st, (const bf16_t*)dy, ldy,
+                           (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps);
+    else if (wgrad_big_ok(M, N, K))
         hipLaunchKernelGGL(gemm_tn_bf16_big_kernel, dim3((N / 256) * (K / 256) * nsplit), dim3(256), 0, st, (const bf16_t*)dy, ldy,
                            (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps);
     else
