@@ -13,7 +13,7 @@ def per_kernel(path, counter):
     return {k: sum(v) / len(v) for k, v in d.items()}
 
 names = {"attn_fwd": "attn_fwd_bf16", "attn_pmean": "attn_tile_qk_bf16_kernel<0>", "attn_delta": "attn_delta_bf16",
-         "attn_dkdv": "attn_dkdv_bf16", "attn_dq": "attn_dq_bf16", "cons_fwd": "cons_fwd", "wgrad_gemm": "gemm_tn_bf16_big",
+         "attn_dkdv": "attn_dkdv_bf16", "attn_dq": "attn_dq_bf16", "cons_fwd": "cons_fwd", "wgrad_gemm": "gemm_tn_bf16_wide",
          "wgrad_reduce": "wgrad_reduce_kernel"}
 F = per_kernel(sys.argv[1], "FETCH_SIZE"); W = per_kernel(sys.argv[2], "WRITE_SIZE")
 def pick(d, pat):
