@@ -209,7 +209,11 @@ def test_errors_are_loud():
 
 @pytest.mark.parametrize("M,N,K,bias,resid", [(1, 128, 64, True, False), (130, 200, 128, True, True),
                                               (785, 2304, 768, True, False), (2 * 785, 768, 768, False, True),
-                                              (333, 768, 2304, False, False)])
+                                              (333, 768, 2304, False, False),
+                                              # large problems take the eight-wave 320x256 kernel (>= 200 tiles):
+                                              # ragged in M and N, with and without bias / residual; K = 64 is one stage
+                                              (320 * 100 + 17, 520, 64, True, True), (32 * 785, 768, 768, True, True),
+                                              (320 * 70 + 300, 1000, 192, False, False)])
 def test_linear_bf16(M, N, K, bias, resid):
     """acr_linear_bf16 (hand-written MFMA GEMM) forward + autograd against fp64; ragged M/N tails included."""
     from acr_wsss_amd import ops
