@@ -65,6 +65,9 @@ SIGNATURES = {
                                        c_int32, c_int32, c_void_p]),
     "acr_linear_dgelu_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                         c_int32, c_int32, c_void_p]),
+    "acr_wgrad_bias_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),
+    "acr_wgrad_bias_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
     "acr_layernorm_ws_floats": (c_size_t, [c_int32, c_int32]),
     "acr_layernorm_fwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float,
                                          c_void_p]),

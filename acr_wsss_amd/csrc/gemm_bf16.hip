@@ -1088,10 +1088,20 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_big_kernel(const bf16_t* __r
 // 320x256 NT kernel reach 1 PF).  Same ring, same LDS image, same split-major order; 4 DMA instructions per stage and
 // thread, 12 transpose reads per 16-row slice and wave for 8 MFMAs.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void gemm_tn_bf16_wide_kernel(const bf16_t* __restrict__ dY, int64_t ldy,
+// Bias gradient for free: the dY fragments a wave reads ARE the columns whose sums the bias gradient needs (fragment t of
+// a wave = 32 columns x 16 token rows, 8 rows per lane half).  Wave (wi, wj) sums fragment t = wj -- the 8 waves then
+// cover the tile's 256 columns once -- ~16 VALU per 8 MFMAs, hidden behind the matrix pipe.  Every workgroup of a row
+// of tiles does it (no imbalance), the tk = 0 one writes its per-split partial; the final sum over the splits is
+// the existing two-stage column-sum's second stage.  Replaces a full extra pass over dY (1.1 ms per step).
+__device__ __forceinline__ float w8_sum8(const bf16x4& lo, const bf16x4& hi) {
+    return (((float)lo[0] + (float)lo[1]) + ((float)lo[2] + (float)lo[3])) + (((float)hi[0] + (float)hi[1]) + ((float)hi[2] + (float)hi[3]));
+}
+
+template <bool COLSUM>                                     // compile-time: a runtime test inside the step body breaks its
+__global__ __launch_bounds__(512, 2) void gemm_tn_bf16_wide_kernel(const bf16_t* __restrict__ dY, int64_t ldy,   // scheduling (2x slower)
                                                                    const bf16_t* __restrict__ X, int64_t ldx,
                                                                    float* __restrict__ slabs, int M, int N, int K, int nsplit,
-                                                                   int steps_per_split) {
+                                                                   int steps_per_split, float* __restrict__ cs_part) {
     __shared__ __attribute__((aligned(1024))) bf16_t smem[4 * WB_STAGE];
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef const __attribute__((address_space(1))) void* glb_vp;
@@ -1162,15 +1172,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_wide_kernel(const bf16_t*
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                           \
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                           \
     }
-        auto body = [&](int it, auto mode_tag) {
+    // this wave's share of the column sums: fragment WJS = wj, a compile-time index -- the loop is instantiated once per
+    // wj and each wave runs its own copy (selecting the fragment at run time cost the kernel half its speed)
+#define W8_PICK(L, H) w8_sum8(L[WJS], H[WJS])
+        float csum = 0.f;
+        auto body = [&](int it, auto mode_tag, auto wj_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
+            constexpr int WJS = decltype(wj_tag)::value;
             const uint32_t so = (uint32_t)(it & 3) * (WB_STAGE * 2), so2 = (uint32_t)((it + 1) & 3) * (WB_STAGE * 2);
             W8_READ6(x1l, x1h, so, 4096);                   // slice 1 of stage it
             W8_WAIT(12, x0l, x0h);                          // the 12 older reads (slice 0) are done
             if (MODE == 0) { dma(it + 3, 0); dma(it + 3, 1); }
             W8_MFMA8(x0l, x0h);
+            if (COLSUM) csum += W8_PICK(x0l, x0h);
             if (MODE == 0) { W8_SPREAD2 }
             W8_WAIT(0, x1l, x1h);                           // this wave holds every fragment of stage it
+            if (COLSUM) csum += W8_PICK(x1l, x1h);
             if (MODE <= 1) {
                 // stage it+1 landed; stage it+2 (4) and the first half of stage it+3 (2) may stay in flight
                 if (MODE == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -1197,15 +1214,32 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_wide_kernel(const bf16_t*
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         W8_READ6(x0l, x0h, 0u, 0);
-        int it = 0;
-        for (; it + 3 < n; ++it) body(it, std::integral_constant<int, 0>{});
-        for (; it + 1 < n; ++it) body(it, std::integral_constant<int, 1>{});
-        body(it, std::integral_constant<int, 2>{});
+        auto run = [&](auto wj_tag) {
+            int it = 0;
+            for (; it + 3 < n; ++it) body(it, std::integral_constant<int, 0>{}, wj_tag);
+            for (; it + 1 < n; ++it) body(it, std::integral_constant<int, 1>{}, wj_tag);
+            body(it, std::integral_constant<int, 2>{}, wj_tag);
+        };
+        if (COLSUM) {
+            if (wj == 0) run(std::integral_constant<int, 0>{});
+            else if (wj == 1) run(std::integral_constant<int, 1>{});
+            else if (wj == 2) run(std::integral_constant<int, 2>{});
+            else run(std::integral_constant<int, 3>{});
+        } else {
+            run(std::integral_constant<int, 0>{});
+        }
 #undef W8_RD
 #undef W8_READ6
 #undef W8_WAIT
 #undef W8_MFMA8
 #undef W8_SPREAD2
+#undef W8_PICK
+        if (COLSUM && tk == 0) {
+            csum += __shfl_xor(csum, 32);                   // the two lane halves hold different token rows of a column
+            if (hh == 0) cs_part[(int64_t)split * N + tn * 256 + 128 * wi + 32 * wj + r] = csum;
+        }
+    } else if (COLSUM && tk == 0 && hh == 0) {
+        cs_part[(int64_t)split * N + tn * 256 + 128 * wi + 32 * wj + r] = 0.f;       // empty split: contributes nothing
     }
     // acc[i][j][reg] = dW[tn*256 + 128 wi + 32 i + krow(reg,hh)][tk*256 + 64 wj + 32 j + r]
 #pragma unroll
@@ -1255,8 +1289,8 @@ extern "C" int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_
     hipStream_t st = (hipStream_t)stream;
     static const int tn_waves = getenv("ACR_WGRAD_WAVES") ? atoi(getenv("ACR_WGRAD_WAVES")) : 8;     // 4 or 8 waves per workgroup
     if (wgrad_big_ok(M, N, K) && tn_waves == 8)
-        hipLaunchKernelGGL(gemm_tn_bf16_wide_kernel, dim3((N / 256) * (K / 256) * nsplit), dim3(512), 0, st, (const bf16_t*)dy, ldy,
-                           (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps);
+        hipLaunchKernelGGL(gemm_tn_bf16_wide_kernel<false>, dim3((N / 256) * (K / 256) * nsplit), dim3(512), 0, st, (const bf16_t*)dy,
+                           ldy, (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps, (float*)nullptr);
     else if (wgrad_big_ok(M, N, K))
         hipLaunchKernelGGL(gemm_tn_bf16_big_kernel, dim3((N / 256) * (K / 256) * nsplit), dim3(256), 0, st, (const bf16_t*)dy, ldy,
                            (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps);
@@ -1267,6 +1301,43 @@ extern "C" int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsplit,
                        nk, (bf16_t*)dw);
     return acr_check_launch("acr_wgrad_bf16");
+}
+
+// Weight AND bias gradient of a Linear in one sweep over dY (see the column sums inside gemm_tn_bf16_wide_kernel); falls
+// back to acr_wgrad_bf16 + acr_colsum_bf16 for shapes the eight-wave kernel does not take.
+extern "C" size_t acr_wgrad_bias_ws_floats(int32_t M, int32_t N, int32_t K) {
+    const size_t a = acr_wgrad_ws_floats(M, N, K);
+    if (a == 0) return 0;
+    const size_t cs = (size_t)((M + CS_ROWS - 1) / CS_ROWS) * (size_t)N;        // fallback column-sum partials
+    const size_t fused = (size_t)wgrad_split(M, N, K) * (size_t)N;
+    return a + (cs > fused ? cs : fused);
+}
+
+extern "C" int acr_wgrad_bias_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int32_t M, int32_t N, int32_t K,
+                                   float* ws, void* dw, void* dbias, void* stream) {
+    ACR_CHECK_ARG(dy && x && ws && dw && dbias, "acr_wgrad_bias_bf16: null pointer");
+    static const int tn_waves = getenv("ACR_WGRAD_WAVES") ? atoi(getenv("ACR_WGRAD_WAVES")) : 8;
+    const size_t slab_floats = acr_wgrad_ws_floats(M, N, K);
+    ACR_CHECK_ARG(slab_floats > 0, "acr_wgrad_bias_bf16: N and K must be multiples of 128 (N=%d K=%d)", N, K);
+    if (!(wgrad_big_ok(M, N, K) && tn_waves == 8)) {
+        int rc = acr_wgrad_bf16(dy, ldy, x, ldx, M, N, K, ws, dw, stream);
+        if (rc) return rc;
+        return acr_colsum_bf16(dy, ldy, M, N, ws + slab_floats, dbias, stream);
+    }
+    ACR_CHECK_ARG((ldy % 8) == 0 && (ldx % 8) == 0 && ldy >= N && ldx >= K && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0,
+                  "acr_wgrad_bias_bf16: row pitches must be multiples of 8 elements and operands 16-byte aligned");
+    const int nsplit = wgrad_split(M, N, K);
+    const int total_steps = (M + WB_ROWS - 1) / WB_ROWS;
+    const int sps = (total_steps + nsplit - 1) / nsplit;
+    hipStream_t st = (hipStream_t)stream;
+    float* cs = ws + slab_floats;
+    hipLaunchKernelGGL(gemm_tn_bf16_wide_kernel<true>, dim3((N / 256) * (K / 256) * nsplit), dim3(512), 0, st, (const bf16_t*)dy, ldy,
+                       (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps, cs);
+    const int64_t nk = (int64_t)N * K;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsplit,
+                       nk, (bf16_t*)dw);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 15) / 16), dim3(256), 0, st, (const float*)cs, nsplit, N, (bf16_t*)dbias);
+    return acr_check_launch("acr_wgrad_bias_bf16");
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -209,6 +209,27 @@ def wgrad_bf16(dy2, x2):
     return dw
 
 
+FUSED_BIAS_GRAD = os.environ.get("ACR_WGRAD_FUSED_BIAS", "1") != "0"      # A/B switch
+
+
+def wgrad_bias_bf16(dy2, x2):
+    """(dW, db) = (dy2^T @ x2, column sums of dy2) in ONE sweep over dy2 (acr_wgrad_bias_bf16: the bias gradient is
+    accumulated from the dY fragments inside the weight-gradient kernel); unsupported shapes take the two separate ops."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    lib = L.load()
+    nws = lib.acr_wgrad_bias_ws_floats(M, N, K) if FUSED_BIAS_GRAD else 0
+    if (nws == 0 or N % 8 or dy2.stride(1) != 1 or x2.stride(1) != 1 or dy2.stride(0) % 8 or x2.stride(0) % 8
+            or dy2.data_ptr() % 16 or x2.data_ptr() % 16):
+        return wgrad_bf16(dy2, x2), colsum_bf16(dy2)
+    ws = torch.empty(nws, dtype=torch.float32, device=dy2.device)
+    dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy2.device)
+    db = torch.empty(N, dtype=torch.bfloat16, device=dy2.device)
+    L.check(lib.acr_wgrad_bias_bf16(L.ptr(dy2), dy2.stride(0), L.ptr(x2), x2.stride(0), M, N, K, L.ptr(ws), L.ptr(dw), L.ptr(db),
+                                    L.stream_ptr()), "acr_wgrad_bias_bf16")
+    return dw, db
+
+
 class LinearBf16Fn(Function):
     """y = x W^T + b (+ resid) for the attention block's qkv / proj Linears in the bf16 mode, on the hand-written
     MFMA GEMM for forward and input gradient; the weight gradient (a reduction over all tokens) stays on
@@ -243,10 +264,14 @@ class LinearBf16Fn(Function):
             else:                                           # contraction length not a multiple of the K tile
                 dx = torch.mm(dy2, weight)
             dx = dx.reshape(*dy.shape[:-1], weight.shape[1])
-        if ctx.needs_input_grad[1]:
-            dw = wgrad_bf16(dy2, x2) if ctx.hip_dw else torch.mm(dy2.t(), x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum_bf16(dy2)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and ctx.hip_dw and want_db:
+            dw, db = wgrad_bias_bf16(dy2, x2)               # one sweep over dy for both
+        else:
+            if ctx.needs_input_grad[1]:
+                dw = wgrad_bf16(dy2, x2) if ctx.hip_dw else torch.mm(dy2.t(), x2)
+            if want_db:
+                db = colsum_bf16(dy2)
         return dx, dw, db, (dy if ctx.has_resid else None), None, None, None
 
 
@@ -286,14 +311,12 @@ class MlpFn(Function):
             dy2 = dy2.contiguous()
         M, Hd = h.shape
         lib = L.load()
-        dw2 = wgrad_bf16(dy2, a)
-        db2 = colsum_bf16(dy2)
+        dw2, db2 = wgrad_bias_bf16(dy2, a)
         w2t = w2.t().contiguous()                             # (hidden, out): dA = dY W2
         dh = torch.empty_like(h)
         L.check(lib.acr_linear_dgelu_bf16(L.ptr(dy2), dy2.stride(0), L.ptr(w2t), w2t.stride(0), L.ptr(h), h.stride(0), L.ptr(dh),
                                           dh.stride(0), M, Hd, dy2.shape[1], L.stream_ptr()), "acr_linear_dgelu_bf16")
-        dw1 = wgrad_bf16(dh, x2)
-        db1 = colsum_bf16(dh)
+        dw1, db1 = wgrad_bias_bf16(dh, x2)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = linear_bf16(dh, w1.t().contiguous()).reshape(*dy.shape[:-1], w1.shape[1])

@@ -109,6 +109,12 @@ int acr_linear_dgelu_bf16(const void* a, int64_t lda, const void* w, int64_t ldw
 size_t acr_wgrad_ws_floats(int32_t M, int32_t N, int32_t K);
 int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int32_t M, int32_t N, int32_t K,
                    float* ws, void* dw, void* stream);
+/* Weight and bias gradient in one sweep over dy: dbias[n] = sum_m dy[m][n] is accumulated from the dy fragments inside
+ * the weight-gradient kernel (no second pass over dy).  ws: acr_wgrad_bias_ws_floats(M, N, K) floats. */
+size_t acr_wgrad_bias_ws_floats(int32_t M, int32_t N, int32_t K);
+int acr_wgrad_bias_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int32_t M, int32_t N, int32_t K, float* ws,
+                        void* dw, void* dbias, void* stream);
+
 
 /* Bias gradient of a projection: out[n] = sum_m dy[m, n], bf16 in/out, fp32 two-stage deterministic accumulation.
  * ws: caller-owned fp32 scratch of acr_colsum_ws_floats(M, N) floats.  N and ld multiples of 8. */
