@@ -1256,25 +1256,62 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_wide_kernel(const bf16_t*
 
 static bool wgrad_big_ok(int M, int N, int K) {
     static const int env = getenv("ACR_WGRAD_VARIANT") ? atoi(getenv("ACR_WGRAD_VARIANT")) : 2;      // 1: 128x128 tiles, 2: 256x256
-    // the 256x256 kernel has no ragged-row path: token counts that are not a multiple of its 32-row stage (and small
-    // problems that would not fill the chip) stay on the 128x128 kernel
-    return env == 2 && (N % 256) == 0 && (K % 256) == 0 && (M % WB_ROWS) == 0 && M >= 4096;
+    // small problems (that would not fill the chip) and widths that are not multiples of 256 stay on the 128x128 kernel
+    return env == 2 && (N % 256) == 0 && (K % 256) == 0 && M >= 4096;
 }
 
-static int wgrad_split(int M, int N, int K) {
-    const bool big = wgrad_big_ok(M, N, K);
-    const int tiles = big ? (N / 256) * (K / 256) : (N / 128) * (K / 128);
-    int s = (big ? 256 : 512) / tiles;                       // one 256x256 or ~2 128x128 workgroups per CU
-    const int total_steps = big ? (M + WB_ROWS - 1) / WB_ROWS : (M + 63) / 64;
+// The 256x256 kernels have no ragged-row path: they take the first M_main = floor(M / 32) * 32 token rows; the remaining
+// (< 32) rows go through the 128x128 kernel (which masks ragged rows) into ONE extra slab, summed with the others.
+struct WgradPlan { bool big; int m_main, tail, nsplit, sps, nslab; };
+static WgradPlan wgrad_plan(int M, int N, int K) {
+    WgradPlan p;
+    p.big = wgrad_big_ok(M, N, K);
+    p.m_main = p.big ? (M / WB_ROWS) * WB_ROWS : M;
+    p.tail = M - p.m_main;
+    const int tiles = p.big ? (N / 256) * (K / 256) : (N / 128) * (K / 128);
+    const int total_steps = p.big ? p.m_main / WB_ROWS : (M + 63) / 64;
+    int s = (p.big ? 256 : 512) / tiles;                     // one 256x256 or ~2 128x128 workgroups per CU
     if (s < 1) s = 1;
     if (s > 32) s = 32;
     if (s > total_steps) s = total_steps;
-    return s;
+    p.nsplit = s;
+    p.sps = (total_steps + s - 1) / s;
+    p.nslab = s + (p.tail ? 1 : 0);
+    return p;
 }
 
 extern "C" size_t acr_wgrad_ws_floats(int32_t M, int32_t N, int32_t K) {
-    if (N <= 0 || K <= 0 || (N % 128) || (K % 128)) return 0;
-    return (size_t)wgrad_split(M, N, K) * (size_t)N * (size_t)K;
+    if (M <= 0 || N <= 0 || K <= 0 || (N % 128) || (K % 128)) return 0;
+    return (size_t)wgrad_plan(M, N, K).nslab * (size_t)N * (size_t)K;
+}
+
+// slabs of the main part (and of the ragged tail) into ws; cs (nullable): per-slab column sums of dy for the fused bias path
+static void wgrad_launch(const WgradPlan& p, const bf16_t* dy, int64_t ldy, const bf16_t* x, int64_t ldx, int M, int N, int K, float* ws,
+                         float* cs, hipStream_t st) {
+    static const int tn_waves = getenv("ACR_WGRAD_WAVES") ? atoi(getenv("ACR_WGRAD_WAVES")) : 8;     // 4 or 8 waves per workgroup
+    if (p.big && (tn_waves == 8 || cs)) {
+        if (cs)
+            hipLaunchKernelGGL(gemm_tn_bf16_wide_kernel<true>, dim3((N / 256) * (K / 256) * p.nsplit), dim3(512), 0, st, dy, ldy, x, ldx,
+                               ws, p.m_main, N, K, p.nsplit, p.sps, cs);
+        else
+            hipLaunchKernelGGL(gemm_tn_bf16_wide_kernel<false>, dim3((N / 256) * (K / 256) * p.nsplit), dim3(512), 0, st, dy, ldy, x,
+                               ldx, ws, p.m_main, N, K, p.nsplit, p.sps, (float*)nullptr);
+    } else if (p.big) {
+        hipLaunchKernelGGL(gemm_tn_bf16_big_kernel, dim3((N / 256) * (K / 256) * p.nsplit), dim3(256), 0, st, dy, ldy, x, ldx, ws,
+                           p.m_main, N, K, p.nsplit, p.sps);
+    } else {
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((N / 128) * (K / 128) * p.nsplit), dim3(256), 0, st, dy, ldy, x, ldx, ws, M, N, K,
+                           p.nsplit, p.sps);
+    }
+    if (p.tail) {                                            // ragged rows of the big path: one more slab (and column-sum row)
+        const bf16_t* dyt = dy + (int64_t)p.m_main * ldy;
+        const bf16_t* xt = x + (int64_t)p.m_main * ldx;
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((N / 128) * (K / 128)), dim3(256), 0, st, dyt, ldy, xt, ldx,
+                           ws + (int64_t)p.nsplit * N * K, p.tail, N, K, 1, 1);
+        if (cs)
+            hipLaunchKernelGGL(colsum_partial_kernel, dim3((N / 8 + 63) / 64, 1), dim3(256), 0, st, dyt, ldy, p.tail, N,
+                               cs + (int64_t)p.nsplit * N);
+    }
 }
 
 extern "C" int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int32_t M, int32_t N, int32_t K,
@@ -1283,22 +1320,11 @@ extern "C" int acr_wgrad_bf16(const void* dy, int64_t ldy, const void* x, int64_
     ACR_CHECK_ARG(M > 0 && N > 0 && K > 0 && (N % 128) == 0 && (K % 128) == 0, "acr_wgrad_bf16: N and K must be multiples of 128 (N=%d K=%d)", N, K);
     ACR_CHECK_ARG((ldy % 8) == 0 && (ldx % 8) == 0 && ldy >= N && ldx >= K && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0,
                   "acr_wgrad_bf16: row pitches must be multiples of 8 elements and operands 16-byte aligned");
-    const int nsplit = wgrad_split(M, N, K);
-    const int total_steps = wgrad_big_ok(M, N, K) ? (M + WB_ROWS - 1) / WB_ROWS : (M + 63) / 64;
-    const int sps = (total_steps + nsplit - 1) / nsplit;
+    const WgradPlan p = wgrad_plan(M, N, K);
     hipStream_t st = (hipStream_t)stream;
-    static const int tn_waves = getenv("ACR_WGRAD_WAVES") ? atoi(getenv("ACR_WGRAD_WAVES")) : 8;     // 4 or 8 waves per workgroup
-    if (wgrad_big_ok(M, N, K) && tn_waves == 8)
-        hipLaunchKernelGGL(gemm_tn_bf16_wide_kernel<false>, dim3((N / 256) * (K / 256) * nsplit), dim3(512), 0, st, (const bf16_t*)dy,
-                           ldy, (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps, (float*)nullptr);
-    else if (wgrad_big_ok(M, N, K))
-        hipLaunchKernelGGL(gemm_tn_bf16_big_kernel, dim3((N / 256) * (K / 256) * nsplit), dim3(256), 0, st, (const bf16_t*)dy, ldy,
-                           (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps);
-    else
-        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((N / 128) * (K / 128) * nsplit), dim3(256), 0, st, (const bf16_t*)dy, ldy,
-                           (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps);
+    wgrad_launch(p, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, N, K, ws, nullptr, st);
     const int64_t nk = (int64_t)N * K;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsplit,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nslab,
                        nk, (bf16_t*)dw);
     return acr_check_launch("acr_wgrad_bf16");
 }
@@ -1309,34 +1335,30 @@ extern "C" size_t acr_wgrad_bias_ws_floats(int32_t M, int32_t N, int32_t K) {
     const size_t a = acr_wgrad_ws_floats(M, N, K);
     if (a == 0) return 0;
     const size_t cs = (size_t)((M + CS_ROWS - 1) / CS_ROWS) * (size_t)N;        // fallback column-sum partials
-    const size_t fused = (size_t)wgrad_split(M, N, K) * (size_t)N;
+    const size_t fused = (size_t)wgrad_plan(M, N, K).nslab * (size_t)N;
     return a + (cs > fused ? cs : fused);
 }
 
 extern "C" int acr_wgrad_bias_bf16(const void* dy, int64_t ldy, const void* x, int64_t ldx, int32_t M, int32_t N, int32_t K,
                                    float* ws, void* dw, void* dbias, void* stream) {
     ACR_CHECK_ARG(dy && x && ws && dw && dbias, "acr_wgrad_bias_bf16: null pointer");
-    static const int tn_waves = getenv("ACR_WGRAD_WAVES") ? atoi(getenv("ACR_WGRAD_WAVES")) : 8;
     const size_t slab_floats = acr_wgrad_ws_floats(M, N, K);
     ACR_CHECK_ARG(slab_floats > 0, "acr_wgrad_bias_bf16: N and K must be multiples of 128 (N=%d K=%d)", N, K);
-    if (!(wgrad_big_ok(M, N, K) && tn_waves == 8)) {
+    const WgradPlan p = wgrad_plan(M, N, K);
+    if (!p.big) {
         int rc = acr_wgrad_bf16(dy, ldy, x, ldx, M, N, K, ws, dw, stream);
         if (rc) return rc;
         return acr_colsum_bf16(dy, ldy, M, N, ws + slab_floats, dbias, stream);
     }
     ACR_CHECK_ARG((ldy % 8) == 0 && (ldx % 8) == 0 && ldy >= N && ldx >= K && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0,
                   "acr_wgrad_bias_bf16: row pitches must be multiples of 8 elements and operands 16-byte aligned");
-    const int nsplit = wgrad_split(M, N, K);
-    const int total_steps = (M + WB_ROWS - 1) / WB_ROWS;
-    const int sps = (total_steps + nsplit - 1) / nsplit;
     hipStream_t st = (hipStream_t)stream;
     float* cs = ws + slab_floats;
-    hipLaunchKernelGGL(gemm_tn_bf16_wide_kernel<true>, dim3((N / 256) * (K / 256) * nsplit), dim3(512), 0, st, (const bf16_t*)dy, ldy,
-                       (const bf16_t*)x, ldx, ws, M, N, K, nsplit, sps, cs);
+    wgrad_launch(p, (const bf16_t*)dy, ldy, (const bf16_t*)x, ldx, M, N, K, ws, cs, st);
     const int64_t nk = (int64_t)N * K;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsplit,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nslab,
                        nk, (bf16_t*)dw);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 15) / 16), dim3(256), 0, st, (const float*)cs, nsplit, N, (bf16_t*)dbias);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 15) / 16), dim3(256), 0, st, (const float*)cs, p.nslab, N, (bf16_t*)dbias);
     return acr_check_launch("acr_wgrad_bias_bf16");
 }
 

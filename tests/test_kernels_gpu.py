@@ -275,9 +275,12 @@ def test_groupnorm_fused(N, C, H, W, act):
         assert (r.grad.double() - rd.grad).abs().max() <= 1e-2 * rd.grad.abs().max()
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (100, 256, 128), (785 * 2 + 3, 768, 2304), (25120, 2304, 768)])
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (100, 256, 128), (785 * 2 + 3, 768, 2304), (25120, 2304, 768),
+                                   # 256x256 eight-wave kernel + ragged tail rows through the 128x128 kernel (M % 32 != 0)
+                                   (16 * 785, 768, 768), (16 * 1025, 256, 512), (4096 + 31, 512, 256)])
 def test_wgrad_bf16(M, N, K):
-    """Split-M TN weight-gradient GEMM (acr_wgrad_bf16) vs fp64, including a ragged last 64-row chunk."""
+    """Split-M TN weight-gradient GEMM (acr_wgrad_bf16 / acr_wgrad_bias_bf16) vs fp64, including ragged token counts; the
+    fused bias gradient (column sums of dy from the same sweep) against the fp64 column sums."""
     from acr_wsss_amd import ops
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(M + N)
@@ -289,6 +292,12 @@ def test_wgrad_bf16(M, N, K):
     assert (dw.double() - ref).abs().max() <= 1e-2 * ref.abs().max()
     # deterministic: same bits on a second run
     assert torch.equal(dw, ops.wgrad_bf16(dy, x))
+    dw2, db = ops.wgrad_bias_bf16(dy, x)
+    assert (dw2.double() - ref).abs().max() <= 1e-2 * ref.abs().max()
+    cs = dy.double().sum(0)
+    assert db.shape == (N,) and (db.double() - cs).abs().max() <= 1e-2 * cs.abs().max() + 1e-2
+    dw3, db3 = ops.wgrad_bias_bf16(dy, x)
+    assert torch.equal(dw2, dw3) and torch.equal(db, db3)
 
 
 def test_weight_std_all_fused():
