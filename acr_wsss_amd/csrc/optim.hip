@@ -66,3 +66,45 @@ extern "C" int acr_sgd_step_bf16(const void* table, const int32_t* blk_tensor, c
                        blk_tensor, blk_chunk, lr, momentum);
     return acr_check_launch("acr_sgd_step_bf16");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// W^T of every block Linear in ONE launch, right after the optimizer step.  The input-gradient GEMMs want the weight
+// as (in, out); the per-layer `weight.t().contiguous()` they used ran at 0.7 TB/s and cost 0.6 ms per step (48
+// launches).  Table-driven like the optimizer step; 64x64 tiles through LDS (padded rows), 16-byte accesses both ways.
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void transpose_many_kernel(const acr_tr_tensor* __restrict__ tab, const int32_t* __restrict__ blk_tensor) {
+    __shared__ bf16_t tile[64][72];
+    const acr_tr_tensor t = tab[blk_tensor[blockIdx.x]];
+    const int lt = blockIdx.x - t.tile0;
+    const int r0 = (lt / t.tiles_c) * 64, c0 = (lt % t.tiles_c) * 64;
+    const bf16_t* s = (const bf16_t*)t.src;
+    bf16_t* d = (bf16_t*)t.dst;
+    const int tid = threadIdx.x;
+    // load 64 rows x 64 cols: 8 threads x 16 B per row, 32 rows per pass
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = p * 32 + (tid >> 3), c = (tid & 7) * 8;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r0 + r < t.rows && c0 + c < t.cols) v = *reinterpret_cast<const bf16x8*>(s + (int64_t)(r0 + r) * t.cols + c0 + c);
+        *reinterpret_cast<bf16x8*>(&tile[r][c]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c = p * 32 + (tid >> 3), r = (tid & 7) * 8;      // output row = source column c, 8 source rows r..r+7
+        if (c0 + c < t.cols && r0 + r < t.rows) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[r + e][c];
+            *reinterpret_cast<bf16x8*>(d + (int64_t)(c0 + c) * t.rows + r0 + r) = v;
+        }
+    }
+}
+
+extern "C" int acr_transpose_many_bf16(const void* table, const int32_t* blk_tensor, int32_t nblocks, void* stream) {
+    ACR_CHECK_ARG(table && blk_tensor && nblocks > 0, "acr_transpose_many_bf16: null pointer / empty launch");
+    hipLaunchKernelGGL(transpose_many_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const acr_tr_tensor*)table,
+                       blk_tensor);
+    return acr_check_launch("acr_transpose_many_bf16");
+}

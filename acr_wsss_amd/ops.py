@@ -230,14 +230,69 @@ def wgrad_bias_bf16(dy2, x2):
     return dw, db
 
 
+class WeightTransposes:
+    """(in, out) copies of Linear weights for the input-gradient GEMMs, refreshed in ONE launch (acr_transpose_many_bf16).
+
+    ``refresh()`` is called by the training step's owner right after the optimizer step; a copy is used only while the
+    weight's autograd version equals the one recorded at refresh (an in-place update by anything else makes the consumer
+    fall back to transposing on the fly), so a stale copy can never be read silently."""
+
+    def __init__(self, modules):
+        import numpy as np
+        self.lins = [m for m in modules if isinstance(m, torch.nn.Linear) and m.weight.is_cuda
+                     and m.weight.dtype == torch.bfloat16 and m.weight.shape[0] % 8 == 0 and m.weight.shape[1] % 8 == 0]
+        self.ok = bool(self.lins)
+        if not self.ok:
+            return
+        dev = self.lins[0].weight.device
+        rec = np.zeros(len(self.lins), dtype=[("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("tile0", "<i4"),
+                                              ("tiles_c", "<i4")])
+        bt, t0 = [], 0
+        self.bufs = []
+        for i, m in enumerate(self.lins):
+            rows, cols = m.weight.shape
+            wt = torch.empty((cols, rows), dtype=torch.bfloat16, device=dev)
+            self.bufs.append(wt)
+            tr, tc = (rows + 63) // 64, (cols + 63) // 64
+            rec[i] = (m.weight.data_ptr(), wt.data_ptr(), rows, cols, t0, tc)
+            bt.append(np.full(tr * tc, i, dtype=np.int32))
+            t0 += tr * tc
+        self._ptrs = [m.weight.data_ptr() for m in self.lins]
+        self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        self.blk = torch.from_numpy(np.concatenate(bt)).to(dev)
+        self.nblocks = t0
+
+    @torch.no_grad()
+    def refresh(self):
+        if not self.ok:
+            return
+        if any(m.weight.data_ptr() != p for m, p in zip(self.lins, self._ptrs)):
+            self.ok = False                                   # storages were re-allocated: stop serving copies
+            for m in self.lins:
+                m._acr_wt = None
+            return
+        L.check(L.load().acr_transpose_many_bf16(L.ptr(self.table), L.ptr(self.blk), self.nblocks, L.stream_ptr()),
+                "acr_transpose_many_bf16")
+        for m, wt in zip(self.lins, self.bufs):
+            m._acr_wt, m._acr_wt_ver = wt, m.weight._version
+
+
+def weight_t(weight, owner=None):
+    """weight^T contiguous: the cached copy of ``owner`` (an nn.Linear) when it is current, else a fresh transpose."""
+    wt = getattr(owner, "_acr_wt", None) if owner is not None else None
+    if wt is not None and owner._acr_wt_ver == weight._version and wt.shape[0] == weight.shape[1]:
+        return wt
+    return weight.t().contiguous()
+
+
 class LinearBf16Fn(Function):
     """y = x W^T + b (+ resid) for the attention block's qkv / proj Linears in the bf16 mode, on the hand-written
     MFMA GEMM for forward and input gradient; the weight gradient (a reduction over all tokens) stays on
     hipBLASLt through torch.mm."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, resid, hip_dx=True, hip_dw=True, hip_fwd=True):
-        ctx.hip_dx, ctx.hip_dw = hip_dx, hip_dw
+    def forward(ctx, x, weight, bias, resid, hip_dx=True, hip_dw=True, hip_fwd=True, owner=None):
+        ctx.hip_dx, ctx.hip_dw, ctx.owner = hip_dx, hip_dw, owner
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         r2 = resid.reshape(-1, weight.shape[0]) if resid is not None else None
@@ -260,7 +315,7 @@ class LinearBf16Fn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if ctx.hip_dx and weight.shape[0] % 64 == 0:
-                dx = linear_bf16(dy2, weight.t().contiguous())
+                dx = linear_bf16(dy2, weight_t(weight, ctx.owner))
             else:                                           # contraction length not a multiple of the K tile
                 dx = torch.mm(dy2, weight)
             dx = dx.reshape(*dy.shape[:-1], weight.shape[1])
@@ -272,7 +327,7 @@ class LinearBf16Fn(Function):
                 dw = wgrad_bf16(dy2, x2) if ctx.hip_dw else torch.mm(dy2.t(), x2)
             if want_db:
                 db = colsum_bf16(dy2)
-        return dx, dw, db, (dy if ctx.has_resid else None), None, None, None
+        return dx, dw, db, (dy if ctx.has_resid else None), None, None, None, None
 
 
 def mlp_fusable(x, fc1, fc2):
@@ -287,7 +342,8 @@ class MlpFn(Function):
     multiplied by GELU'(h).  Replaces the separate GELU forward / backward passes over the (tokens x 3072) activations."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, resid):
+    def forward(ctx, x, w1, b1, w2, b2, resid, fc1=None, fc2=None):
+        ctx.fc1, ctx.fc2 = fc1, fc2
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         M, K = x2.shape
@@ -312,19 +368,19 @@ class MlpFn(Function):
         M, Hd = h.shape
         lib = L.load()
         dw2, db2 = wgrad_bias_bf16(dy2, a)
-        w2t = w2.t().contiguous()                             # (hidden, out): dA = dY W2
+        w2t = weight_t(w2, ctx.fc2)                           # (hidden, out): dA = dY W2
         dh = torch.empty_like(h)
         L.check(lib.acr_linear_dgelu_bf16(L.ptr(dy2), dy2.stride(0), L.ptr(w2t), w2t.stride(0), L.ptr(h), h.stride(0), L.ptr(dh),
                                           dh.stride(0), M, Hd, dy2.shape[1], L.stream_ptr()), "acr_linear_dgelu_bf16")
         dw1, db1 = wgrad_bias_bf16(dh, x2)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = linear_bf16(dh, w1.t().contiguous()).reshape(*dy.shape[:-1], w1.shape[1])
-        return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None)
+            dx = linear_bf16(dh, weight_t(w1, ctx.fc1)).reshape(*dy.shape[:-1], w1.shape[1])
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None), None, None
 
 
 def mlp(x, fc1, fc2, resid=None):
-    return MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, resid)
+    return MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, resid, fc1, fc2)
 
 
 def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hip_fwd=True):
@@ -332,7 +388,7 @@ def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hi
     ``hip_dx`` = False leaves the input gradient on hipBLASLt (shapes where the library kernel is faster)."""
     if (use_hip and x.is_cuda and x.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16
             and lin.weight.shape[1] % 64 == 0 and x.is_contiguous()):
-        return LinearBf16Fn.apply(x, lin.weight, lin.bias, resid, hip_dx, hip_dw, hip_fwd)
+        return LinearBf16Fn.apply(x, lin.weight, lin.bias, resid, hip_dx, hip_dw, hip_fwd, lin)
     y = torch.nn.functional.linear(x, lin.weight, lin.bias)
     return y if resid is None else resid + y
 

@@ -76,6 +76,11 @@ class MasterWeights:
                 b.data = b.data.to(torch.bfloat16)
         self.optimizer = optimizer_factory(self.masters)
         self.param_groups = self.optimizer.param_groups
+        # (in, out) copies of the Linear weights for the input-gradient GEMMs: refreshed in one launch after every step
+        from . import ops as _ops
+        self.weight_t = _ops.WeightTransposes(model.modules()) if (self.masters and self.masters[0].is_cuda) else None
+        if self.weight_t is not None:
+            self.weight_t.refresh()
 
     @property
     def global_step(self):
@@ -100,6 +105,8 @@ class MasterWeights:
             torch._foreach_copy_([m.grad for m, _ in live], [p.grad for _, p in live])
         self.optimizer.step()
         torch._foreach_copy_([p for p in self.model_params], self.masters)
+        if self.weight_t is not None:
+            self.weight_t.refresh()
 
     # ---- fused path: one HIP launch updates momentum, fp32 master and bf16 working copy of every parameter ----
     fused = True
@@ -155,6 +162,8 @@ class MasterWeights:
         L.check(lib.acr_sgd_step_bf16(L.ptr(self._sgd_tab), L.ptr(self._sgd_bt), L.ptr(self._sgd_bc), self._sgd_bt.numel(),
                                       float(grp["lr"]), float(grp["momentum"]), L.stream_ptr()), "acr_sgd_step_bf16")
         opt.global_step += 1
+        if self.weight_t is not None:
+            self.weight_t.refresh()
 
 
 def train_step(model, optimizer, img, label, alpha, grad_sync=None, amp_dtype=None):

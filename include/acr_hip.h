@@ -155,6 +155,18 @@ int32_t acr_sgd_chunk_elems(void);
 int acr_sgd_step_bf16(const void* table, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t nblocks, float lr,
                       float momentum, void* stream);
 
+/* ---- Batched transpose: dst_i (cols, rows) = src_i (rows, cols)^T for a table of bf16 matrices in one launch (the
+ * (in, out) copies of the block weights that the input-gradient GEMMs read; refreshed once per optimizer step).
+ * rows and cols multiples of 8; block b transposes 64x64 tile (b - tile0) of tensor blk_tensor[b]. */
+typedef struct acr_tr_tensor {
+    const void* src;
+    void* dst;
+    int32_t rows, cols;
+    int32_t tile0;      /* index of the tensor's first tile in the launch */
+    int32_t tiles_c;    /* ceil(cols / 64) */
+} acr_tr_tensor;
+int acr_transpose_many_bf16(const void* table, const int32_t* blk_tensor, int32_t nblocks, void* stream);
+
 /* ---- LayerNorm of the transformer blocks (models/vision_transformer.py:219-222,299), bf16 (M, C) rows ----
  * C a multiple of 256, <= 1024.  stats: (M*2) fp32 [mean, rstd].  Backward writes dx, dgamma, dbeta in one pass over
  * x and dy; ws: fp32 scratch of acr_layernorm_ws_floats(M, C) floats (per-wave partials, summed in wave order).

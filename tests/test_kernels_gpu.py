@@ -417,3 +417,24 @@ def test_fused_mlp_bf16(M, D, Hd):
     for n, a, b in zip(names, got, want):
         err = (a.double() - b).abs().max().item() / max(b.abs().max().item(), 1e-9)
         assert err <= 2.5e-2, (n, err)
+
+
+def test_weight_transposes_cache():
+    """WeightTransposes: one launch transposes every registered Linear weight (ragged 64x64 tiles included); the cached
+    copy is served only while the weight's version is the recorded one -- an in-place update makes weight_t fall back."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    torch.manual_seed(3)
+    lins = [torch.nn.Linear(i, o).to(dev).bfloat16() for i, o in ((768, 2304), (3072, 768), (72, 200), (64, 64))]
+    cache = ops.WeightTransposes(lins)
+    cache.refresh()
+    for m in lins:
+        wt = ops.weight_t(m.weight, m)
+        assert wt is m._acr_wt and torch.equal(wt, m.weight.t().contiguous())
+    with torch.no_grad():
+        lins[0].weight.mul_(2.0)                              # in-place update bumps the version: the copy is stale
+    wt0 = ops.weight_t(lins[0].weight, lins[0])
+    assert wt0 is not lins[0]._acr_wt and torch.equal(wt0, lins[0].weight.t().contiguous())
+    cache.refresh()
+    assert ops.weight_t(lins[0].weight, lins[0]) is lins[0]._acr_wt
+    assert torch.equal(lins[0]._acr_wt, lins[0].weight.t().contiguous())
