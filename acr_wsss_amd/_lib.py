@@ -33,6 +33,8 @@ _P = ctypes.POINTER(AttnDesc)
 SIGNATURES = {
     "acr_version": (c_int32, []),
     "acr_last_error": (ctypes.c_char_p, []),
+    "acr_set_option": (c_int32, [c_int32, c_int32]),
+    "acr_get_option": (c_int32, [c_int32]),
     "acr_attn_fwd": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                c_void_p]),
     "acr_attn_bwd": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
@@ -89,7 +91,16 @@ SIGNATURES = {
                                       c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
 }
 
+# acr_option (include/acr_hip.h) and the documented A/B environment variable each one is set from at load time
+OPTIONS = {"gemm_variant": (0, "ACR_GEMM_VARIANT"), "gemm_nowide": (1, "ACR_GEMM_NOWIDE"), "gemm_regstage": (2, "ACR_GEMM_REGSTAGE"),
+           "wgrad_variant": (3, "ACR_WGRAD_VARIANT"), "wgrad_waves": (4, "ACR_WGRAD_WAVES"), "dq_variant": (5, "ACR_DQ_VARIANT")}
+
 _lib = None
+
+
+def set_option(name, value):
+    """Select a kernel variant (A/B measurement switch; acr_set_option in include/acr_hip.h)."""
+    check(load().acr_set_option(OPTIONS[name][0], int(value)), "acr_set_option")
 
 
 class AcrHipError(RuntimeError):
@@ -111,6 +122,10 @@ def load():
         if lib.acr_version() != 1:
             raise AcrHipError("libacr_hip.so ABI version %d != 1" % lib.acr_version())
         _lib = lib
+        for name, (code, env) in OPTIONS.items():            # the library itself never reads the environment
+            val = os.environ.get(env)
+            if val is not None:
+                lib.acr_set_option(code, int(val) if val.lstrip("-").isdigit() else 1)
     return _lib
 
 

@@ -23,6 +23,7 @@ void acr_set_error(const char* fmt, ...);
         }                                   \
     } while (0)
 int acr_check_launch(const char* what);
+int32_t acr_opt(int option);          // explicit option table (acr_set_option), api.hip
 
 // ---- XCD-aware block remap --------------------------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap the

@@ -879,7 +879,7 @@ void acr_attn_bwd_bf16(const acr_attn_desc* d, const void* q, const void* k, con
     // 2: 2-wave sweep, 4: 4-wave sweep.  Measured at B=32, H=12, T=785: with G both take 217 us (the sweep is bound by its
     // MFMA -> softmax -> MFMA dependency chain at 2 waves/SIMD, not by load latency); without G (CAM inference, plain
     // attention) the 4-wave sweep is 9 % faster (127 vs 139 us) and uses 168 registers.  Default: by HAS_G.
-    static const int dq_env = getenv("ACR_DQ_VARIANT") ? atoi(getenv("ACR_DQ_VARIANT")) : 0;
+    const int dq_env = acr_opt(ACR_OPT_DQ_VARIANT);
     const int dq_variant = dq_env ? dq_env : (gm ? 2 : 4);
     const dim3 grid4(d->B * d->H * ((d->T + 127) / 128));
 #define ACR_BWD_LAUNCH(HG)                                                                                          \

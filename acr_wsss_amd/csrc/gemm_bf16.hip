@@ -653,16 +653,16 @@ extern "C" int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_
     // / 120 / 142 us on proj, qkv-dX, qkv, fc2, fc1 (820-1030 TF) against 43 / 112 / 126 / 156 / 189 us for the 128x128
     // kernel; the N = 768 shapes fit ONE round of the CUs (79 x 3 = 237 workgroups).  Small problems keep 128x128 tiles.
     const int64_t tilesw = (int64_t)((M + GW_BM - 1) / GW_BM) * ((N + GB_BN - 1) / GB_BN);
-    static const bool env_nowide = getenv("ACR_GEMM_NOWIDE") != nullptr;
+    const bool env_nowide = acr_opt(ACR_OPT_GEMM_NOWIDE) != 0;
     const bool wide_ok = !env_nowide && tilesw >= 200;
     const dim3 gridw((unsigned)tilesw);
     const dim3 grid3((unsigned)(((M + 64 * mt - 1) / (64 * mt)) * ((N + GB_BN - 1) / GB_BN)));
     hipStream_t st = (hipStream_t)stream;
-    static const int env_variant = getenv("ACR_GEMM_VARIANT") ? atoi(getenv("ACR_GEMM_VARIANT")) : 2;   // 2: 128x128x64 2-stage, 3: 256x256x32 4-stage
+    const int env_variant = acr_opt(ACR_OPT_GEMM_VARIANT);   // 2: 128x128x64 2-stage, 3: 256x256x32 4-stage
     // LDS-DMA kernel stores 8-column (16-byte) groups: needs N, ldy, ldr multiples of 8 and 16-byte aligned y/bias/resid
     const bool vec_ok = (N % 8) == 0 && (ldy % 8) == 0 && (ldr % 8) == 0 && ((uintptr_t)y & 15) == 0 &&
                         ((uintptr_t)bias & 15) == 0 && ((uintptr_t)resid & 15) == 0;
-    static const bool env_regstage = getenv("ACR_GEMM_REGSTAGE") != nullptr;       // A/B switch for the older variant
+    const bool env_regstage = acr_opt(ACR_OPT_GEMM_REGSTAGE) != 0;       // A/B switch for the older variant
     const bool use_regstage = env_regstage || !vec_ok;
 #define ACR_GEMM_LAUNCH(BI, RE)                                                                                       \
     if (use_regstage)                                                                                                 \
@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16_wide_kernel(const bf16_t*
 }
 
 static bool wgrad_big_ok(int M, int N, int K) {
-    static const int env = getenv("ACR_WGRAD_VARIANT") ? atoi(getenv("ACR_WGRAD_VARIANT")) : 2;      // 1: 128x128 tiles, 2: 256x256
+    const int env = acr_opt(ACR_OPT_WGRAD_VARIANT);      // 1: 128x128 tiles, 2: 256x256
     // small problems (that would not fill the chip) and widths that are not multiples of 256 stay on the 128x128 kernel
     return env == 2 && (N % 256) == 0 && (K % 256) == 0 && M >= 4096;
 }
@@ -1288,7 +1288,7 @@ extern "C" size_t acr_wgrad_ws_floats(int32_t M, int32_t N, int32_t K) {
 // slabs of the main part (and of the ragged tail) into ws; cs (nullable): per-slab column sums of dy for the fused bias path
 static void wgrad_launch(const WgradPlan& p, const bf16_t* dy, int64_t ldy, const bf16_t* x, int64_t ldx, int M, int N, int K, float* ws,
                          float* cs, hipStream_t st) {
-    static const int tn_waves = getenv("ACR_WGRAD_WAVES") ? atoi(getenv("ACR_WGRAD_WAVES")) : 8;     // 4 or 8 waves per workgroup
+    const int tn_waves = acr_opt(ACR_OPT_WGRAD_WAVES);     // 4 or 8 waves per workgroup
     if (p.big && (tn_waves == 8 || cs)) {
         if (cs)
             hipLaunchKernelGGL(gemm_tn_bf16_wide_kernel<true>, dim3((N / 256) * (K / 256) * p.nsplit), dim3(512), 0, st, dy, ldy, x, ldx,

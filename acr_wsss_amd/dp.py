@@ -18,7 +18,7 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "views", "pending", "work")
+    __slots__ = ("flat", "params", "views", "pending", "work", "index", "late")
 
 
 class GradSync:
@@ -51,9 +51,15 @@ class GradSync:
                 off += pad(p.numel())
                 self._of[p] = b
                 p.register_post_accumulate_grad_hook(self._hook)
-            b.pending, b.work = 0, None
+            b.pending, b.work, b.late = 0, None, False
+            b.index = len(self.buckets)
             self.buckets.append(b)
         self._armed = False
+        # Parameters that got no gradient in the previous step (the reference model has 9 such tensors: bkg_token, norm.*,
+        # head.*, scratch.*) are not waited for: otherwise the bucket they share -- the FIRST one backward fills,
+        # the one with the most overlap to gain -- could only be launched from finish(), after backward.
+        self._unused = set()
+        self.launch_log = []                              # (bucket index, "backward" | "finish") of the last step
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"                     # RCCL has a native AVG; gloo does not
 
@@ -63,12 +69,14 @@ class GradSync:
         a bucket has arrived they are copied into the bucket with ONE multi-tensor launch and ``.grad`` is re-pointed at
         the bucket views.  Slots of parameters that never receive a gradient stay zero (zeroed once, at construction)."""
         for b in self.buckets:
-            b.pending, b.work = len(b.params), None
+            b.pending, b.work, b.late = sum(1 for p in b.params if p not in self._unused), None, False
             for p in b.params:
                 p.grad = None
+        self.launch_log = []
         self._armed = True
 
-    def _launch(self, b):
+    def _launch(self, b, where="backward"):
+        self.launch_log.append((b.index, where))
         live = [(v, p.grad) for p, v in zip(b.params, b.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if live:
             torch._foreach_copy_([v for v, _ in live], [g for _, g in live])
@@ -85,6 +93,11 @@ class GradSync:
         if not self._armed:
             return
         b = self._of[p]
+        if p in self._unused:                             # it does receive a gradient this step after all
+            self._unused.discard(p)
+            if b.work is not None:                        # its bucket has already gone out without it: redo it in finish()
+                b.late = True
+            return
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
@@ -94,12 +107,21 @@ class GradSync:
         tensors), wait for every collective, and turn sums into means."""
         for b in self.buckets:
             if b.work is None:
-                self._launch(b)
+                self._launch(b, "finish")
         for b in self.buckets:
             if b.work:
                 b.work.wait()
                 if not self._avg:
                     b.flat.div_(self.world)
+            if b.late:                                    # a parameter thought unused produced a gradient after the launch:
+                b.work = None                             # every rank holds the same averaged values, so averaging the
+                self._launch(b, "finish")                 # bucket again only adds the late gradient's exchange
+                if b.work:
+                    b.work.wait()
+                    if not self._avg:
+                        b.flat.div_(self.world)
+        # re-learned every step: a tensor that stops (or starts) receiving gradients costs one late exchange, once
+        self._unused = {p for b in self.buckets for p in b.params if p.grad is None}
         self._armed = False
 
 

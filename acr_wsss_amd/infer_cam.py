@@ -40,6 +40,11 @@ def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", 
     patch_acc = [torch.zeros((C, out_hws[i][0], out_hws[i][1]), dtype=torch.float32, device=dev) for i in range(B)]
     old_trunc = model.truncate_at
     model.truncate_at = start_layer if truncate else None
+    # the truncated backward differentiates w.r.t. the tokens entering block `start_layer` only: with the parameters
+    # frozen for the duration of the call no Function computes (and throws away) weight or bias gradients
+    frozen = [p for p in model.parameters() if p.requires_grad] if truncate else []
+    for p in frozen:
+        p.requires_grad_(False)
     try:
         for scale in scales:
             base = F.interpolate(imgs, size=(int(h * scale), int(w * scale)), mode="bilinear", align_corners=False)
@@ -80,6 +85,8 @@ def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", 
                                             out=cam_acc[i])
     finally:
         model.truncate_at = old_trunc
+        for p in frozen:
+            p.requires_grad_(True)
     out = []
     for i in range(B):
         ca, pa = cam_acc[i], patch_acc[i]

@@ -367,14 +367,26 @@ class MlpFn(Function):
             dy2 = dy2.contiguous()
         M, Hd = h.shape
         lib = L.load()
-        dw2, db2 = wgrad_bias_bf16(dy2, a)
+        need = ctx.needs_input_grad                             # (x, w1, b1, w2, b2, resid, ...): CAM inference wants dx only
+        dw1 = db1 = dw2 = db2 = None
+        if need[3] and need[4]:
+            dw2, db2 = wgrad_bias_bf16(dy2, a)
+        elif need[3]:
+            dw2 = wgrad_bf16(dy2, a)
+        elif need[4]:
+            db2 = colsum_bf16(dy2)
         w2t = weight_t(w2, ctx.fc2)                           # (hidden, out): dA = dY W2
         dh = torch.empty_like(h)
         L.check(lib.acr_linear_dgelu_bf16(L.ptr(dy2), dy2.stride(0), L.ptr(w2t), w2t.stride(0), L.ptr(h), h.stride(0), L.ptr(dh),
                                           dh.stride(0), M, Hd, dy2.shape[1], L.stream_ptr()), "acr_linear_dgelu_bf16")
-        dw1, db1 = wgrad_bias_bf16(dh, x2)
+        if need[1] and need[2]:
+            dw1, db1 = wgrad_bias_bf16(dh, x2)
+        elif need[1]:
+            dw1 = wgrad_bf16(dh, x2)
+        elif need[2]:
+            db1 = colsum_bf16(dh)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if need[0]:
             dx = linear_bf16(dh, weight_t(w1, ctx.fc1)).reshape(*dy.shape[:-1], w1.shape[1])
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None), None, None
 

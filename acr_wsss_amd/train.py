@@ -90,6 +90,25 @@ class MasterWeights:
         for p in self.model_params:
             p.grad = None
 
+    # ---- checkpoint / resume: model.state_dict() alone holds only the bf16 ROUNDINGS of the weights ----
+    def state_dict(self):
+        """fp32 masters + optimizer state (momentum buffers, lr schedule position): everything a resume needs on top of
+        (or instead of) ``model.state_dict()``."""
+        return {"masters": [m.detach().clone() for m in self.masters], "optimizer": self.optimizer.state_dict(),
+                "global_step": self.optimizer.global_step}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        assert len(sd["masters"]) == len(self.masters), "checkpoint has %d masters, model %d" % (len(sd["masters"]), len(self.masters))
+        for m, src in zip(self.masters, sd["masters"]):
+            m.copy_(src.to(m.device))
+        self.optimizer.load_state_dict(sd["optimizer"])     # replaces the momentum buffers: the pointer table is stale now
+        self.optimizer.global_step = int(sd["global_step"])
+        self._sgd_tab = None
+        torch._foreach_copy_([p for p in self.model_params], self.masters)      # bf16 working copies <- masters
+        if self.weight_t is not None:
+            self.weight_t.refresh()
+
     @torch.no_grad()
     def step(self):
         if self._fused_ok():
@@ -150,6 +169,14 @@ class MasterWeights:
         hn = host.numpy()
         hn[:, 0] = [0 if p.grad is None else p.grad.data_ptr() for p in self.model_params]
         hn[:, 3] = [p.data_ptr() for p in self.model_params]
+        # masters / momentum buffers may have been replaced since the table was built (optimizer.load_state_dict on
+        # resume does exactly that): every column is refreshed from the live tensors, so a stale pointer cannot survive
+        for i, m in enumerate(self.masters):
+            st = opt.state[m]
+            if st.get("momentum_buffer") is None:
+                st["momentum_buffer"] = torch.zeros_like(m)
+        hn[:, 1] = [m.data_ptr() for m in self.masters]
+        hn[:, 2] = [opt.state[m]["momentum_buffer"].data_ptr() for m in self.masters]
         self._sgd_tab.copy_(host, non_blocking=True)
         self._sgd_evt = torch.cuda.Event()
         self._sgd_evt.record()

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- ACR training-step throughput (BASELINE.json metric) on N MI355X GPUs of one node.
 
+The HEADLINE (`value`, `dtype: "f32"`) is measured at the reference's precision: fp32 end to end (train_acr.py:137,
+autocast(enabled=False)).  The same invocation then runs the bf16 training mode of this build (bf16 tensors + bf16 MFMA,
+fp32 master weights / accumulate / softmax / loss; parity pinned by tests/test_model_gpu.py::test_bf16_train_step_448)
+and reports it as the sub-record `"bf16": {...}` -- never as `value`.
+
     python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1: run directly)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W  (N>1: one rank per GPU, RCCL)
@@ -11,6 +16,7 @@ step.  Workload = BASELINE configs[1]: 448x448, batch 16 per GPU (weak scaling: 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -25,6 +31,9 @@ if ROOT not in sys.path:
 
 FLOP_PER_IMG_448 = 1.1307e12          # SURVEY 6 [probe]: 2 views, fwd+bwd, hybrid-base @448^2
 PEAK_MFMA = {"f32": 157.3e12, "bf16": 2.5e15}   # MI355X_MICROARCH.md: dense matrix peaks
+PRECISION = {"f32": "fp32 end to end (reference precision, exact-fp32 MFMA)",
+             "bf16": "bf16 params/activations/grads + bf16 MFMA, fp32 master weights + fp32 accumulate/softmax/loss"}
+IN_STEP = os.path.join(ROOT, "profiles", "r02_in_step_kernels.json")     # rocprofv3 kernel-trace of this bench, per dtype
 
 
 def parse():
@@ -34,13 +43,15 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU (BASELINE configs[1]: 16)")
     ap.add_argument("--size", type=int, default=448)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("ACR_BENCH_DTYPE", "bf16"))
+    ap.add_argument("--dtype", choices=["both", "f32", "bf16"], default=os.environ.get("ACR_BENCH_DTYPE", "both"),
+                    help="both (default): the fp32 run is the headline (the reference trains in fp32, train_acr.py:137) and "
+                         "the bf16 run rides along as the named sub-record 'bf16'; f32 / bf16: that run only (profiling)")
     ap.add_argument("--classes", type=int, default=20)
     ap.add_argument("--alpha", type=int, default=125)
     ap.add_argument("--amp", choices=["master", "autocast"], default="master",
                     help="bf16 mode: bf16 model + fp32 master weights (default) or torch.autocast")
     ap.add_argument("--channels-last", action="store_true")
-    ap.add_argument("--stock-linear", action="store_true", help="qkv/proj on torch F.linear instead of acr_linear_bf16")
+    ap.add_argument("--stock-linear", action="store_true", help="block Linears on torch F.linear instead of the HIP GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -69,14 +80,30 @@ def time_kernel(fn, iters=10, warm=2):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def roofline_probe(args, dev):
-    """Dominant hand-written kernel of the step at the bench geometry: the attention backward's dK/dV sweep
-    (4 of the 11 T^2 x 64 products per head per layer).  Launched directly through the C ABI and timed with
-    events; algorithmic FLOPs = 4 products x 2*T*T*64 x B*H per launch (DESIGN.md 'kernels')."""
+def _mfma_rec(name, alg_flops, exec_flops, t, peak, extra=None):
+    rec = {"bound": "mfma", "kernel": name, "achieved": round(alg_flops / t / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+           "frac": round(alg_flops / t / peak, 4), "launch_ms": round(t * 1e3, 4), "flops_per_launch": alg_flops,
+           "executed_flops_per_launch": exec_flops, "executed_frac": round(exec_flops / t / peak, 4)}
+    if extra:
+        rec.update(extra)
+    return rec
+
+
+def roofline_probe(args, dev, dtype):
+    """The hand-written kernels of the step, launched one by one through the C ABI at the bench geometry and timed with
+    HIP events on the launch stream.  ALGORITHMIC work per launch:
+      attention forward  : S = q k^T and O = P v             -> 2 products of 2*T*T*64 FLOP per (sample, head)
+      attention backward : dP = dO v^T, dV, dK, dQ           -> 4 products (what autograd's bmm backward executes)
+      Linear / dX / dW   : 2*M*N*K
+    `executed_*` additionally counts what the flash-style kernels recompute (S in both backward sweeps, the head-mean
+    pass of the forward).  `frac` is ALGORITHMIC work / time / dense matrix peak of the dtype.  Returns the record of the
+    kernel that is on top of this round's in-step rocprof profile (profiles/r02_in_step_kernels.json) with the others
+    under `kernels`."""
     from acr_wsss_amd import _lib as L, ops
     lib = L.load()
     B, H, T = 2 * args.batch, 12, (args.size // 16) ** 2 + 1
-    dt = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    peak = PEAK_MFMA[dtype]
     g = torch.Generator(device="cpu").manual_seed(0)
     qkv = torch.randn(B, T, 3 * H * 64, generator=g).to(dev).to(dt)
     d_o = torch.randn(B, T, H * 64, generator=g).to(dev).to(dt)
@@ -101,7 +128,10 @@ def roofline_probe(args, dev):
     t_fwd = time_kernel(fwd)
     t_bwd = time_kernel(bwd)
     unit = 2.0 * T * T * 64 * B * H                      # one T x T x 64 product over all (b, h)
-    fl_fwd, fl_bwd = 3 * unit, 8 * unit                  # fwd: S, PV (+S for head-mean); bwd: 1 + 4 + 3 products
+    kernels = {
+        "acr_attn_bwd": _mfma_rec("acr_attn_bwd (delta + dq + dkdv)", 4 * unit, 8 * unit, t_bwd, peak),
+        "acr_attn_fwd": _mfma_rec("acr_attn_fwd (+ head-mean)", 2 * unit, 3 * unit, t_fwd, peak),
+    }
     # K3 (HBM-bound): forward reads 2 stacks
     Lyr = 12
     a = torch.rand(B, Lyr, T, T, device=dev)
@@ -113,46 +143,63 @@ def roofline_probe(args, dev):
                                         args.size // 16, L.ptr(ws), L.ptr(out2), st), "k3")
     t_k3 = time_kernel(k3)
     k3_bytes = 4.0 * B * Lyr * T * T
-    # second MFMA kernel of the step by time: the weight-gradient GEMM dW = dY^T X (fc1's shape), bf16 mode only
-    wg = None
-    if args.dtype == "bf16":
-        Mtok, Nw, Kw = B * T, 3072, 768
-        dyw = torch.randn(Mtok, Nw, generator=g).to(dev).bfloat16()
-        xw = torch.randn(Mtok, Kw, generator=g).to(dev).bfloat16()
+    kernels["acr_consistency_fwd"] = {"bound": "hbm", "achieved": round(k3_bytes / t_k3 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                      "frac": round(k3_bytes / t_k3 / 8e12, 4), "launch_ms": round(t_k3 * 1e3, 4),
+                                      "bytes_per_launch": k3_bytes}
+    del a, ws
+    # the block Linears at the bench's token count: fc1's three GEMMs (forward, input gradient, weight gradient)
+    Mtok, Nw, Kw = B * T, 3072, 768
+    x = torch.randn(Mtok, Kw, generator=g).to(dev).to(dt)
+    w = (torch.randn(Nw, Kw, generator=g) * Kw ** -0.5).to(dev).to(dt)
+    bias = torch.zeros(Nw, device=dev, dtype=dt)
+    dy = torch.randn(Mtok, Nw, generator=g).to(dev).to(dt)
+    fl = 2.0 * Mtok * Nw * Kw
+    if dtype == "bf16":
+        y = torch.empty(Mtok, Nw, dtype=dt, device=dev)
+        wt = w.t().contiguous()
+        dx = torch.empty(Mtok, Kw, dtype=dt, device=dev)
         wsw = torch.empty(lib.acr_wgrad_ws_floats(Mtok, Nw, Kw), dtype=torch.float32, device=dev)
-        dww = torch.empty(Nw, Kw, dtype=torch.bfloat16, device=dev)
-
-        def wgrad():
-            L.check(lib.acr_wgrad_bf16(L.ptr(dyw), Nw, L.ptr(xw), Kw, Mtok, Nw, Kw, L.ptr(wsw), L.ptr(dww), st), "wgrad")
-        t_wg = time_kernel(wgrad)
-        wg = {"bound": "mfma", "achieved": round(2.0 * Mtok * Nw * Kw / t_wg / 1e12, 2), "peak": PEAK_MFMA["bf16"] / 1e12,
-              "unit": "TFLOP/s", "frac": round(2.0 * Mtok * Nw * Kw / t_wg / PEAK_MFMA["bf16"], 4),
-              "launch_ms": round(t_wg * 1e3, 3), "shape": "dW(3072x768) over %d tokens, incl. slab reduction" % Mtok}
-    peak = PEAK_MFMA[args.dtype] if args.dtype == "f32" else PEAK_MFMA["bf16"]
-    ach = fl_bwd / t_bwd / 1e12
-    # HBM traffic of the same launches from the committed rocprofv3 PMC passes (bench.py --probe-only under
-    # --pmc FETCH_SIZE / --pmc WRITE_SIZE, gfx950 x2 fetch correction applied); only valid for the default geometry
-    traffic = None
+        dww = torch.empty(Nw, Kw, dtype=dt, device=dev)
+        t = time_kernel(lambda: L.check(lib.acr_linear_bf16(L.ptr(x), Kw, L.ptr(w), Kw, L.ptr(bias), None, 0, L.ptr(y), Nw, Mtok, Nw, Kw, st), "lin"))
+        kernels["acr_linear_bf16"] = _mfma_rec("gemm_nt_bf16_wide (fc1 forward, %dx%dx%d)" % (Mtok, Nw, Kw), fl, fl, t, peak)
+        t = time_kernel(lambda: L.check(lib.acr_linear_bf16(L.ptr(dy), Nw, L.ptr(wt), Nw, None, None, 0, L.ptr(dx), Kw, Mtok, Kw, Nw, st), "dx"))
+        kernels["acr_linear_bf16_dx"] = _mfma_rec("gemm_nt_bf16_wide (fc1 input gradient)", fl, fl, t, peak)
+        t = time_kernel(lambda: L.check(lib.acr_wgrad_bf16(L.ptr(dy), Nw, L.ptr(x), Kw, Mtok, Nw, Kw, L.ptr(wsw), L.ptr(dww), st), "wgrad"))
+        kernels["acr_wgrad_bf16"] = _mfma_rec("gemm_tn_bf16_wide + slab reduction (fc1 weight gradient)", fl, fl, t, peak)
+    elif hasattr(ops, "gemm_f32_raw"):
+        y = torch.empty(Mtok, Nw, dtype=dt, device=dev)
+        dx = torch.empty(Mtok, Kw, dtype=dt, device=dev)
+        dww = torch.empty(Nw, Kw, dtype=dt, device=dev)
+        for key, name, call in (
+                ("acr_gemm_f32_nt", "gemm_f32 NT (fc1 forward, %dx%dx%d)" % (Mtok, Nw, Kw), lambda: ops.gemm_f32_raw("nt", x, w, y, bias=bias)),
+                ("acr_gemm_f32_nn", "gemm_f32 NN (fc1 input gradient)", lambda: ops.gemm_f32_raw("nn", dy, w, dx)),
+                ("acr_gemm_f32_tn", "gemm_f32 TN (fc1 weight gradient)", lambda: ops.gemm_f32_raw("tn", dy, x, dww))):
+            t = time_kernel(call, iters=5)
+            kernels[key] = _mfma_rec(name, fl, fl, t, peak)
+    # in-step rocprofv3 durations of this round (same command, kernel-trace; scripts/step_breakdown.py), and the PMC traffic
+    in_step, traffic, top = {}, None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            if args.dtype == "bf16" and args.batch == 16 and args.size == 448:
-                traffic = json.load(f)["acr_attn_bwd_bytes_per_launch"]
+        with open(IN_STEP) as f:
+            rec = json.load(f).get(dtype, {})
+        if (args.batch, args.size) == (16, 448):
+            in_step, traffic, top = rec.get("kernels", {}), rec.get("traffic_bytes_per_launch"), rec.get("top")
     except OSError:
         pass
-    return {
-        "bound": "mfma", "kernel": "acr_attn_bwd (delta + dkdv + dq)", "achieved": round(ach, 2),
-        "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / (peak / 1e12), 4), "traffic": traffic,
-        "launch_ms": round(t_bwd * 1e3, 3), "flops_per_launch": fl_bwd,
-        "attn_fwd": {"achieved": round(fl_fwd / t_fwd / 1e12, 2), "launch_ms": round(t_fwd * 1e3, 3)},
-        "consistency_fwd": {"bound": "hbm", "achieved": round(k3_bytes / t_k3 / 1e9, 1), "peak": 8000.0,
-                            "unit": "GB/s", "frac": round(k3_bytes / t_k3 / 8e12, 4), "launch_ms": round(t_k3 * 1e3, 3)},
-        "wgrad_gemm": wg,
-    }
+    for k, v in in_step.items():
+        if k in kernels:
+            kernels[k]["in_step_us"] = v
+    if top not in kernels:                               # no profile committed yet for this dtype: slowest MFMA group of the probe
+        top = max((k for k in kernels if kernels[k]["bound"] == "mfma"), key=lambda k: kernels[k]["launch_ms"])
+    head = dict(kernels[top])
+    head["traffic"] = traffic.get(top) if isinstance(traffic, dict) else None
+    head["kernels"] = {k: v for k, v in kernels.items() if k != top}
+    return head
 
 
 def cpu_baseline(args):
-    """The CPU oracle (oracle/acr_oracle.py, a parity-pinned restatement of the reference) timed on this
-    host's cores on a bounded sample of the same workload: 1 step at 448^2 with a small batch."""
+    """The CPU oracle (oracle/acr_oracle.py, a parity-pinned restatement of the reference) timed on this host's cores on
+    a bounded sample of the same workload: train steps at the bench resolution with batch 1 -- one warm-up at the SAME
+    shape, then 3 timed steps, median reported."""
     from oracle import acr_oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from recipe import recipe_state_dict
@@ -168,21 +215,23 @@ def cpu_baseline(args):
     sd = {k: v.requires_grad_(True) for k, v in recipe_state_dict(layout, 0).items()}
     bsz = 1
     g = torch.Generator().manual_seed(1)
-    warm = torch.randn(1, 3, 64, 64, generator=g)
-    lab = torch.zeros(1, 20)
-    lab[:, 0] = 1
-    O.train_step(sd, O.HYBRID_BASE, warm, lab, args.alpha)[0].backward()
-    log("cpu_baseline: warm-up step (64x64) done")
     img = torch.randn(bsz, 3, args.size, args.size, generator=g)
     lab = torch.zeros(bsz, 20)
     lab[:, 0] = 1
-    t0 = time.time()
-    loss, _ = O.train_step(sd, O.HYBRID_BASE, img, lab, args.alpha)
-    loss.backward()
-    dt = time.time() - t0
-    return {"value": round(bsz / dt, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 oracle train step (fwd mirror + ACR loss + bwd), hybrid-base %dx%d, batch %d, fp32, %.1f s"
-                      % (args.size, args.size, bsz, dt)}
+    times = []
+    for it in range(4):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.time()
+        loss, _ = O.train_step(sd, O.HYBRID_BASE, img, lab, args.alpha)
+        loss.backward()
+        times.append(time.time() - t0)
+        log("cpu_baseline: step %d (%s) %.2f s" % (it, "warm-up" if it == 0 else "timed", times[-1]))
+    timed = sorted(times[1:])
+    med = timed[len(timed) // 2]
+    return {"value": round(bsz / med, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle train step (fwd mirror + ACR loss + bwd), hybrid-base %dx%d, batch %d, fp32: 1 warm-up at the same shape "
+                      "+ 3 timed, median %.2f s (min %.2f, max %.2f)" % (args.size, args.size, bsz, med, timed[0], timed[-1])}
 
 
 def log(msg):
@@ -191,6 +240,65 @@ def log(msg):
 
 
 _T0 = time.time()
+
+
+def run_mode(args, dtype, world, rank, dev):
+    """Build the model in `dtype`, do W untimed + K timed steps (barrier + synchronize on both sides, max over ranks)."""
+    from acr_wsss_amd.DPT.ACR import ACR
+    from acr_wsss_amd.train import MasterWeights, PolyOptimizer, train_step
+    from acr_wsss_amd.dp import GradSync, broadcast_parameters
+
+    torch.manual_seed(0)
+    model = ACR(num_classes=args.classes, backbone_name="vitb_hybrid", use_pretrain=False,
+                channels_last=args.channels_last).to(dev)
+    if args.channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    model.train()
+    broadcast_parameters(model)
+    img, label = make_batch(args.batch, args.size, args.classes, rank, dev)
+    amp = None
+    if dtype == "bf16" and args.amp == "master":
+        opt = MasterWeights(model, lambda ps: PolyOptimizer(ps, lr=0.05, weight_decay=5e-4, max_step=100000))
+        img = img.to(torch.bfloat16)
+    else:
+        opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=100000)
+        amp = torch.bfloat16 if dtype == "bf16" else None
+    sync = GradSync(model.parameters()) if (world > 1 or os.environ.get("ACR_FORCE_GRADSYNC") == "1") else None
+
+    def step():
+        return train_step(model, opt, img, label, args.alpha, grad_sync=sync, amp_dtype=amp)
+
+    torch.cuda.reset_peak_memory_stats()
+    log("%s: model built; warmup" % dtype)
+    for i in range(args.warmup):
+        loss, _ = step()
+        torch.cuda.synchronize()
+        log("%s: warmup step %d done" % (dtype, i))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    log("%s: timed %d steps in %.3f s" % (dtype, args.steps, elapsed))
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    value = args.batch * world * args.steps / elapsed
+    rec = {"value": round(value, 3), "unit": "img/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3), "dtype": dtype,
+           "precision": PRECISION[dtype] if not (dtype == "bf16" and args.amp == "autocast") else "torch.autocast(bf16)",
+           "loss": round(float(loss.detach()), 5),
+           "step_mfma_frac": round(value * FLOP_PER_IMG_448 * (args.size / 448.0) ** 2 / (world * PEAK_MFMA[dtype]), 4),
+           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    del model, opt, sync, step, img, label, loss
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
@@ -216,82 +324,39 @@ def main():
     tuned = enable_tuned_gemms()                           # shipped hipBLASLt selections for the three library GEMMs
     if os.environ.get("ACR_MIOPEN_FIND", "0") == "1":      # experiment: let MIOpen benchmark its solvers per conv shape
         torch.backends.cudnn.benchmark = True
-    if args.probe_only:
-        print(json.dumps(roofline_probe(args, dev)), flush=True)
-        return
-
-    from acr_wsss_amd.DPT.ACR import ACR
-    from acr_wsss_amd.train import MasterWeights, PolyOptimizer, train_step
-    from acr_wsss_amd.dp import GradSync, broadcast_parameters
-
-    torch.manual_seed(0)
-    model = ACR(num_classes=args.classes, backbone_name="vitb_hybrid", use_pretrain=False,
-                channels_last=args.channels_last).to(dev)
-    if args.channels_last:
-        model = model.to(memory_format=torch.channels_last)
     if args.stock_linear:
         from acr_wsss_amd.backbone import Attention
         Attention.hip_linear = False
-    model.train()
-    broadcast_parameters(model)
-    img, label = make_batch(args.batch, args.size, args.classes, rank, dev)
-    amp = None
-    if args.dtype == "bf16" and args.amp == "master":
-        opt = MasterWeights(model, lambda ps: PolyOptimizer(ps, lr=0.05, weight_decay=5e-4, max_step=100000))
-        img = img.to(torch.bfloat16)
-    else:
-        opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=100000)
-        amp = torch.bfloat16 if args.dtype == "bf16" else None
-    sync = GradSync(model.parameters()) if (world > 1 or os.environ.get("ACR_FORCE_GRADSYNC") == "1") else None
+    modes = ["f32", "bf16"] if args.dtype == "both" else [args.dtype]
+    if args.probe_only:
+        print(json.dumps({m: roofline_probe(args, dev, m) for m in modes}), flush=True)
+        return
 
-    def step():
-        return train_step(model, opt, img, label, args.alpha, grad_sync=sync, amp_dtype=amp)
-
-    log("model built; warmup")
-    for i in range(args.warmup):
-        loss, _ = step()
-        torch.cuda.synchronize()
-        log("warmup step %d done" % i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    log("timed %d steps in %.3f s" % (args.steps, elapsed))
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    loss_val = float(loss.detach())
-
+    runs = {m: run_mode(args, m, world, rank, dev) for m in modes}
     if rank == 0:
-        imgs = args.batch * world * args.steps
-        value = imgs / elapsed
+        head = runs[modes[0]]                              # fp32 unless a single dtype was asked for
+        std = (args.size, args.batch, args.classes) == (448, 16, 20)
         out = {
-            "metric": "img/s ACR-ViT-hybrid-base %dx%d train step" % (args.size, args.size), "value": round(value, 3), "unit": "img/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "precision": ("bf16 params/activations/grads, fp32 master weights + fp32 softmax/loss" if (args.dtype == "bf16" and args.amp == "master")
-                          else ("torch.autocast(bf16)" if args.dtype == "bf16" else "fp32 end to end (reference precision)")),
-            "config": {"workload": "%sViT-hybrid-base (DPT) %dx%d, batch %d per GPU, ACR train step "
-                                   "(2 views, fwd+bwd+SGD)" % ("BASELINE configs[1]: " if (args.size, args.batch, args.classes) == (448, 16, 20) else "",
-                                                               args.size, args.size, args.batch),
+            "metric": "img/s ACR-ViT-hybrid-base %dx%d train step" % (args.size, args.size), "value": head["value"], "unit": "img/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+            "precision": head["precision"],
+            "config": {"workload": "%sViT-hybrid-base (DPT) %dx%d, batch %d per GPU, ACR train step (2 views, fwd+bwd+SGD)"
+                                   % ("BASELINE configs[1]: " if std else "", args.size, args.size, args.batch),
                        "global_batch": args.batch * world, "classes": args.classes, "alpha": args.alpha,
                        "parallelism": "dp%d" % world, "tokens_per_view": (args.size // 16) ** 2 + 1},
-            "loss": round(loss_val, 5),
-            "step_mfma_frac": round(value * FLOP_PER_IMG_448 * (args.size / 448.0) ** 2 / (world * PEAK_MFMA[args.dtype]), 4),
-            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            "loss": head["loss"], "step_mfma_frac": head["step_mfma_frac"], "peak_mem_gb": head["peak_mem_gb"],
             "tuned_library_gemms": bool(tuned),
         }
         if world == 1 and not args.no_roofline:
-            out["roofline"] = roofline_probe(args, dev)
-            log("roofline probe done")
+            out["roofline"] = roofline_probe(args, dev, head["dtype"])
+            log("roofline probe (%s) done" % head["dtype"])
+        for m in modes[1:]:
+            sub = dict(runs[m])
+            if world == 1 and not args.no_roofline:
+                sub["roofline"] = roofline_probe(args, dev, m)
+                log("roofline probe (%s) done" % m)
+            out[m] = sub
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -9,7 +9,9 @@
  * Conventions (all entry points):
  *   - plain C, no torch types; device pointers are raw `void*` / `float*` owned by the caller
  *   - work is enqueued on `stream` (a hipStream_t passed as void*); no hidden synchronisation,
- *     no allocation, no global mutable state -> safe to capture into a hipGraph, re-entrant
+ *     no allocation -> safe to capture into a hipGraph, re-entrant.  The ONLY process-wide state is
+ *     the explicit option table below (acr_set_option): kernel-variant selectors for A/B measurements,
+ *     atomically readable, never read from the environment by the library itself
  *   - returns 0 on success, a negative acr_status on failure; acr_last_error() gives a
  *     thread-local message for the last failure on the calling thread
  *   - tensors are row-major; "stride" arguments are in ELEMENTS of the tensor's dtype
@@ -58,6 +60,22 @@ typedef struct acr_attn_desc {
 
 int         acr_version(void);
 const char* acr_last_error(void);
+
+/* Kernel-variant selectors (A/B measurement switches; defaults = the measured-fastest settings).
+ * Process-wide, set explicitly by the host (acr_wsss_amd/_lib.py maps the documented ACR_* environment variables
+ * onto these calls at load time); results are identical under every setting up to the documented tolerances.
+ * acr_set_option returns ACR_ERR_INVALID for an unknown option; acr_get_option returns INT32_MIN for one. */
+typedef enum acr_option {
+    ACR_OPT_GEMM_VARIANT = 0,   /* acr_linear_bf16: 2 = by size (128x128 LDS-DMA / 320x256 8-wave), 3 = 256x256 4-wave, 4 = always 320x256 */
+    ACR_OPT_GEMM_NOWIDE = 1,    /* 1: never take the 320x256 8-wave kernel */
+    ACR_OPT_GEMM_REGSTAGE = 2,  /* 1: register-staged 128x128 kernel (oldest variant) */
+    ACR_OPT_WGRAD_VARIANT = 3,  /* acr_wgrad_bf16: 1 = 128x128 tiles, 2 = 256x256 */
+    ACR_OPT_WGRAD_WAVES = 4,    /* 4 or 8 waves per 256x256 workgroup */
+    ACR_OPT_DQ_VARIANT = 5,     /* acr_attn_bwd (bf16) dQ sweep: 0 = by presence of G, 2 = 2-wave, 4 = 4-wave */
+    ACR_OPT_COUNT_
+} acr_option;
+int     acr_set_option(int32_t option, int32_t value);
+int32_t acr_get_option(int32_t option);
 
 /* ---- attention (models/vision_transformer.py:198-214 `Attention.forward`, minus the two Linears) ----
  * O = softmax(q k^T * scale) v without materialising P.  lse2 (B,H,T) fp32 receives the row

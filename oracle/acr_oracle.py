@@ -290,7 +290,8 @@ def infer_image(sd, cfg, img, label, out_hw, start_layer=10, func="grad", aff=Tr
     cmin, cmax = csum.min((1, 2), keepdims=True), csum.max((1, 2), keepdims=True)
     cnorm = (csum - cmin) / (cmax - cmin + 1e-6)
     keep = [ci for ci in range(C) if label[0, ci] > 1e-5]
-    return {ci: cnorm[ci] for ci in keep}, {ci: pnorm[ci] for ci in keep}, np.stack(rows)
+    rows_out = np.stack(rows) if len({r.shape for r in rows}) == 1 else rows      # ragged over scales
+    return {ci: cnorm[ci] for ci in keep}, {ci: pnorm[ci] for ci in keep}, rows_out
 
 
 # --------------------------------------------------------------------------------------------

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from recipe import make_inputs
 from acr_wsss_amd.infer_cam import infer_cam_image
-from acr_wsss_amd.selfcheck import _recipe_model
+from __graft_entry__ import _recipe_model
 dev = torch.device("cuda:0")
 model, _ = _recipe_model(dev); model.eval()
 img, _ = make_inputs(1, 96, 20, 5)

@@ -29,9 +29,11 @@ def recipe_sd(kind="hybrid", seed=0):
     from recipe import recipe_state_dict
     key = (kind, seed)
     if key not in _SD_CACHE:
-        fn = "state_dict_layout.json" if kind == "hybrid" else "state_dict_layout_tiny.json"
+        fn = "state_dict_layout_tiny.json" if kind == "tiny" else "state_dict_layout.json"
         with open(os.path.join(GOLDEN, fn)) as f:
             layout = json.load(f)
+        if kind == "coco":                                  # train_acr_coco.py:91: ACR(num_classes=80) -- only the head differs
+            layout["cls_head.weight"], layout["cls_head.bias"] = [80, 768], [80]
         _SD_CACHE[key] = recipe_state_dict(layout, seed)
     return _SD_CACHE[key]
 
@@ -44,6 +46,26 @@ def hybrid_sd():
 @pytest.fixture(scope="session")
 def tiny_sd():
     return recipe_sd("tiny")
+
+
+def seed_planes(cams, t, shape):
+    """(1 + n, h, w) planes evaluation.py:27-33 takes the argmax over, restricted to the classes present."""
+    return np.stack([np.full(shape, t, np.float32)] + [cams[c] for c in sorted(cams)])
+
+
+def assert_seeds_exact_or_tie(got_seed, ref_seed, ref_cams, t, cam_err, what=""):
+    """north_star: argmax seeds bit-exact.  A pixel may differ only where the reference's own decision is an fp tie:
+    every plane moved by at most ``cam_err`` (the measured max |CAM - reference CAM|), so the argmax can only change
+    where the reference's top-1 / top-2 margin is <= 2 * cam_err.  Anything else fails; ties are printed."""
+    if np.array_equal(got_seed, ref_seed):
+        return 0
+    diff = got_seed != ref_seed
+    planes = np.sort(seed_planes(ref_cams, t, ref_seed.shape), axis=0)
+    margin = (planes[-1] - planes[-2])[diff]
+    print("seed pixels differing %s t=%.1f: %d of %d, reference margins max %.3e (measured CAM error %.3e)"
+          % (what, t, int(diff.sum()), diff.size, float(margin.max()), cam_err))
+    assert float(margin.max()) <= 2.0 * cam_err + 1e-7, (what, t, float(margin.max()), cam_err)
+    return int(diff.sum())
 
 
 def has_gpu():

