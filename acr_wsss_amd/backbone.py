@@ -217,6 +217,9 @@ class Mlp(nn.Module):
         # on the hand-written split-M TN GEMM / column-sum kernels (scripts/bench_gemm.py)
         if Mlp.fused and Attention.hip_linear and isinstance(self.act, nn.GELU) and ops.mlp_fusable(x, self.fc1, self.fc2):
             return ops.mlp(x, self.fc1, self.fc2, resid)     # GELU / GELU' inside the GEMM epilogues
+        if (Mlp.fused and Attention.hip_linear and isinstance(self.act, nn.GELU) and ops.mlp_f32_usable(x, self.fc1, self.fc2)
+                and not torch.is_autocast_enabled()):
+            return ops.mlp_f32(x, self.fc1, self.fc2, resid)  # reference precision: exact-fp32 MFMA GEMMs, same fusion
         lib = Mlp.mlp_on_lib                                 # A/B: fc1 forward and the MLP input gradients on hipBLASLt
         h = self.act(ops.linear_or_hip(x, self.fc1, None, Attention.hip_linear, hip_dx=not lib, hip_fwd=not lib))
         return ops.linear_or_hip(h, self.fc2, resid, Attention.hip_linear, hip_dx=not lib, hip_fwd=Mlp.fc2_hip_fwd)

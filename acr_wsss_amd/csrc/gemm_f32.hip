@@ -1,0 +1,500 @@
+// fp32 GEMMs of the transformer blocks at the REFERENCE precision (train_acr.py:137 runs fp32 end to end):
+//   NT  y  = x W^T + b (+ resid)      models/vision_transformer.py:158-164 (fc1, fc2), :200 (qkv), :212 (proj)
+//   NN  dx = dy W                      their input gradients
+//   TN  dW = dy^T x, db = colsum(dy)   their weight / bias gradients (contraction over all tokens, split over workgroups)
+// on v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (a k-ordered fmaf chain, MI355X_MICROARCH.md "Matrix
+// cores"), 64 FLOP/clk/SIMD = 157 TFLOP/s.
+//
+// Design for gfx950.  The fp32 MFMA needs ONE operand register per 4096 FLOP, i.e. 1/8 of the operand bytes per cycle of
+// the bf16 32x32x16 form, so neither LDS bandwidth nor the L2 -> LDS path limits it (128x128 tiles: 1 ds_read_b128 per 4
+// MFMAs = 256 cycles; 32 KiB of operands per 4096 MFMA cycles per workgroup).  What matters instead is (a) never leaving
+// the matrix pipe idle and (b) tile quantisation: a 25 120-token activation against N = 768 is 591 tiles of 128x256 but
+// only 297 of 256x256 for 256 CUs.  Hence: 128x128x32 tiles, 256 threads = 4 waves of 64x64 (4 accumulators of 16
+// registers), TWO workgroups per CU so that each SIMD holds two waves from different workgroups: while one sits in its
+// barrier / LDS refill the other issues MFMAs.  Operands are staged global -> registers -> LDS one K-chunk ahead (the global
+// loads of chunk c+1 are in flight during the 64 MFMAs of chunk c) with two LDS buffers and one barrier per chunk.
+//
+// Operand layouts.  "KC" = contraction index contiguous in memory (x, W in NT): LDS image [i][k] with a 36-float pitch --
+// ds_read_b128 fragment reads are bank-conflict free for every 16-lane group of the instruction (36*r mod 64 is a
+// permutation of the 16 four-bank slots over any 16 consecutive r).  "KS" = contraction index strided (W in NN, dy and x
+// in TN): LDS image [k][i], fragment = 4 ds_read_b32 of 32 consecutive floats.  No transposed copies of any weight.
+// The 32x32x2 MFMA sums over k in any order as long as A and B agree: lane half h takes k = 8q + 4h + s of a chunk in
+// step (q, s), which is what makes one 16-byte read feed four MFMAs.
+#include <math.h>
+
+#include "acr_common.h"
+
+#define F_BM 128
+#define F_BN 128
+#define F_BK 32
+#define F_PKC 36                 // [i][k] pitch (floats)
+#define F_PKS 128                // [k][i] pitch (floats)
+#define F_STAGE (F_BM * F_PKC)   // floats per operand per stage (>= F_BK * F_PKS = 4096)
+
+struct GemmF32Args {
+    const float* a; int64_t lda;
+    const float* b; int64_t ldb;
+    const float* bias;             // (N) or null
+    const float* aux; int64_t ldaux;   // resid (ACT 0) / saved pre-activation h (ACT 2), (M,N) or null
+    float* c; int64_t ldc;
+    float* c2;                     // ACT 1: GELU(c), same pitch
+    float* cs;                     // TN: per-split column sums of A (bias gradient slabs) or null
+    int M, N, K;
+    int tiles_m, tiles_n, nsplit, kps;   // kps: contraction elements per split (multiple of F_BK)
+#ifdef LAB_STAMP
+    unsigned long long* stamp;
+#endif
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;
+    return cdf + x * pdf;
+}
+
+// one K-chunk of one operand, global -> registers (4 float4 per thread), addresses clamped into the matrix so that every
+// load is unconditional and nothing touches the loaded registers before store_chunk (the loads stay in flight across the
+// chunk's MFMAs).  KC: rows = the operand's non-contraction index, k contiguous; KS: rows = k, 128 contiguous elements.
+template <bool KC>
+__device__ __forceinline__ void load_chunk(f32x4 (&r)[4], const float* __restrict__ p, int64_t ld, int i0, int dim, int k0,
+                                           int kend, int tid) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int f = tid + 256 * ps;
+        if (KC) {
+            const int i = min(i0 + (f >> 3), dim - 1), k = min(k0 + 4 * (f & 7), kend - 4);
+            r[ps] = *reinterpret_cast<const f32x4*>(p + (int64_t)i * ld + k);
+        } else {
+            const int k = min(k0 + (f >> 5), kend - 1), i = min(i0 + 4 * (f & 31), dim - 4);
+            r[ps] = *reinterpret_cast<const f32x4*>(p + (int64_t)k * ld + i);
+        }
+    }
+}
+
+// registers -> LDS; contraction indices at or beyond kend are stored as zeros (only the last chunk of a split has any)
+template <bool KC>
+__device__ __forceinline__ void store_chunk(float* __restrict__ s, f32x4 (&r)[4], int k0, int kend, int tid) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int f = tid + 256 * ps;
+        if (KC) {
+            if (k0 + 4 * (f & 7) >= kend) r[ps] = z;
+            *reinterpret_cast<f32x4*>(s + (f >> 3) * F_PKC + 4 * (f & 7)) = r[ps];
+        } else {
+            if (k0 + (f >> 5) >= kend) r[ps] = z;
+            *reinterpret_cast<f32x4*>(s + (f >> 5) * F_PKS + 4 * (f & 31)) = r[ps];
+        }
+    }
+}
+
+// fragment of 32 rows starting at `base` for k-group q of the chunk: v[s] = T[base + r][8q + 4h + s]
+template <bool KC>
+__device__ __forceinline__ f32x4 read_frag(const float* __restrict__ s, int base, int q, int r, int h) {
+    if (KC) return *reinterpret_cast<const f32x4*>(s + (base + r) * F_PKC + 8 * q + 4 * h);
+    const float* p = s + (8 * q + 4 * h) * F_PKS + base + r;
+    f32x4 v = {p[0], p[F_PKS], p[2 * F_PKS], p[3 * F_PKS]};
+    return v;
+}
+
+// epilogue of one wave's 64x64 block (rows mb.., columns nb..): lane (r, h), register e of a 32x32 accumulator = row
+// krow(e, h), column r.  EDGE = false: the tile is interior, every access is unconditional (loads batch, no branches).
+template <int ACT, bool EDGE>
+__device__ __forceinline__ void epilogue_f32(const GemmF32Args& g, f32x16 (&acc)[2][2], int mb, int nb, int r, int h) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = nb + j * 32 + r;
+        const bool cok = !EDGE || col < g.N;
+        const float bj = (ACT != 2 && g.bias && cok) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float x[16];
+            if (ACT == 2 || (ACT == 0 && g.aux)) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = mb + i * 32 + acr_krow(e, h);
+                    x[e] = (!EDGE || (row < g.M && cok)) ? g.aux[(int64_t)row * g.ldaux + col] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = mb + i * 32 + acr_krow(e, h);
+                if (EDGE && !(row < g.M && cok)) continue;
+                float v = acc[i][j][e] + bj;
+                float* cp = g.c + (int64_t)row * g.ldc + col;
+                if (ACT == 0) {
+                    *cp = g.aux ? v + x[e] : v;
+                } else if (ACT == 1) {
+                    *cp = v;
+                    g.c2[(int64_t)row * g.ldc + col] = gelu_f(v);
+                } else {
+                    *cp = v * dgelu_f(x[e]);
+                }
+            }
+        }
+    }
+}
+
+// ACT: 0 = (+bias)(+resid), 1 = c = h, c2 = GELU(h) with h = acc + bias, 2 = c = acc * GELU'(aux), 3 = split slab (no epilogue)
+template <bool A_KC, bool B_KC, int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * F_STAGE];      // [buf][A|B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int t = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
+    const int split = t / ntile, tt = t - split * ntile;
+    const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
+    const int m0 = tm * F_BM, n0 = tn * F_BN;
+    const int kbeg = split * g.kps, kend = min(g.K, kbeg + g.kps);
+
+#ifdef LAB_STAMP
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // Register sets 0 / 1 hold the chunks in flight from global memory.  Chunk c is computed from LDS buffer c & 1 while
+    // chunk c + 1 (loaded during chunk c - 1) waits in set (c + 1) & 1 and the loads of chunk c + 2 are issued into set
+    // c & 1: every load has TWO chunks of MFMAs (>= 8192 matrix-pipe cycles) to land before its LDS store.
+    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};          // TN bias gradient: this thread's column sums of its A chunks (KS layout)
+    const bool want_cs = ACT == 3 && !A_KC && g.cs && tn == 0;
+    auto add_cs = [&](f32x4 (&x)[4]) {             // after store_chunk: the K tail is already zeroed in x
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[e] += x[ps][e];
+    };
+    auto compute = [&](int buf) {
+        const float* sa = smem + buf * 2 * F_STAGE;
+        const float* sb = sa + F_STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = read_frag<A_KC>(sa, wm * 64 + i * 32, q, r, h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = read_frag<B_KC>(sb, wn * 64 + j * 32, q, r, h);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+        }
+    };
+    // one chunk: issue the loads of chunk k0 + 2 BK into (la, lb), compute chunk k0 from LDS[buf], then move chunk
+    // k0 + BK from (sa_, sb_) to LDS[buf ^ 1]
+    auto step = [&](f32x4 (&la)[4], f32x4 (&lb)[4], f32x4 (&sa_)[4], f32x4 (&sb_)[4], int k0, int buf) {
+        if (k0 + 2 * F_BK < kend) {
+            load_chunk<A_KC>(la, g.a, g.lda, m0, g.M, k0 + 2 * F_BK, kend, tid);
+            load_chunk<B_KC>(lb, g.b, g.ldb, n0, g.N, k0 + 2 * F_BK, kend, tid);
+        }
+        compute(buf);
+        if (k0 + F_BK < kend) {
+            float* d = smem + (buf ^ 1) * 2 * F_STAGE;
+            store_chunk<A_KC>(d, sa_, k0 + F_BK, kend, tid);
+            store_chunk<B_KC>(d + F_STAGE, sb_, k0 + F_BK, kend, tid);
+            if (want_cs) add_cs(sa_);
+        }
+        __syncthreads();
+    };
+    load_chunk<A_KC>(ra0, g.a, g.lda, m0, g.M, kbeg, kend, tid);
+    load_chunk<B_KC>(rb0, g.b, g.ldb, n0, g.N, kbeg, kend, tid);
+    if (kbeg + F_BK < kend) {
+        load_chunk<A_KC>(ra1, g.a, g.lda, m0, g.M, kbeg + F_BK, kend, tid);
+        load_chunk<B_KC>(rb1, g.b, g.ldb, n0, g.N, kbeg + F_BK, kend, tid);
+    }
+    store_chunk<A_KC>(smem, ra0, kbeg, kend, tid);
+    store_chunk<B_KC>(smem + F_STAGE, rb0, kbeg, kend, tid);
+    if (want_cs) add_cs(ra0);
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * F_BK) {
+        step(ra0, rb0, ra1, rb1, k0, 0);
+        if (k0 + F_BK < kend) step(ra1, rb1, ra0, rb0, k0 + F_BK, 1);
+    }
+
+#ifdef LAB_STAMP
+    if (tid == 0 && g.stamp) {
+        g.stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0;
+        g.stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
+    }
+#endif
+    // ---- epilogue: lane (r, h), register e of a 32x32 accumulator = row krow(e, h), column r
+    if (ACT == 3) {
+        float* slab = g.c + (int64_t)split * g.M * g.ldc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wm * 64 + i * 32 + acr_krow(e, h);
+                    if (row < g.M && col < g.N) slab[(int64_t)row * g.ldc + col] = acc[i][j][e];
+                }
+            }
+        if (!A_KC && g.cs && tn == 0) {
+            // column sums of this split's A rows: thread (kr = tid/32, i4 = tid%32) holds 4 columns; sum the 8 kr rows via LDS
+            float* red = smem;                                   // all fragment reads are behind the loop's last barrier
+            *reinterpret_cast<f32x4*>(red + (tid >> 5) * 128 + 4 * (tid & 31)) = *reinterpret_cast<f32x4*>(csum);
+            __syncthreads();
+            if (tid < 128) {
+                float s = 0.f;
+#pragma unroll
+                for (int kr = 0; kr < 8; ++kr) s += red[kr * 128 + tid];
+                if (m0 + tid < g.M) g.cs[(int64_t)split * g.M + m0 + tid] = s;
+            }
+        }
+        return;
+    }
+    if (m0 + F_BM <= g.M && n0 + F_BN <= g.N)
+        epilogue_f32<ACT, false>(g, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+    else
+        epilogue_f32<ACT, true>(g, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (contraction length a multiple of 32): chunks go global -> LDS directly (global_load_lds_dwordx4),
+// no staging registers and no ds_write path.  Measured on the register-staged kernel above (scripts/lab): its 8 loads +
+// 8 ds_write_b128 per 64 MFMAs cost 18 % of the matrix pipe (4096^3: 150 TF with neither, 128 / 134 TF with one of them,
+// 120 TF with both) although clocks, prefetch depth and wave priorities are not the cause -- VGPR traffic of loads and
+// LDS stores competes with the MFMA operand reads.  A DMA wave-instruction writes 64 lanes x 16 B = 1 KiB linearly:
+//   KC operand: 8 unpadded 128-byte rows; ds_read_b128 bank conflicts are removed by an XOR swizzle applied on the
+//               SOURCE address (lane fetches 16-byte chunk p ^ ((row >> 1) & 7) into slot p) and mirrored on the read;
+//   KS operand: 2 k-rows of 128 floats; fragment reads are 32 consecutive floats, no swizzle needed.
+// ---------------------------------------------------------------------------------------------------------------
+#define F_DTILE (F_BM * F_BK)        // floats per operand per stage, unpadded (16 KiB)
+
+template <bool KC>
+__device__ __forceinline__ void dma_chunk(float* s, const float* __restrict__ p, int64_t ld, int i0, int dim, int k0, int wave,
+                                          int lane) {
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;
+        if (KC) {
+            const int row = piece * 8 + (lane >> 3);
+            const int lc = (lane & 7) ^ ((row >> 1) & 7);
+            const float* src = p + (int64_t)min(i0 + row, dim - 1) * ld + k0 + lc * 4;
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(s + piece * 256), 16, 0, 0);
+        } else {
+            const int kr = piece * 2 + (lane >> 5);
+            const float* src = p + (int64_t)(k0 + kr) * ld + min(i0 + 4 * (lane & 31), dim - 4);
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(s + piece * 256), 16, 0, 0);
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ f32x4 dma_frag(const float* __restrict__ s, int base, int q, int r, int h) {
+    if (KC) {
+        const int row = base + r;
+        return *reinterpret_cast<const f32x4*>(s + row * F_BK + (((2 * q + h) ^ ((row >> 1) & 7)) << 2));
+    }
+    const float* p = s + (8 * q + 4 * h) * F_BM + base + r;
+    f32x4 v = {p[0], p[F_BM], p[2 * F_BM], p[3 * F_BM]};
+    return v;
+}
+
+template <bool A_KC, bool B_KC, int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args g) {
+    __shared__ __attribute__((aligned(1024))) float smem[4 * F_DTILE];      // [A0 | B0 | A1 | B1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int t = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
+    const int split = t / ntile, tt = t - split * ntile;
+    const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
+    const int m0 = tm * F_BM, n0 = tn * F_BN;
+    const int kbeg = split * g.kps, kend = min(g.K, kbeg + g.kps);      // host guarantees (kend - kbeg) % F_BK == 0
+#ifdef LAB_STAMP
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float csum = 0.f;          // TN bias gradient: column tid & 127 of the A chunks, k rows of parity tid >> 7
+    const bool want_cs = ACT == 3 && !A_KC && g.cs && tn == 0;
+
+    dma_chunk<A_KC>(smem, g.a, g.lda, m0, g.M, kbeg, wave, lane);
+    dma_chunk<B_KC>(smem + F_DTILE, g.b, g.ldb, n0, g.N, kbeg, wave, lane);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += F_BK, cur ^= 1) {
+        if (k0 + F_BK < kend) {
+            float* d = smem + (cur ^ 1) * 2 * F_DTILE;
+            dma_chunk<A_KC>(d, g.a, g.lda, m0, g.M, k0 + F_BK, wave, lane);
+            dma_chunk<B_KC>(d + F_DTILE, g.b, g.ldb, n0, g.N, k0 + F_BK, wave, lane);
+        }
+        const float* sa = smem + cur * 2 * F_DTILE;
+        const float* sb = sa + F_DTILE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = dma_frag<A_KC>(sa, wm * 64 + i * 32, q, r, h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = dma_frag<B_KC>(sb, wn * 64 + j * 32, q, r, h);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (want_cs) {                                      // [k][i] image: 16 of the chunk's 32 k rows per thread
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) csum += sa[(2 * kk + (tid >> 7)) * F_BM + (tid & 127)];
+        }
+        __syncthreads();                                    // drains the DMA (vmcnt) and frees buffer `cur`
+    }
+#ifdef LAB_STAMP
+    if (tid == 0 && g.stamp) {
+        g.stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0;
+        g.stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
+    }
+#endif
+    if (ACT == 3) {
+        float* slab = g.c + (int64_t)split * g.M * g.ldc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wm * 64 + i * 32 + acr_krow(e, h);
+                    if (row < g.M && col < g.N) slab[(int64_t)row * g.ldc + col] = acc[i][j][e];
+                }
+            }
+        if (want_cs) {
+            float* red = smem;                              // behind the loop's last barrier
+            red[tid] = csum;
+            __syncthreads();
+            if (tid < 128 && m0 + tid < g.M) g.cs[(int64_t)split * g.M + m0 + tid] = red[tid] + red[tid + 128];
+        }
+        return;
+    }
+    if (m0 + F_BM <= g.M && n0 + F_BN <= g.N)
+        epilogue_f32<ACT, false>(g, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+    else
+        epilogue_f32<ACT, true>(g, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+}
+
+// out[i] = sum_s slab[s][i] in split order (deterministic), float4 per thread; n4 = elements / 4
+__global__ __launch_bounds__(256) void gemm_f32_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t n4,
+                                                              float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = reinterpret_cast<const f32x4*>(ws)[i];
+    for (int k = 1; k < nsplit; ++k) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(ws)[(int64_t)k * n4 + i];
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_reduce1_kernel(const float* __restrict__ ws, int nsplit, int n,
+                                                               float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = ws[i];
+    for (int k = 1; k < nsplit; ++k) s += ws[(int64_t)k * n + i];
+    out[i] = s;
+}
+
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+struct TnPlan { int nsplit, kps; };
+// weight gradient: split the token contraction so that tiles x splits ~ two workgroups per CU, at least 256 tokens per split
+static TnPlan tn_plan(int M, int N, int K) {
+    const int tiles = ((M + F_BM - 1) / F_BM) * ((N + F_BN - 1) / F_BN);
+    int ns = (512 + tiles - 1) / tiles;
+    const int maxs = (K + 255) / 256;
+    if (ns > maxs) ns = maxs;
+    if (ns < 1) ns = 1;
+    int kps = ((K + ns - 1) / ns + F_BK - 1) / F_BK * F_BK;
+    ns = (K + kps - 1) / kps;
+    return {ns, kps};
+}
+
+extern "C" size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K) {
+    if (mode != ACR_GEMM_TN) return 0;
+    const TnPlan p = tn_plan(M, N, K);
+    return (size_t)p.nsplit * ((size_t)M * N + (size_t)M);
+}
+
+extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                            const float* aux, int64_t ldaux, float* c, int64_t ldc, float* c2, float* colsum, int32_t M, int32_t N,
+                            int32_t K, float* ws, void* stream) {
+    ACR_CHECK_ARG(a && b && c, "acr_gemm_f32: null pointer");
+    ACR_CHECK_ARG(M > 0 && N > 0 && K > 0, "acr_gemm_f32: empty problem (M=%d N=%d K=%d)", M, N, K);
+    ACR_CHECK_ARG(mode >= ACR_GEMM_NT && mode <= ACR_GEMM_TN && act >= 0 && act <= 2, "acr_gemm_f32: bad mode %d / act %d", mode, act);
+    ACR_CHECK_ARG(al16(a) && al16(b) && (lda % 4) == 0 && (ldb % 4) == 0, "acr_gemm_f32: operands must be 16-byte aligned with pitches %% 4 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    GemmF32Args g;
+    g.a = a; g.lda = lda; g.b = b; g.ldb = ldb; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.c = c; g.ldc = ldc; g.c2 = c2;
+    g.cs = nullptr; g.M = M; g.N = N; g.K = K;
+#ifdef LAB_STAMP
+    g.stamp = g_lab_stamp;
+#endif
+    g.tiles_m = (M + F_BM - 1) / F_BM; g.tiles_n = (N + F_BN - 1) / F_BN; g.nsplit = 1; g.kps = (K + F_BK - 1) / F_BK * F_BK;
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+    if (mode == ACR_GEMM_TN) {
+        // c[M,N] = a[K,M]^T b[K,N]: both operands contraction-strided; M, N are the weight's dims, K the token count
+        ACR_CHECK_ARG(act == 0 && !bias && !aux, "acr_gemm_f32: TN takes no epilogue");
+        ACR_CHECK_ARG(ws, "acr_gemm_f32: TN needs the acr_gemm_f32_ws_floats workspace");
+        ACR_CHECK_ARG((M % 4) == 0 && (N % 4) == 0 && M >= 4 && N >= 4 && ldc == N && al16(c), "acr_gemm_f32: TN needs M, N %% 4 == 0 and a dense output (ldc == N)");
+        const TnPlan p = tn_plan(M, N, K);
+        g.nsplit = p.nsplit; g.kps = p.kps;
+        g.c = ws; g.ldc = N;
+        g.cs = colsum ? ws + (size_t)p.nsplit * M * N : nullptr;
+        if ((K % F_BK) == 0)
+            hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
+        else
+            hipLaunchKernelGGL((gemm_f32_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
+        const int64_t n4 = (int64_t)M * N / 4;
+        hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit, n4, c);
+        if (colsum)
+            hipLaunchKernelGGL(gemm_f32_reduce1_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)g.cs, p.nsplit, M, colsum);
+        return acr_check_launch("acr_gemm_f32(TN)");
+    }
+    ACR_CHECK_ARG((K % 4) == 0 && K >= 4, "acr_gemm_f32: NT / NN need K %% 4 == 0 (K=%d)", K);
+    if (mode == ACR_GEMM_NN) ACR_CHECK_ARG((N % 4) == 0 && N >= 4, "acr_gemm_f32: NN needs N %% 4 == 0 (N=%d)", N);
+    ACR_CHECK_ARG(act != 1 || c2, "acr_gemm_f32: act 1 (GELU) needs c2");
+    ACR_CHECK_ARG(act != 2 || aux, "acr_gemm_f32: act 2 (GELU') needs the saved pre-activation in aux");
+#define ACR_F32_LAUNCH(AK, BK_, ACTV)                                                                    \
+    do {                                                                                                  \
+        if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);   \
+        else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);           \
+    } while (0)
+    const bool dma = (K % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0;
+    if (mode == ACR_GEMM_NT) {
+        if (act == 0) ACR_F32_LAUNCH(true, true, 0);
+        else if (act == 1) ACR_F32_LAUNCH(true, true, 1);
+        else ACR_F32_LAUNCH(true, true, 2);
+    } else {
+        if (act == 0) ACR_F32_LAUNCH(true, false, 0);
+        else if (act == 1) ACR_F32_LAUNCH(true, false, 1);
+        else ACR_F32_LAUNCH(true, false, 2);
+    }
+#undef ACR_F32_LAUNCH
+    return acr_check_launch("acr_gemm_f32");
+}

@@ -395,12 +395,152 @@ def mlp(x, fc1, fc2, resid=None):
     return MlpFn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, resid, fc1, fc2)
 
 
+# ------------------------------------------------------------------------------------------------
+# fp32 (reference precision) Linears on the exact-fp32 MFMA GEMM (acr_gemm_f32)
+# ------------------------------------------------------------------------------------------------
+GEMM_MODES = {"nt": 0, "nn": 1, "tn": 2}
+
+
+def gemm_f32_raw(mode, a, b, c, bias=None, aux=None, act=0, c2=None, colsum=None):
+    """c = op(a) op(b) through acr_gemm_f32 (see include/acr_hip.h): 'nt' c[M,N] = a[M,K] b[N,K]^T, 'nn' c = a[M,K] b[K,N],
+    'tn' c = a[K,M]^T b[K,N] (+ colsum[M] = column sums of a).  fp32, unit inner strides."""
+    lib = L.load()
+    md = GEMM_MODES[mode]
+    M, N = c.shape
+    K = a.shape[0] if md == 2 else a.shape[1]
+    nws = lib.acr_gemm_f32_ws_floats(md, M, N, K)
+    ws = torch.empty(nws, dtype=torch.float32, device=a.device) if nws else None
+    L.check(lib.acr_gemm_f32(md, act, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(bias), L.ptr(aux),
+                             aux.stride(0) if aux is not None else 0, L.ptr(c), c.stride(0), L.ptr(c2), L.ptr(colsum), M, N, K,
+                             L.ptr(ws), L.stream_ptr()), "acr_gemm_f32")
+    return c
+
+
+def _f32_ok(*ts):
+    return all(t is None or (t.dtype == torch.float32 and t.is_cuda and t.stride(-1) == 1 and t.stride(0) % 4 == 0
+                             and t.data_ptr() % 16 == 0) for t in ts)
+
+
+def linear_f32_usable(x, weight):
+    K = x.shape[-1]
+    N = weight.shape[0]
+    return (F32_HIP_LINEAR and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous()
+            and weight.is_contiguous() and K % 4 == 0 and N % 4 == 0 and K >= 32 and N >= 32 and x.numel() // K >= 1)
+
+
+F32_HIP_LINEAR = os.environ.get("ACR_F32_HIP_LINEAR", "1") != "0"      # A/B switch: fp32 Linears on acr_gemm_f32 vs hipBLASLt
+
+
+class LinearF32Fn(Function):
+    """y = x W^T + b (+ resid) in fp32 on acr_gemm_f32: forward NT, input gradient NN (W as stored), weight + bias gradient
+    in one TN sweep over dy (models/vision_transformer.py:200,212 and their autograd backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, resid):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        N = weight.shape[0]
+        r2 = resid.reshape(-1, N) if resid is not None else None
+        if r2 is not None and not r2.is_contiguous():
+            r2 = r2.contiguous()
+        y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
+        gemm_f32_raw("nt", x2, weight, y, bias=bias, aux=r2)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias, ctx.has_resid = bias is not None, resid is not None
+        return y.reshape(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        N, K = weight.shape
+        dy2 = dy.reshape(-1, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((dy2.shape[0], K), dtype=torch.float32, device=dy.device)
+            gemm_f32_raw("nn", dy2, weight, dx)
+            dx = dx.reshape(*dy.shape[:-1], K)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_db else None
+            gemm_f32_raw("tn", dy2, x2, dw, colsum=db)
+        elif want_db:
+            db = dy2.sum(0)
+        return dx, dw, db, (dy if ctx.has_resid else None)
+
+
+class MlpF32Fn(Function):
+    """y = fc2(GELU(fc1(x))) [+ resid] in fp32 (models/vision_transformer.py:158-164) with the activation in the GEMM
+    epilogues: fc1 writes h and GELU(h) in one pass; fc2's input gradient comes out multiplied by GELU'(h)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, resid):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        M = x2.shape[0]
+        Hd, D = w1.shape[0], w2.shape[0]
+        h = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
+        a = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
+        gemm_f32_raw("nt", x2, w1, h, bias=b1, act=1, c2=a)
+        r2 = resid.reshape(-1, D) if resid is not None else None
+        if r2 is not None and not r2.is_contiguous():
+            r2 = r2.contiguous()
+        y = torch.empty((M, D), dtype=torch.float32, device=x.device)
+        gemm_f32_raw("nt", a, w2, y, bias=b2, aux=r2)
+        ctx.save_for_backward(x2, h, a, w1, w2)
+        ctx.has_resid = resid is not None
+        return y.reshape(*shp[:-1], D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h, a, w1, w2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        M, Hd = h.shape
+        dev = dy.device
+        dw1 = db1 = dw2 = db2 = dx = None
+        if need[3]:
+            dw2 = torch.empty_like(w2)
+            db2 = torch.empty(w2.shape[0], dtype=torch.float32, device=dev) if need[4] else None
+            gemm_f32_raw("tn", dy2, a, dw2, colsum=db2)
+        elif need[4]:
+            db2 = dy2.sum(0)
+        dh = torch.empty_like(h)
+        gemm_f32_raw("nn", dy2, w2, dh, aux=h, act=2)                 # (dY W2) * GELU'(h)
+        if need[1]:
+            dw1 = torch.empty_like(w1)
+            db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if need[2] else None
+            gemm_f32_raw("tn", dh, x2, dw1, colsum=db1)
+        elif need[2]:
+            db1 = dh.sum(0)
+        if need[0]:
+            dx = torch.empty_like(x2)
+            gemm_f32_raw("nn", dh, w1, dx)
+            dx = dx.reshape(*dy.shape[:-1], w1.shape[1])
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None)
+
+
+def mlp_f32_usable(x, fc1, fc2):
+    return (linear_f32_usable(x, fc1.weight) and fc2.weight.dtype == torch.float32 and fc1.bias is not None
+            and fc2.bias is not None and fc2.weight.is_contiguous() and fc2.weight.shape[0] % 4 == 0)
+
+
+def mlp_f32(x, fc1, fc2, resid=None):
+    return MlpF32Fn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, resid)
+
+
 def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hip_fwd=True):
     """nn.Linear forward; bf16 CUDA tensors with K % 64 == 0 take the hand-written GEMM (resid fused).
     ``hip_dx`` = False leaves the input gradient on hipBLASLt (shapes where the library kernel is faster)."""
     if (use_hip and x.is_cuda and x.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16
             and lin.weight.shape[1] % 64 == 0 and x.is_contiguous()):
         return LinearBf16Fn.apply(x, lin.weight, lin.bias, resid, hip_dx, hip_dw, hip_fwd, lin)
+    if use_hip and linear_f32_usable(x, lin.weight) and not torch.is_autocast_enabled():
+        return LinearF32Fn.apply(x, lin.weight, lin.bias, resid)
     y = torch.nn.functional.linear(x, lin.weight, lin.bias)
     return y if resid is None else resid + y
 

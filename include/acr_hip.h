@@ -72,6 +72,7 @@ typedef enum acr_option {
     ACR_OPT_WGRAD_VARIANT = 3,  /* acr_wgrad_bf16: 1 = 128x128 tiles, 2 = 256x256 */
     ACR_OPT_WGRAD_WAVES = 4,    /* 4 or 8 waves per 256x256 workgroup */
     ACR_OPT_DQ_VARIANT = 5,     /* acr_attn_bwd (bf16) dQ sweep: 0 = by presence of G, 2 = 2-wave, 4 = 4-wave */
+    ACR_OPT_GEMM_F32_REGSTAGE = 6, /* 1: acr_gemm_f32 always takes the register-staged kernel (A/B of the LDS-DMA kernel) */
     ACR_OPT_COUNT_
 } acr_option;
 int     acr_set_option(int32_t option, int32_t value);
@@ -120,6 +121,24 @@ int acr_linear_gelu_bf16(const void* a, int64_t lda, const void* w, int64_t ldw,
 int acr_linear_dgelu_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const void* h, int64_t ldh, void* y,
                           int64_t ldy, int32_t M, int32_t N, int32_t K, void* stream);
 
+
+/* ---- the same Linears at the REFERENCE precision: fp32 tensors, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) ----
+ * One entry point, three operand arrangements (models/vision_transformer.py:158-164,200,212 and their autograd backward):
+ *   ACR_GEMM_NT  c[M,N] = a[M,K] . b[N,K]^T      Linear forward  (a = x, b = W as stored)
+ *   ACR_GEMM_NN  c[M,N] = a[M,K] . b[K,N]        input gradient  (a = dy, b = W as stored -- no transposed weight copies)
+ *   ACR_GEMM_TN  c[M,N] = a[K,M]^T . b[K,N]      weight gradient (a = dy, b = x, K = tokens), contraction split over
+ *                workgroups into fp32 slabs summed in split order (deterministic); colsum (nullable, (M)) receives
+ *                sum_k a[k][m] -- the bias gradient -- from the same sweep over dy
+ * Epilogues of NT / NN (act): 0: c = acc (+ bias[N]) (+ aux[M,N] = the block's residual);
+ *   1: c = h = acc + bias and c2 = GELU(h) (exact erf form; fc1 forward writes both in one pass);
+ *   2: c = acc * GELU'(aux) with aux = the saved h (fc2's input gradient taken through the activation).
+ * Pitches in elements, multiples of 4; pointers 16-byte aligned; K %% 4 == 0 (NT/NN), M, N %% 4 == 0 and ldc == N (TN).
+ * ws: caller-owned scratch of acr_gemm_f32_ws_floats(mode, M, N, K) floats (0 for NT / NN). */
+typedef enum acr_gemm_mode { ACR_GEMM_NT = 0, ACR_GEMM_NN = 1, ACR_GEMM_TN = 2 } acr_gemm_mode;
+size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K);
+int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                 const float* aux, int64_t ldaux, float* c, int64_t ldc, float* c2, float* colsum, int32_t M, int32_t N,
+                 int32_t K, float* ws, void* stream);
 
 /* Weight gradient of a projection: dw[N,K] = dy[M,N]^T . x[M,K] (bf16, fp32 accumulate), contraction over the M tokens
  * split over workgroups with fp32 partial slabs summed in a fixed order (deterministic).  N, K multiples of 128.

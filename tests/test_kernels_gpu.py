@@ -440,3 +440,70 @@ def test_weight_transposes_cache():
     cache.refresh()
     assert ops.weight_t(lins[0].weight, lins[0]) is lins[0]._acr_wt
     assert torch.equal(lins[0]._acr_wt, lins[0].weight.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 32, 32), (130, 200, 72), (785, 2304, 768), (2 * 785 + 3, 768, 3072), (333, 576, 192),
+                                   (25120, 768, 768), (1025, 3072, 768)])
+def test_gemm_f32_linear(M, N, K):
+    """acr_gemm_f32 (exact-fp32 MFMA, reference precision) through LinearF32Fn: forward NT with bias + residual, input
+    gradient NN on the weight as stored, weight + bias gradient in one TN sweep -- against fp64; ragged M (not a multiple
+    of 128), N with a partial tile (200, 576), K tails (72 = 2.25 chunks) and a token count that is not a multiple of
+    the 32-deep chunk in the TN contraction (785, 1573, 1025)."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(dev).requires_grad_(True)
+    r = torch.randn(M, N, generator=g).to(dev).requires_grad_(True)
+    assert ops.linear_f32_usable(x, w)
+    y = ops.LinearF32Fn.apply(x, w, b, r)
+    dy = torch.randn(M, N, generator=g).to(dev)
+    (y * dy).sum().backward()
+    xd, wd, bd, rd = (t.detach().double().requires_grad_(True) for t in (x, w, b, r))
+    ref = xd @ wd.t() + bd + rd
+    (ref * dy.double()).sum().backward()
+    for name, got, want in (("y", y, ref), ("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad), ("db", b.grad, bd.grad)):
+        err = (got.double() - want).abs().max() / want.abs().max()
+        assert err <= 1e-5, (name, float(err))
+    torch.testing.assert_close(r.grad, dy)
+    # deterministic (split-token slabs are summed in a fixed order)
+    w.grad = None
+    x.grad = None
+    y2 = ops.LinearF32Fn.apply(x, w, b, r)
+    (y2 * dy).sum().backward()
+    assert torch.equal(y2, y)
+    dw1 = w.grad.clone()
+    w.grad = None
+    (ops.LinearF32Fn.apply(x, w, b, r) * dy).sum().backward()
+    assert torch.equal(dw1, w.grad)
+
+
+@pytest.mark.parametrize("M,D,Hd", [(197 * 2, 192, 768), (785, 768, 3072), (131, 128, 260)])
+def test_fused_mlp_f32(M, D, Hd):
+    """MlpF32Fn (GELU / GELU' inside the fp32 GEMM epilogues) against fp64 fc2(gelu(fc1(x))) + resid and against the
+    stock torch fp32 ops it replaces (same exact-erf GELU): output and all six gradients."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + D)
+    fc1, fc2 = torch.nn.Linear(D, Hd).to(dev), torch.nn.Linear(Hd, D).to(dev)
+    with torch.no_grad():
+        fc1.bias.copy_(torch.randn(Hd, generator=g) * 0.3)
+        fc2.bias.copy_(torch.randn(D, generator=g) * 0.3)
+        fc1.weight.mul_(3.0)                                    # pre-activations of O(1): both GELU branches exercised
+    x = torch.randn(1, M, D, generator=g).to(dev).requires_grad_(True)
+    r = torch.randn(1, M, D, generator=g).to(dev).requires_grad_(True)
+    dy = torch.randn(1, M, D, generator=g).to(dev)
+    assert ops.mlp_f32_usable(x, fc1, fc2)
+    y = ops.mlp_f32(x, fc1, fc2, r)
+    (y * dy).sum().backward()
+    got = [y, x.grad, r.grad, fc1.weight.grad, fc1.bias.grad, fc2.weight.grad, fc2.bias.grad]
+    xd, rd = x.detach().double().requires_grad_(True), r.detach().double().requires_grad_(True)
+    p = [t.detach().double().requires_grad_(True) for t in (fc1.weight, fc1.bias, fc2.weight, fc2.bias)]
+    ref = F.linear(F.gelu(F.linear(xd, p[0], p[1])), p[2], p[3]) + rd
+    (ref * dy.double()).sum().backward()
+    want = [ref, xd.grad, rd.grad, p[0].grad, p[1].grad, p[2].grad, p[3].grad]
+    for n, a, b in zip(["y", "dx", "dresid", "dW1", "db1", "dW2", "db2"], got, want):
+        err = (a.double() - b).abs().max().item() / max(b.abs().max().item(), 1e-9)
+        assert err <= 2e-5, (n, err)
