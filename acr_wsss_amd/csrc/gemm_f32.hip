@@ -423,15 +423,24 @@ __global__ __launch_bounds__(256) void gemm_f32_reduce1_kernel(const float* __re
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 struct TnPlan { int nsplit, kps; };
-// weight gradient: split the token contraction so that tiles x splits ~ two workgroups per CU, at least 256 tokens per split
+// Weight gradient: the token contraction is split over workgroups.  The chip holds 512 workgroups at a time (two per CU),
+// so tiles x splits should fill whole rounds of 512: 576 workgroups take as long as 1024 (measured: fc1's dW with 4
+// splits = 576 workgroups ran at 87 TF, the loop itself at the same 8.4k cycles per chunk as NT).  Pick the split count
+// that minimises  rounds x chunks-per-split x t_chunk  +  slab traffic  (t_chunk = 3.5 us per 32-token chunk with two
+// workgroups sharing a CU; slabs are written and read once at ~4 TB/s), at least 256 tokens per split.
 static TnPlan tn_plan(int M, int N, int K) {
     const int tiles = ((M + F_BM - 1) / F_BM) * ((N + F_BN - 1) / F_BN);
-    int ns = (512 + tiles - 1) / tiles;
     const int maxs = (K + 255) / 256;
-    if (ns > maxs) ns = maxs;
-    if (ns < 1) ns = 1;
-    int kps = ((K + ns - 1) / ns + F_BK - 1) / F_BK * F_BK;
-    ns = (K + kps - 1) / kps;
+    double best = 1e30;
+    int bns = 1;
+    for (int ns = 1; ns <= maxs && ns <= 64; ++ns) {
+        const int kps = ((K + ns - 1) / ns + F_BK - 1) / F_BK * F_BK;
+        const int rounds = (tiles * ns + 511) / 512;
+        const double t = rounds * (kps / (double)F_BK) * 3.5e-6 + (ns > 1 ? ns * (double)M * N * 8.0 / 4e12 : 0.0);
+        if (t < best * 0.999) { best = t; bns = ns; }
+    }
+    int kps = ((K + bns - 1) / bns + F_BK - 1) / F_BK * F_BK;
+    const int ns = (K + kps - 1) / kps;
     return {ns, kps};
 }
 

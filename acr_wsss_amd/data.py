@@ -1,33 +1,35 @@
-"""Input pipeline of the ACR training / CAM steps on the device ("next" row).
+"""Input pipeline of the ACR training / CAM steps on the device.
 
 Counterpart of myTool.py:1158-1199 (`get_data_from_chunk_v2`) and :1364-1403 (`get_data_from_chunk_val`): the
-reference decodes with cv2 on the training process's CPU and does resize / flip / normalise / crop in numpy, one
-image at a time, synchronously; at >100 img/s/GPU that starves the device.  Here the host only hands over decoded
-uint8 HWC RGB arrays (any decoder); everything else runs on the GPU on the upload stream:
+reference decodes with cv2 on the training process's CPU and does resize / flip / normalise / crop in numpy float64,
+one image at a time, synchronously; at >100 img/s/GPU that starves the device.  Here the host only decodes (any
+decoder -- PIL is what this image has) and draws the geometry; ONE H2D copy of the packed uint8 pixels and ONE kernel
+launch (`acr_preprocess_batch`, include/acr_hip.h) produce the (B,3,S,S) network input:
 
-  random resize-long to [0.9*S, S/0.875]   (RandomResizeLong :995-1008; cv2.resize default = bilinear, half-pixel
-                                             centres, no anti-aliasing == F.interpolate(bilinear, align_corners=False))
+  random resize-long to [0.9*S, S/0.875]   (RandomResizeLong :995-1008; cv2.resize float-path bilinear)
   horizontal flip with probability 1/2     (flip :895-899)
   (x/255 - mean) / std                     (:1180-1182)
   zero-padded random crop to S x S         (RandomCrop :923-955)
 
-and returns the same contract as the reference: images (B,3,S,S) fp32 + labels (B,C) from the `cls_labels.npy`
-dict (voc12/make_cls_labels.py:18-22).  Geometry draws come from a seedable numpy Generator (the reference uses
-the unseeded `random` module, train_acr.py:23 commented out).  Parity with cv2's resize is NOT pinned (cv2 is not
-installed in the build image): the geometry/normalisation contract is tested instead.
+and returns the same contract as the reference: images (B,3,S,S) + labels (B,C) from the `cls_labels.npy` dict
+(voc12/make_cls_labels.py:18-22).  The draws follow the reference's order (np.random.uniform for the flip, then
+random.randint / random.randrange) from SEEDABLE generators (the reference's are the unseeded globals, train_acr.py:23).
+There is no CPU path: tensors land on the GPU through the HIP kernel or the call raises.
 """
+import ctypes
+import random as _pyrandom
+
 import numpy as np
 import torch
-import torch.nn.functional as F
+
+from . import _lib as L
 
 MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
 
-
-def _norm_consts(device):
-    m = torch.tensor(MEAN, device=device).view(3, 1, 1)
-    s = torch.tensor(STD, device=device).view(3, 1, 1)
-    return m, s
+PRE_IMAGE = np.dtype([("offset", "<i8"), ("h", "<i4"), ("w", "<i4"), ("rh", "<i4"), ("rw", "<i4"), ("flip", "<i4"),
+                      ("cont_top", "<i4"), ("cont_left", "<i4"), ("img_top", "<i4"), ("img_left", "<i4"), ("ch", "<i4"),
+                      ("cw", "<i4")])                       # struct acr_pre_image
 
 
 def load_cls_labels(path, names, num_classes=20):
@@ -37,62 +39,89 @@ def load_cls_labels(path, names, num_classes=20):
 
 
 def resize_long_target(h, w, target_long):
-    """myTool.py:995-1005: the longer side becomes target_long, the other is rounded."""
+    """myTool.py:995-1005: the longer side becomes target_long, the other is rounded.  Returns (new_h, new_w)."""
     if w < h:
-        return target_long, int(round(w * target_long / h))          # (new_h, new_w)
+        return target_long, int(round(w * target_long / h))
     return int(round(h * target_long / w)), target_long
 
 
 def random_crop_boxes(h, w, crop, rng):
-    """myTool.py:923-948 -> (cont_top, cont_left, img_top, img_left, ch, cw)."""
+    """myTool.py:923-948 -> (cont_top, cont_left, img_top, img_left, ch, cw); w is drawn before h, like the reference.
+    ``rng``: a ``random.Random``."""
     ch, cw = min(crop, h), min(crop, w)
     w_space, h_space = w - crop, h - crop
     if w_space > 0:
-        cont_left, img_left = 0, int(rng.integers(0, w_space + 1))
+        cont_left, img_left = 0, rng.randrange(w_space + 1)
     else:
-        cont_left, img_left = int(rng.integers(0, -w_space + 1)), 0
+        cont_left, img_left = rng.randrange(-w_space + 1), 0
     if h_space > 0:
-        cont_top, img_top = 0, int(rng.integers(0, h_space + 1))
+        cont_top, img_top = 0, rng.randrange(h_space + 1)
     else:
-        cont_top, img_top = int(rng.integers(0, -h_space + 1)), 0
+        cont_top, img_top = rng.randrange(-h_space + 1), 0
     return cont_top, cont_left, img_top, img_left, ch, cw
 
 
+def preprocess_batch(images_uint8, records, S, device, dtype=torch.float32):
+    """Run acr_preprocess_batch: ``images_uint8`` = list of (h,w,3) uint8 RGB arrays, ``records`` = PRE_IMAGE array with
+    everything but ``offset`` filled in.  One pinned staging buffer, one H2D copy, one launch."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise L.AcrHipError("acr_wsss_amd.data runs on the GPU only (acr_preprocess_batch); there is no CPU path")
+    sizes = [int(a.shape[0]) * int(a.shape[1]) * 3 for a in images_uint8]
+    offs = np.concatenate([[0], np.cumsum([(s + 15) // 16 * 16 for s in sizes])])       # 16-byte aligned images
+    stage = torch.empty(int(offs[-1]), dtype=torch.uint8).pin_memory()
+    sn = stage.numpy()
+    for a, o, s in zip(images_uint8, offs[:-1], sizes):
+        assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3, "decoded images must be (h, w, 3) uint8 RGB"
+        sn[o:o + s] = np.ascontiguousarray(a).reshape(-1)
+    records = records.copy()
+    records["offset"] = offs[:-1]
+    packed = stage.to(device, non_blocking=True)
+    table = torch.from_numpy(records.view(np.uint8).reshape(-1).copy()).to(device, non_blocking=True)
+    out = torch.empty((len(images_uint8), 3, S, S), dtype=dtype, device=device)
+    mean = (ctypes.c_float * 3)(*MEAN)
+    std = (ctypes.c_float * 3)(*STD)
+    with torch.cuda.device(device):
+        L.check(L.load().acr_preprocess_batch(L.ptr(packed), L.ptr(table), len(images_uint8), S, mean, std, L.dtype_code(dtype)
+                                              if dtype != torch.bfloat16 else L.ACR_BF16, L.ptr(out), L.stream_ptr()),
+                "acr_preprocess_batch")
+    # the staging buffer and the table must outlive the asynchronous copies: tie them to the output
+    out._acr_keep = (stage, packed, table)
+    return out
+
+
 class TrainBatcher:
-    def __init__(self, crop_size, device="cuda", seed=None):
+    """get_data_from_chunk_v2 for a chunk of decoded images.  ``seed`` seeds both generators the reference draws from."""
+
+    def __init__(self, crop_size, device="cuda", seed=None, dtype=torch.float32):
         self.S = crop_size
         self.device = torch.device(device)
-        self.rng = np.random.default_rng(seed)
-        self.mean, self.std = _norm_consts(self.device)
+        self.dtype = dtype
+        self.pyrandom = _pyrandom.Random(seed)
+        self.nprandom = np.random.RandomState(seed)
+
+    def draw(self, h, w):
+        """The per-image draws in the reference's order: flip_p (:1175), target_long (:996), crop boxes (:935-945)."""
+        S = self.S
+        flip_p = self.nprandom.uniform(0, 1)
+        target_long = self.pyrandom.randint(int(S * 0.9), int(S / 0.875))
+        nh, nw = resize_long_target(h, w, target_long)
+        ct, cl, it, il, ch, cw = random_crop_boxes(nh, nw, S, self.pyrandom)
+        return (0, h, w, nh, nw, int(flip_p > 0.5), ct, cl, it, il, ch, cw)
 
     def __call__(self, images_uint8, labels):
-        """images_uint8: list of (h,w,3) uint8 RGB arrays; labels: (B,C) tensor.  Returns (img, label) on device."""
-        S = self.S
-        out = torch.zeros((len(images_uint8), 3, S, S), dtype=torch.float32, device=self.device)
-        for i, arr in enumerate(images_uint8):
-            t = torch.from_numpy(np.ascontiguousarray(arr))
-            if self.device.type == "cuda":
-                t = t.pin_memory().to(self.device, non_blocking=True)
-            x = t.permute(2, 0, 1).float().unsqueeze(0)                          # (1,3,h,w)
-            h, w = x.shape[-2:]
-            target_long = int(self.rng.integers(int(S * 0.9), int(S / 0.875) + 1))
-            nh, nw = resize_long_target(h, w, target_long)
-            x = F.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False)[0]
-            if self.rng.uniform(0, 1) > 0.5:
-                x = x.flip(-1)
-            x = (x / 255.0 - self.mean) / self.std
-            ct, cl, it, il, ch, cw = random_crop_boxes(nh, nw, S, self.rng)
-            out[i, :, ct:ct + ch, cl:cl + cw] = x[:, it:it + ch, il:il + cw]
-        return out, labels.to(self.device, non_blocking=True)
+        """images_uint8: list of (h,w,3) uint8 RGB arrays; labels: (B,C) tensor.  Returns (img, label) on the device."""
+        rec = np.zeros(len(images_uint8), PRE_IMAGE)
+        for i, a in enumerate(images_uint8):
+            rec[i] = self.draw(int(a.shape[0]), int(a.shape[1]))
+        self.last_records = rec
+        return preprocess_batch(images_uint8, rec, self.S, self.device, self.dtype), labels.to(self.device, non_blocking=True)
 
 
-def val_batch(images_uint8, crop_size, device="cuda"):
+def val_batch(images_uint8, crop_size, device="cuda", dtype=torch.float32):
     """myTool.py:1364-1403: plain resize to crop x crop + normalise (no augmentation)."""
-    device = torch.device(device)
-    mean, std = _norm_consts(device)
-    out = []
-    for arr in images_uint8:
-        x = torch.from_numpy(np.ascontiguousarray(arr)).to(device).permute(2, 0, 1).float().unsqueeze(0)
-        x = F.interpolate(x, size=(crop_size, crop_size), mode="bilinear", align_corners=False)[0]
-        out.append((x / 255.0 - mean) / std)
-    return torch.stack(out)
+    S = crop_size
+    rec = np.zeros(len(images_uint8), PRE_IMAGE)
+    for i, a in enumerate(images_uint8):
+        rec[i] = (0, int(a.shape[0]), int(a.shape[1]), S, S, 0, 0, 0, 0, 0, S, S)
+    return preprocess_batch(images_uint8, rec, S, device, dtype)

@@ -266,6 +266,23 @@ int acr_getam_row_accum(const acr_attn_desc* desc, const void* q, const void* k,
 int acr_aff_refine(const float* a, int32_t L, int32_t T, const float* cam, int32_t n_cam,
                    float* out, void* stream);
 
+/* ---- input pipeline (myTool.py:1158-1199 get_data_from_chunk_v2, :1364-1403 get_data_from_chunk_val) ----
+ * One launch turns a batch of decoded uint8 HWC RGB images into the (B,3,S,S) network input: bilinear resize with
+ * cv2.resize's float-path INTER_LINEAR rule (RandomResizeLong :995-1008 / cv2.resize(S,S)), optional horizontal flip
+ * (:895-899), (x/255 - mean)/std (:1180-1182) and the zero-padded RandomCrop (:923-955).  The HOST decodes and draws the
+ * geometry (the reference uses the unseeded `random` module); packed_u8 holds the images back to back, `table` is a
+ * device array of `batch` acr_pre_image records.  Validation batches: rh = rw = S, flip 0, boxes = the whole image.
+ * mean3 / std3: HOST pointers to 3 floats.  out_dtype: ACR_F32 or ACR_BF16. */
+typedef struct acr_pre_image {
+    int64_t offset;        /* byte offset of this image inside packed_u8 */
+    int32_t h, w;          /* decoded height, width */
+    int32_t rh, rw;        /* height, width after the resize step */
+    int32_t flip;          /* 1 = flip horizontally after resizing */
+    int32_t cont_top, cont_left, img_top, img_left, ch, cw;   /* RandomCrop: container / image corners, copied extent */
+} acr_pre_image;
+int acr_preprocess_batch(const void* packed_u8, const void* table, int32_t batch, int32_t S, const float* mean3,
+                         const float* std3, int32_t out_dtype, void* out, void* stream);
+
 /* ---- CAM read-outs ----
  * Patch-token -> class activation (DPT/ACR.py:133-134): out[n][c] = relu(x[n,:] . w[c,:] + bias[c]),
  * x (N, D) with row stride x_st, w (C, D) contiguous, out (N, C) contiguous; dtype of x/w/bias. */

@@ -1,49 +1,74 @@
-"""Contract of the device-side input pipeline (acr_wsss_amd/data.py) -- runs on CPU tensors here."""
+"""Input pipeline, CPU side: the oracle's restatement of myTool.py:923-1008,1158-1199,1364-1403 against
+independent formulations, the host geometry of acr_wsss_amd/data.py against the oracle (same draws in the same order from
+the same seeds), and the no-CPU-fallback rule."""
+import random
+
 import numpy as np
+import pytest
 import torch
 
 from acr_wsss_amd import data
+from oracle import data_oracle as DO
 
 
-def test_resize_long_and_crop_geometry():
-    assert data.resize_long_target(300, 500, 400) == (240, 400)
-    assert data.resize_long_target(500, 300, 400) == (400, 240)
+def test_cv2_linear_rule_matches_torch_bilinear():
+    """OpenCV's float INTER_LINEAR rule == F.interpolate(bilinear, align_corners=False) (no antialias), up- and
+    down-scaling, odd sizes; plus hand-checked border behaviour."""
     rng = np.random.default_rng(0)
+    for (h, w, nh, nw) in ((50, 70, 64, 64), (120, 200, 77, 129), (33, 17, 100, 9), (5, 4, 5, 4), (1, 7, 3, 20)):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.float64)
+        got = DO.cv2_resize_linear(img, nw, nh)
+        ref = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(nh, nw), mode="bilinear",
+                                              align_corners=False)[0].permute(1, 2, 0).numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9)
+    one = np.arange(4, dtype=np.float64).reshape(1, 4, 1).repeat(3, axis=2)          # [0, 1, 2, 3] upscaled x2
+    up = DO.cv2_resize_linear(one, 8, 1)[0, :, 0]
+    np.testing.assert_allclose(up, [0, 0.25, 0.75, 1.25, 1.75, 2.25, 2.75, 3.0])
+
+
+def test_geometry_restatement():
+    assert DO.resize_long_shape(300, 500, 400) == (400, 240)          # (width, height) as handed to cv2.resize
+    assert DO.resize_long_shape(500, 300, 400) == (240, 400)
+    assert data.resize_long_target(300, 500, 400) == (240, 400) and data.resize_long_target(500, 300, 400) == (400, 240)
+    r = random.Random(0)
     for (h, w) in ((600, 500), (300, 500), (200, 100), (448, 448)):
         for _ in range(20):
-            ct, cl, it, il, ch, cw = data.random_crop_boxes(h, w, 448, rng)
-            assert 0 <= ct and ct + ch <= 448 and 0 <= cl and cl + cw <= 448
-            assert 0 <= it and it + ch <= h and 0 <= il and il + cw <= w
-            assert ch == min(h, 448) and cw == min(w, 448)
+            b = DO.random_crop_boxes(h, w, 448, r)
+            assert 0 <= b["cont_top"] and b["cont_top"] + b["ch"] <= 448 and 0 <= b["cont_left"] and b["cont_left"] + b["cw"] <= 448
+            assert 0 <= b["img_top"] and b["img_top"] + b["ch"] <= h and 0 <= b["img_left"] and b["img_left"] + b["cw"] <= w
+            assert b["ch"] == min(h, 448) and b["cw"] == min(w, 448)
 
 
-def test_train_batcher_contract():
+def test_host_draws_follow_the_reference_order():
+    """TrainBatcher.draw consumes random.Random / np.random.RandomState exactly like the oracle's restatement of
+    get_data_from_chunk_v2 -> identical geometry from identical seeds, image after image."""
+    b = data.TrainBatcher(448, device="cpu", seed=11)
+    pr, nr = random.Random(11), np.random.RandomState(11)
+    for (h, w) in ((375, 500), (500, 333), (120, 90), (800, 1200), (448, 448)):
+        rec = b.draw(h, w)
+        g = DO.draw_train_geometry(h, w, 448, pr, nr)
+        assert rec[3:] == (g["rh"], g["rw"], g["flip"], g["cont_top"], g["cont_left"], g["img_top"], g["img_left"], g["ch"], g["cw"])
+
+
+def test_oracle_train_image_contract():
     rng = np.random.default_rng(1)
-    imgs = [rng.integers(0, 256, (120, 200, 3), dtype=np.uint8), rng.integers(0, 256, (260, 90, 3), dtype=np.uint8)]
-    labels = torch.tensor([[1.0, 0, 1] + [0] * 17, [0, 1.0, 0] + [0] * 17])
-    b = data.TrainBatcher(128, device="cpu", seed=7)
-    x, y = b(imgs, labels)
-    assert x.shape == (2, 3, 128, 128) and x.dtype == torch.float32 and torch.equal(y, labels)
-    # long side in [0.9*S, S/0.875] -> the short side leaves a zero-padded band; padded pixels are exactly 0
-    assert (x == 0).any()
-    nz = x[0].abs().sum(0) > 0
-    rows, cols = nz.any(1).sum().item(), nz.any(0).sum().item()
-    assert 115 <= max(rows, cols) <= 128 and min(rows, cols) < 128
-    # normalisation range: (0/255 - mean)/std ... (255/255 - mean)/std
-    lo = min((0 - m) / s for m, s in zip(data.MEAN, data.STD))
-    hi = max((1 - m) / s for m, s in zip(data.MEAN, data.STD))
+    img = rng.integers(0, 256, (120, 200, 3), dtype=np.uint8)
+    g = DO.draw_train_geometry(120, 200, 128, random.Random(3), np.random.RandomState(3))
+    x = DO.train_image(img, 128, g)
+    assert x.shape == (3, 128, 128) and x.dtype == np.float32
+    assert 115 <= max(g["rh"], g["rw"]) <= 146 and (x == 0).any()          # short side leaves a zero band
+    lo = min((0 - m) / s for m, s in zip(DO.MEAN, DO.STD))
+    hi = max((1 - m) / s for m, s in zip(DO.MEAN, DO.STD))
     assert x.min() >= lo - 1e-4 and x.max() <= hi + 1e-4
-    # same seed -> same batch (the reference's geometry is unseeded; ours is reproducible)
-    x2, _ = data.TrainBatcher(128, device="cpu", seed=7)(imgs, labels)
-    assert torch.equal(x, x2)
+    v = DO.val_image(img, 64)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1).double()[None], size=(64, 64), mode="bilinear",
+                                          align_corners=False)[0]
+    m = torch.tensor(DO.MEAN).view(3, 1, 1)
+    s = torch.tensor(DO.STD).view(3, 1, 1)
+    np.testing.assert_allclose(v, ((ref / 255 - m) / s).float().numpy(), atol=1e-6)
 
 
-def test_val_batch_matches_manual():
-    rng = np.random.default_rng(2)
-    img = rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)
-    x = data.val_batch([img], 64, device="cpu")
-    ref = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1).float()[None], size=(64, 64),
-                                          mode="bilinear", align_corners=False)[0]
-    m = torch.tensor(data.MEAN).view(3, 1, 1)
-    s = torch.tensor(data.STD).view(3, 1, 1)
-    torch.testing.assert_close(x[0], (ref / 255 - m) / s)
+def test_no_cpu_path():
+    from acr_wsss_amd._lib import AcrHipError
+    with pytest.raises(AcrHipError):
+        data.val_batch([np.zeros((8, 8, 3), np.uint8)], 16, device="cpu")
