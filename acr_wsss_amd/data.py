@@ -29,7 +29,8 @@ STD = (0.229, 0.224, 0.225)
 
 PRE_IMAGE = np.dtype([("offset", "<i8"), ("h", "<i4"), ("w", "<i4"), ("rh", "<i4"), ("rw", "<i4"), ("flip", "<i4"),
                       ("cont_top", "<i4"), ("cont_left", "<i4"), ("img_top", "<i4"), ("img_left", "<i4"), ("ch", "<i4"),
-                      ("cw", "<i4")])                       # struct acr_pre_image
+                      ("cw", "<i4"), ("_pad", "<i4")])      # struct acr_pre_image: 8-byte aligned -> 56 bytes
+assert PRE_IMAGE.itemsize == 56
 
 
 def load_cls_labels(path, names, num_classes=20):
@@ -76,6 +77,13 @@ def preprocess_batch(images_uint8, records, S, device, dtype=torch.float32):
         sn[o:o + s] = np.ascontiguousarray(a).reshape(-1)
     records = records.copy()
     records["offset"] = offs[:-1]
+    for rec, a in zip(records, images_uint8):               # the kernel trusts the table: validate it here
+        ok = (rec["h"] == a.shape[0] and rec["w"] == a.shape[1] and rec["rh"] > 0 and rec["rw"] > 0
+              and 0 <= rec["cont_top"] and rec["cont_top"] + rec["ch"] <= S and 0 <= rec["cont_left"] and rec["cont_left"] + rec["cw"] <= S
+              and 0 <= rec["img_top"] and rec["img_top"] + rec["ch"] <= rec["rh"] and 0 <= rec["img_left"]
+              and rec["img_left"] + rec["cw"] <= rec["rw"])
+        if not ok:
+            raise L.AcrHipError("acr_preprocess_batch: inconsistent geometry record %s for a %s image" % (rec, a.shape))
     packed = stage.to(device, non_blocking=True)
     table = torch.from_numpy(records.view(np.uint8).reshape(-1).copy()).to(device, non_blocking=True)
     out = torch.empty((len(images_uint8), 3, S, S), dtype=dtype, device=device)
@@ -107,7 +115,7 @@ class TrainBatcher:
         target_long = self.pyrandom.randint(int(S * 0.9), int(S / 0.875))
         nh, nw = resize_long_target(h, w, target_long)
         ct, cl, it, il, ch, cw = random_crop_boxes(nh, nw, S, self.pyrandom)
-        return (0, h, w, nh, nw, int(flip_p > 0.5), ct, cl, it, il, ch, cw)
+        return (0, h, w, nh, nw, int(flip_p > 0.5), ct, cl, it, il, ch, cw, 0)
 
     def __call__(self, images_uint8, labels):
         """images_uint8: list of (h,w,3) uint8 RGB arrays; labels: (B,C) tensor.  Returns (img, label) on the device."""
@@ -123,5 +131,5 @@ def val_batch(images_uint8, crop_size, device="cuda", dtype=torch.float32):
     S = crop_size
     rec = np.zeros(len(images_uint8), PRE_IMAGE)
     for i, a in enumerate(images_uint8):
-        rec[i] = (0, int(a.shape[0]), int(a.shape[1]), S, S, 0, 0, 0, 0, 0, S, S)
+        rec[i] = (0, int(a.shape[0]), int(a.shape[1]), S, S, 0, 0, 0, 0, 0, S, S, 0)
     return preprocess_batch(images_uint8, rec, S, device, dtype)

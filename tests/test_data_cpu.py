@@ -47,7 +47,7 @@ def test_host_draws_follow_the_reference_order():
     for (h, w) in ((375, 500), (500, 333), (120, 90), (800, 1200), (448, 448)):
         rec = b.draw(h, w)
         g = DO.draw_train_geometry(h, w, 448, pr, nr)
-        assert rec[3:] == (g["rh"], g["rw"], g["flip"], g["cont_top"], g["cont_left"], g["img_top"], g["img_left"], g["ch"], g["cw"])
+        assert rec[3:12] == (g["rh"], g["rw"], g["flip"], g["cont_top"], g["cont_left"], g["img_top"], g["img_left"], g["ch"], g["cw"])
 
 
 def test_oracle_train_image_contract():
@@ -66,6 +66,19 @@ def test_oracle_train_image_contract():
     m = torch.tensor(DO.MEAN).view(3, 1, 1)
     s = torch.tensor(DO.STD).view(3, 1, 1)
     np.testing.assert_allclose(v, ((ref / 255 - m) / s).float().numpy(), atol=1e-6)
+
+
+def test_record_layout_matches_the_c_struct():
+    """acr_pre_image has an int64 first member: the C struct is padded to 56 bytes, and so must the numpy record be
+    (a 52-byte record made every image after the first read garbage geometry)."""
+    import re, os
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "acr_hip.h")).read()
+    body = re.search(r"typedef struct acr_pre_image \{(.*?)\} acr_pre_image;", hdr, re.S).group(1)
+    n64 = len(re.findall(r"int64_t\s+\w+", body))
+    n32 = sum(len(m.split(",")) for m in re.findall(r"int32_t\s+([\w,\s]+);", body))
+    assert (n64, n32) == (1, 11)
+    assert data.PRE_IMAGE.itemsize == (8 * n64 + 4 * n32 + 7) // 8 * 8 == 56
+    assert [data.PRE_IMAGE.fields[k][1] for k in ("offset", "h", "flip", "cw")] == [0, 8, 24, 48]
 
 
 def test_no_cpu_path():
