@@ -25,6 +25,16 @@ void acr_set_error(const char* fmt, ...);
 int acr_check_launch(const char* what);
 int32_t acr_opt(int option);          // explicit option table (acr_set_option), api.hip
 
+// ---- barrier that publishes LDS-DMA data ---------------------------------------------------------
+// `global_load_lds` writes LDS asynchronously and is tracked by the issuing wave's vmcnt only.  hipcc does NOT always put
+// the s_waitcnt vmcnt(0) in front of a __syncthreads() that follows (seen missing when the barrier sits at a loop head
+// reached over `continue` edges: waves passed the barrier with their DMA still in flight and a partner read stale LDS,
+// once in ~50 launches).  Every barrier that hands DMA'd tiles to other waves therefore goes through this.
+__device__ __forceinline__ void acr_dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // ---- XCD-aware block remap --------------------------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap the
 // linear block id so that each XCD walks one contiguous chunk of the work list: neighbouring

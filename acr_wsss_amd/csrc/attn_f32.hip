@@ -23,6 +23,7 @@
 //           with conflict-free ds_read_b32 -- no transposes, no lane shuffles.
 // On this fp32 path the MFMA pipe is the bound (64 cycles per 32x32x2); LDS and VALU hide under it.
 #include "acr_common.h"
+#include "attn_f32.h"
 
 #define LDP 68                     // LDS row pitch (floats): 64 + 4 -> conflict-free b128 row reads
 #define TILE_FLOATS (32 * LDP)
@@ -97,12 +98,6 @@ __device__ __forceinline__ void mma_accop_b(f32x16& acc, const f32x16& z, const 
     }
 }
 
-struct AttnGeom {
-    int B, H, T;
-    float scale;
-    int64_t sb, st, sh;       // q/k/v (and dq/dk/dv)
-    int64_t osb, ost, osh;    // o / do
-};
 
 // ---------------------------------------------------------------------------------------------
 // forward: grid = B*H*ceil(T/64) blocks (XCD-remapped), 2 waves, each wave owns 32 query rows
@@ -572,6 +567,11 @@ extern "C" int acr_attn_fwd(const acr_attn_desc* d, const void* q, const void* k
                   "acr_attn_fwd: q/k/v/o must be 16-byte (fp32) / 8-byte (bf16) aligned");
     ACR_CHECK_ARG(!pmean || (pmean_st >= d->T && pmean_sb >= (int64_t)d->T * pmean_st),
                   "acr_attn_fwd: pmean row pitch < T or batch stride < T*pitch");
+    if (f32 && acr_opt(ACR_OPT_ATTN_F32_GEN1) == 0) {
+        acr_attn_fwd_f32_dma(geom(d), (const float*)q, (const float*)k, (const float*)v, (float*)o, lse2, pmean, pmean_sb, pmean_st,
+                             (hipStream_t)stream);
+        return acr_check_launch("acr_attn_fwd");
+    }
     if (f32) return attn_fwd_t<float>(d, q, k, v, o, lse2, pmean, pmean_sb, pmean_st, (hipStream_t)stream);
     const void* ptrs[4] = {q, k, v, o};
     if (d->dtype == ACR_BF16 && acr_bf16_mfma_ok(d, ptrs, 4)) {
@@ -609,6 +609,11 @@ extern "C" int acr_attn_bwd(const acr_attn_desc* d, const void* q, const void* k
     ACR_CHECK_ARG(f32 ? (aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(d_o))
                       : (aligned8(q) && aligned8(k) && aligned8(v) && aligned8(o) && aligned8(d_o)),
                   "acr_attn_bwd: inputs must be 16-byte (fp32) / 8-byte (bf16) aligned");
+    if (f32 && acr_opt(ACR_OPT_ATTN_F32_GEN1) == 0) {
+        acr_attn_bwd_f32_dma(geom(d), (const float*)q, (const float*)k, (const float*)v, (const float*)o, (const float*)d_o, lse2,
+                             gmean, gmean_sb, gmean_st, (float*)dq, (float*)dk, (float*)dv, delta_ws, (hipStream_t)stream);
+        return acr_check_launch("acr_attn_bwd");
+    }
     if (f32)
         return attn_bwd_t<float>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, gmean_st, dq, dk, dv, delta_ws, (hipStream_t)stream);
     const void* ptrs[8] = {q, k, v, o, d_o, dq, dk, dv};

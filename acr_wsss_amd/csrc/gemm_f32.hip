@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
 
     dma_chunk<A_KC>(smem, g.a, g.lda, m0, g.M, kbeg, wave, lane);
     dma_chunk<B_KC>(smem + F_DTILE, g.b, g.ldb, n0, g.N, kbeg, wave, lane);
-    __syncthreads();
+    acr_dma_barrier();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += F_BK, cur ^= 1) {
         if (k0 + F_BK < kend) {
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) csum += sa[(2 * kk + (tid >> 7)) * F_BM + (tid & 127)];
         }
-        __syncthreads();                                    // drains the DMA (vmcnt) and frees buffer `cur`
+        acr_dma_barrier();                                  // the chunk in flight has landed; buffer `cur` is free
     }
 #ifdef LAB_STAMP
     if (tid == 0 && g.stamp) {
