@@ -85,6 +85,10 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                          c_void_p]),
     "acr_weight_std_bf16": (c_int32, [c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p]),
+    "acr_weight_std_f32": (c_int32, [c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p]),
+    "acr_layernorm_fwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
+    "acr_layernorm_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int32, c_int32, c_void_p]),
     "acr_preprocess_batch": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
                                        c_int32, c_void_p, c_void_p]),
     "acr_getam_row_accum": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,

@@ -164,11 +164,11 @@ class ResNetV2(nn.Module):
 
     def forward(self, x, taps=None):
         convs = None
-        if self.fused_weight_std and x.is_cuda and x.dtype == torch.bfloat16:
+        if self.fused_weight_std and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and not torch.is_autocast_enabled():
             # one HIP launch standardises all 52 conv weights (and one more in backward) instead of ~10 tiny
             # kernels per convolution and direction
             convs = [m for m in self.modules() if isinstance(m, StdConv2dSame)]
-            if all(c.weight.dtype == torch.bfloat16 for c in convs):
+            if all(c.weight.dtype == x.dtype for c in convs):
                 for c, w_hat in zip(convs, ops.weight_std_all([c.weight for c in convs], convs[0].eps)):
                     c._w_hat = w_hat
             else:

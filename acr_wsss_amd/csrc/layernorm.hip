@@ -17,9 +17,9 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
     return v;
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
-                                                     const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                     const T* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ stats, int M, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * LN_WAVES + (threadIdx.x >> 6), nw = gridDim.x * LN_WAVES;
@@ -27,16 +27,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     f32x4 ga[NV], be[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        ga[i] = acr_load4<bf16_t>(gamma + (i * 64 + lane) * 4);
-        be[i] = acr_load4<bf16_t>(beta + (i * 64 + lane) * 4);
+        ga[i] = acr_load4<T>(gamma + (i * 64 + lane) * 4);
+        be[i] = acr_load4<T>(beta + (i * 64 + lane) * 4);
     }
     for (int row = gw; row < M; row += nw) {
-        const bf16_t* xr = x + (int64_t)row * C;
+        const T* xr = x + (int64_t)row * C;
         f32x4 xv[NV];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            xv[i] = acr_load4<bf16_t>(xr + (i * 64 + lane) * 4);
+            xv[i] = acr_load4<T>(xr + (i * 64 + lane) * 4);
             s += xv[i][0] + xv[i][1] + xv[i][2] + xv[i][3];
         }
         const float mean = ln_wave_sum(s) * inv_c;
@@ -46,22 +46,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; ss = fmaf(d, d, ss); }
         const float rstd = rsqrtf(ln_wave_sum(ss) * inv_c + eps);
-        bf16_t* yr = y + (int64_t)row * C;
+        T* yr = y + (int64_t)row * C;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = fmaf((xv[i][e] - mean) * rstd, ga[i][e], be[i][e]);
-            acr_store4<bf16_t>(yr + (i * 64 + lane) * 4, o);
+            acr_store4<T>(yr + (i * 64 + lane) * 4, o);
         }
         if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
     }
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
-                                                     const bf16_t* __restrict__ gamma, const float* __restrict__ stats,
-                                                     const bf16_t* __restrict__ dskip, bf16_t* __restrict__ dx,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const T* __restrict__ gamma, const float* __restrict__ stats,
+                                                     const T* __restrict__ dskip, T* __restrict__ dx,
                                                      float* __restrict__ part, int M, int C) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * LN_WAVES + (threadIdx.x >> 6), nw = gridDim.x * LN_WAVES;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     f32x4 ga[NV], dg[NV], db[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        ga[i] = acr_load4<bf16_t>(gamma + (i * 64 + lane) * 4);
+        ga[i] = acr_load4<T>(gamma + (i * 64 + lane) * 4);
         dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const f32x4 xv = acr_load4<bf16_t>(x + (int64_t)row * C + (i * 64 + lane) * 4);
-            const f32x4 dv = acr_load4<bf16_t>(dy + (int64_t)row * C + (i * 64 + lane) * 4);
+            const f32x4 xv = acr_load4<T>(x + (int64_t)row * C + (i * 64 + lane) * 4);
+            const f32x4 dv = acr_load4<T>(dy + (int64_t)row * C + (i * 64 + lane) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 xh[i][e] = (xv[e] - mean) * rstd;
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rstd * (g[i][e] - c1 - xh[i][e] * c2);
-            if (dskip) o += acr_load4<bf16_t>(dskip + (int64_t)row * C + (i * 64 + lane) * 4);   // skip-path gradient
-            acr_store4<bf16_t>(dx + (int64_t)row * C + (i * 64 + lane) * 4, o);
+            if (dskip) o += acr_load4<T>(dskip + (int64_t)row * C + (i * 64 + lane) * 4);   // skip-path gradient
+            acr_store4<T>(dx + (int64_t)row * C + (i * 64 + lane) * 4, o);
         }
     }
     // the 4 waves of the workgroup are summed in wave order through LDS -> one (2, C) partial per workgroup
@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 
 // 32 columns x 8 row groups per block: each thread sums its share of the partials with 8 independent loads in flight,
 // the 8 groups are combined in a fixed order through LDS.
+template <typename T>
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int np, int C,
-                                                              bf16_t* __restrict__ dgamma, bf16_t* __restrict__ dbeta) {
+                                                              T* __restrict__ dgamma, T* __restrict__ dbeta) {
     __shared__ float sh[8][32];
     const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;                        // over 2*C columns (2*C % 32 == 0)
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
         float tot = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) tot += sh[u][cl];
-        if (c < C) dgamma[c] = (bf16_t)tot; else dbeta[c - C] = (bf16_t)tot;
+        if (c < C) acr_store1<T>(dgamma + c, tot); else acr_store1<T>(dbeta + c - C, tot);
     }
 }
 
@@ -152,12 +153,12 @@ static int ln_check(const char* who, int M, int C) {
     ACR_CHECK_ARG(M > 0 && C > 0 && (C % 256) == 0 && C <= 256 * LN_MAXV, "%s: C=%d must be a multiple of 256 and <= 1024", who, C);
     return ACR_OK;
 }
-#define LN_DISPATCH(KERNEL, ...)                                                                  \
-    switch (C / 256) {                                                                             \
-        case 1: hipLaunchKernelGGL((KERNEL<1>), grid, dim3(256), 0, st, __VA_ARGS__); break;       \
-        case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), 0, st, __VA_ARGS__); break;       \
-        case 3: hipLaunchKernelGGL((KERNEL<3>), grid, dim3(256), 0, st, __VA_ARGS__); break;       \
-        default: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), 0, st, __VA_ARGS__); break;      \
+#define LN_DISPATCH(KERNEL, TT, ...)                                                                  \
+    switch (C / 256) {                                                                                 \
+        case 1: hipLaunchKernelGGL((KERNEL<1, TT>), grid, dim3(256), 0, st, __VA_ARGS__); break;       \
+        case 2: hipLaunchKernelGGL((KERNEL<2, TT>), grid, dim3(256), 0, st, __VA_ARGS__); break;       \
+        case 3: hipLaunchKernelGGL((KERNEL<3, TT>), grid, dim3(256), 0, st, __VA_ARGS__); break;       \
+        default: hipLaunchKernelGGL((KERNEL<4, TT>), grid, dim3(256), 0, st, __VA_ARGS__); break;      \
     }
 
 extern "C" int acr_layernorm_fwd_bf16(const void* x, const void* gamma, const void* beta, void* y, float* stats,
@@ -167,7 +168,7 @@ extern "C" int acr_layernorm_fwd_bf16(const void* x, const void* gamma, const vo
     if (rc) return rc;
     const dim3 grid(ln_grid(M));
     hipStream_t st = (hipStream_t)stream;
-    LN_DISPATCH(ln_fwd_kernel, (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, stats, M, C, eps)
+    LN_DISPATCH(ln_fwd_kernel, bf16_t, (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, stats, M, C, eps)
     return acr_check_launch("acr_layernorm_fwd_bf16");
 }
 
@@ -179,9 +180,33 @@ extern "C" int acr_layernorm_bwd_bf16(const void* dy, const void* x, const void*
     if (rc) return rc;
     const dim3 grid(ln_grid(M));
     hipStream_t st = (hipStream_t)stream;
-    LN_DISPATCH(ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gamma, stats, (const bf16_t*)dskip,
+    LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gamma, stats, (const bf16_t*)dskip,
                 (bf16_t*)dx, ws, M, C)
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(2 * C / 32), dim3(256), 0, st, (const float*)ws, ln_grid(M), C,
+    hipLaunchKernelGGL(ln_param_reduce_kernel<bf16_t>, dim3(2 * C / 32), dim3(256), 0, st, (const float*)ws, ln_grid(M), C,
                        (bf16_t*)dgamma, (bf16_t*)dbeta);
     return acr_check_launch("acr_layernorm_bwd_bf16");
+}
+
+// ---- fp32 rows (reference precision): the same kernels on float tensors; vision_transformer.py:219-222 in the fp32 step ----
+extern "C" int acr_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* stats, int32_t M,
+                                     int32_t C, float eps, void* stream) {
+    ACR_CHECK_ARG(x && gamma && beta && y && stats, "acr_layernorm_fwd_f32: null pointer");
+    int rc = ln_check("acr_layernorm_fwd_f32", M, C);
+    if (rc) return rc;
+    const dim3 grid(ln_grid(M));
+    hipStream_t st = (hipStream_t)stream;
+    LN_DISPATCH(ln_fwd_kernel, float, x, gamma, beta, y, stats, M, C, eps)
+    return acr_check_launch("acr_layernorm_fwd_f32");
+}
+
+extern "C" int acr_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* stats, const float* dskip,
+                                     float* dx, float* ws, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream) {
+    ACR_CHECK_ARG(dy && x && gamma && stats && dx && ws && dgamma && dbeta, "acr_layernorm_bwd_f32: null pointer");
+    int rc = ln_check("acr_layernorm_bwd_f32", M, C);
+    if (rc) return rc;
+    const dim3 grid(ln_grid(M));
+    hipStream_t st = (hipStream_t)stream;
+    LN_DISPATCH(ln_bwd_kernel, float, dy, x, gamma, stats, dskip, dx, ws, M, C)
+    hipLaunchKernelGGL(ln_param_reduce_kernel<float>, dim3(2 * C / 32), dim3(256), 0, st, (const float*)ws, ln_grid(M), C, dgamma, dbeta);
+    return acr_check_launch("acr_layernorm_bwd_f32");
 }

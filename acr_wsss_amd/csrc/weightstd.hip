@@ -24,7 +24,7 @@ __device__ __forceinline__ float wstd_block_sum(float v, float* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-template <bool BWD>
+template <bool BWD, typename T>
 __global__ __launch_bounds__(256) void wstd_kernel(const WStdDesc* __restrict__ desc, int n_conv, float eps) {
     __shared__ float sh[4];
     const int ch = blockIdx.x;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void wstd_kernel(const WStdDesc* __restrict__ 
     while (ci + 1 < n_conv && desc[ci + 1].ch_start <= ch) ++ci;
     const WStdDesc d = desc[ci];
     const int c = ch - d.ch_start, n = d.n, tid = threadIdx.x;
-    const bf16_t* w = reinterpret_cast<const bf16_t*>(d.p0) + (int64_t)c * n;
+    const T* w = reinterpret_cast<const T*>(d.p0) + (int64_t)c * n;
     const float inv_n = 1.f / (float)n;
     float s = 0.f;
     for (int i = tid; i < n; i += 256) s += (float)w[i];
@@ -42,11 +42,11 @@ __global__ __launch_bounds__(256) void wstd_kernel(const WStdDesc* __restrict__ 
     const float sd = sqrtf(wstd_block_sum(ss, sh) * inv_n);
     const float inv = 1.f / (sd + eps);
     if (!BWD) {
-        bf16_t* out = reinterpret_cast<bf16_t*>(d.p1) + (int64_t)c * n;
-        for (int i = tid; i < n; i += 256) out[i] = (bf16_t)(((float)w[i] - mean) * inv);
+        T* out = reinterpret_cast<T*>(d.p1) + (int64_t)c * n;
+        for (int i = tid; i < n; i += 256) out[i] = (T)(((float)w[i] - mean) * inv);
     } else {
-        const bf16_t* g = reinterpret_cast<const bf16_t*>(d.p1) + (int64_t)c * n;
-        bf16_t* dw = reinterpret_cast<bf16_t*>(d.p2) + (int64_t)c * n;
+        const T* g = reinterpret_cast<const T*>(d.p1) + (int64_t)c * n;
+        T* dw = reinterpret_cast<T*>(d.p2) + (int64_t)c * n;
         float sg = 0.f, sgw = 0.f;
         for (int i = tid; i < n; i += 256) {
             const float gi = (float)g[i];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void wstd_kernel(const WStdDesc* __restrict__ 
         const float mgw = wstd_block_sum(sgw, sh) * inv_n;
         const float k = (sd > 0.f) ? mgw * (sd + eps) / sd : 0.f;
         for (int i = tid; i < n; i += 256)
-            dw[i] = (bf16_t)(((float)g[i] - mg - ((float)w[i] - mean) * inv * k) * inv);
+            dw[i] = (T)(((float)g[i] - mg - ((float)w[i] - mean) * inv * k) * inv);
     }
 }
 
@@ -65,10 +65,23 @@ extern "C" int acr_weight_std_bf16(const void* desc_dev, int32_t n_conv, int32_t
                                    int32_t backward, void* stream) {
     ACR_CHECK_ARG(desc_dev && n_conv > 0 && total_channels > 0, "acr_weight_std_bf16: bad arguments");
     if (backward)
-        hipLaunchKernelGGL((wstd_kernel<true>), dim3(total_channels), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((wstd_kernel<true, bf16_t>), dim3(total_channels), dim3(256), 0, (hipStream_t)stream,
                            (const WStdDesc*)desc_dev, n_conv, eps);
     else
-        hipLaunchKernelGGL((wstd_kernel<false>), dim3(total_channels), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((wstd_kernel<false, bf16_t>), dim3(total_channels), dim3(256), 0, (hipStream_t)stream,
                            (const WStdDesc*)desc_dev, n_conv, eps);
     return acr_check_launch("acr_weight_std_bf16");
+}
+
+// the same for fp32 weights (reference precision; replaces ~800 tiny elementwise / reduction launches per fp32 step)
+extern "C" int acr_weight_std_f32(const void* desc_dev, int32_t n_conv, int32_t total_channels, float eps, int32_t backward,
+                                  void* stream) {
+    ACR_CHECK_ARG(desc_dev && n_conv > 0 && total_channels > 0, "acr_weight_std_f32: bad arguments");
+    if (backward)
+        hipLaunchKernelGGL((wstd_kernel<true, float>), dim3(total_channels), dim3(256), 0, (hipStream_t)stream,
+                           (const WStdDesc*)desc_dev, n_conv, eps);
+    else
+        hipLaunchKernelGGL((wstd_kernel<false, float>), dim3(total_channels), dim3(256), 0, (hipStream_t)stream,
+                           (const WStdDesc*)desc_dev, n_conv, eps);
+    return acr_check_launch("acr_weight_std_f32");
 }

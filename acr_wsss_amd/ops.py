@@ -655,8 +655,8 @@ class LayerNormFn(Function):
         lib = L.load()
         y = torch.empty_like(x2)
         stats = torch.empty(2 * M, dtype=torch.float32, device=x.device)
-        L.check(lib.acr_layernorm_fwd_bf16(L.ptr(x2), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), M, C, eps,
-                                           L.stream_ptr()), "acr_layernorm_fwd_bf16")
+        fwd = lib.acr_layernorm_fwd_f32 if x.dtype == torch.float32 else lib.acr_layernorm_fwd_bf16
+        L.check(fwd(L.ptr(x2), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), M, C, eps, L.stream_ptr()), "acr_layernorm_fwd")
         ctx.save_for_backward(x2, weight, stats)
         ctx.set_materialize_grads(False)
         return y.reshape(x.shape), x.view_as(x)
@@ -669,8 +669,8 @@ class LayerNormFn(Function):
             return dskip, None, None, None
         lib = L.load()
         dy2 = dy.reshape(M, C)
-        if not dy2.is_contiguous():
-            dy2 = dy2.contiguous()
+        if not dy2.is_contiguous() or dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype).contiguous()
         ds2 = None
         if dskip is not None:
             ds2 = dskip.reshape(M, C)
@@ -678,17 +678,18 @@ class LayerNormFn(Function):
                 ds2 = ds2.to(x2.dtype).contiguous()
         dx = torch.empty_like(x2)
         ws = torch.empty(lib.acr_layernorm_ws_floats(M, C), dtype=torch.float32, device=x2.device)
-        dg = torch.empty(C, dtype=torch.bfloat16, device=x2.device)
-        db = torch.empty(C, dtype=torch.bfloat16, device=x2.device)
-        L.check(lib.acr_layernorm_bwd_bf16(L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats), L.ptr(ds2), L.ptr(dx),
-                                           L.ptr(ws), L.ptr(dg), L.ptr(db), M, C, L.stream_ptr()), "acr_layernorm_bwd_bf16")
+        dg = torch.empty(C, dtype=x2.dtype, device=x2.device)
+        db = torch.empty(C, dtype=x2.dtype, device=x2.device)
+        bwd = lib.acr_layernorm_bwd_f32 if x2.dtype == torch.float32 else lib.acr_layernorm_bwd_bf16
+        L.check(bwd(L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats), L.ptr(ds2), L.ptr(dx), L.ptr(ws), L.ptr(dg), L.ptr(db), M, C,
+                    L.stream_ptr()), "acr_layernorm_bwd")
         return dx.reshape(dy.shape), dg, db, None
 
 
 def layer_norm_fusable(x, ln):
     C = x.shape[-1]
-    return (x.is_cuda and x.dtype == torch.bfloat16 and ln.weight.dtype == torch.bfloat16 and x.is_contiguous()
-            and C % 256 == 0 and C <= 1024)
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and ln.weight.dtype == x.dtype and x.is_contiguous()
+            and C % 256 == 0 and C <= 1024 and not (x.dtype == torch.float32 and torch.is_autocast_enabled()))
 
 
 def layer_norm(x, ln, use_hip=True):
@@ -781,7 +782,8 @@ class WeightStdAllFn(Function):
         ws = [w.contiguous() for w in weights]
         outs = [torch.empty_like(w) for w in ws]
         desc, total = _wstd_desc(ws, outs, None, ws[0].device)
-        L.check(L.load().acr_weight_std_bf16(L.ptr(desc), len(ws), total, eps, 0, L.stream_ptr()), "acr_weight_std_bf16")
+        fn = L.load().acr_weight_std_f32 if ws[0].dtype == torch.float32 else L.load().acr_weight_std_bf16
+        L.check(fn(L.ptr(desc), len(ws), total, eps, 0, L.stream_ptr()), "acr_weight_std")
         ctx.save_for_backward(*ws)
         ctx.eps = eps
         ctx._keep = desc
@@ -793,7 +795,8 @@ class WeightStdAllFn(Function):
         gs = [g.contiguous() if g is not None else torch.zeros_like(w) for g, w in zip(grads, ws)]
         dws = [torch.empty_like(w) for w in ws]
         desc, total = _wstd_desc(list(ws), gs, dws, ws[0].device)
-        L.check(L.load().acr_weight_std_bf16(L.ptr(desc), len(ws), total, ctx.eps, 1, L.stream_ptr()), "acr_weight_std_bf16")
+        fn = L.load().acr_weight_std_f32 if ws[0].dtype == torch.float32 else L.load().acr_weight_std_bf16
+        L.check(fn(L.ptr(desc), len(ws), total, ctx.eps, 1, L.stream_ptr()), "acr_weight_std")
         ctx._keep_b = desc
         return (None,) + tuple(dws)
 

@@ -94,7 +94,9 @@ class MasterWeights:
     def state_dict(self):
         """fp32 masters + optimizer state (momentum buffers, lr schedule position): everything a resume needs on top of
         (or instead of) ``model.state_dict()``."""
-        return {"masters": [m.detach().clone() for m in self.masters], "optimizer": self.optimizer.state_dict(),
+        import copy
+        # a SNAPSHOT: optimizer.state_dict() hands out the live momentum buffers, which the next step updates in place
+        return {"masters": [m.detach().clone() for m in self.masters], "optimizer": copy.deepcopy(self.optimizer.state_dict()),
                 "global_step": self.optimizer.global_step}
 
     @torch.no_grad()

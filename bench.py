@@ -176,22 +176,27 @@ def roofline_probe(args, dev, dtype):
                 ("acr_gemm_f32_tn", "gemm_f32 TN (fc1 weight gradient)", lambda: ops.gemm_f32_raw("tn", dy, x, dww))):
             t = time_kernel(call, iters=5)
             kernels[key] = _mfma_rec(name, fl, fl, t, peak)
-    # in-step rocprofv3 durations of this round (same command, kernel-trace; scripts/step_breakdown.py), and the PMC traffic
-    in_step, traffic, top = {}, None, None
+    # in-step rocprofv3 durations of this round (scripts/profile_round.sh + scripts/make_in_step.py: kernel trace of this very
+    # command) and the HBM traffic of the probe's launches from the two separate PMC passes; the record's head is the
+    # kernel group on TOP of the in-step profile, not the one that looks worst
+    in_step, traffic, top = {}, {}, None
     try:
         with open(IN_STEP) as f:
             rec = json.load(f).get(dtype, {})
         if (args.batch, args.size) == (16, 448):
-            in_step, traffic, top = rec.get("kernels", {}), rec.get("traffic_bytes_per_launch"), rec.get("top")
+            in_step, traffic, top = rec.get("kernels", {}), rec.get("traffic", {}), rec.get("top")
     except OSError:
         pass
     for k, v in in_step.items():
         if k in kernels:
-            kernels[k]["in_step_us"] = v
+            kernels[k]["in_step"] = {"kernel_launches_per_step": v["kernel_launches_per_step"], "ms_per_step": v["ms_per_step"]}
+    for k, v in traffic.items():
+        if k in kernels:
+            kernels[k]["traffic"] = v.get("bytes_per_launch")
     if top not in kernels:                               # no profile committed yet for this dtype: slowest MFMA group of the probe
         top = max((k for k in kernels if kernels[k]["bound"] == "mfma"), key=lambda k: kernels[k]["launch_ms"])
     head = dict(kernels[top])
-    head["traffic"] = traffic.get(top) if isinstance(traffic, dict) else None
+    head.setdefault("traffic", None)
     head["kernels"] = {k: v for k, v in kernels.items() if k != top}
     return head
 

@@ -216,6 +216,12 @@ int acr_layernorm_fwd_bf16(const void* x, const void* gamma, const void* beta, v
 int acr_layernorm_bwd_bf16(const void* dy, const void* x, const void* gamma, const float* stats, const void* dskip,
                            void* dx, float* ws, void* dgamma, void* dbeta, int32_t M, int32_t C, void* stream);
 
+/* fp32 rows (reference precision), same contract with float tensors. */
+int acr_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* stats, int32_t M, int32_t C,
+                          float eps, void* stream);
+int acr_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* stats, const float* dskip, float* dx,
+                          float* ws, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream);
+
 /* ---- ResNetV2 stem: fused GroupNorm(32) [+ residual] [+ ReLU], bf16 NCHW ----
  * models/layers/norm_act.py:69-85 (GroupNormAct), models/resnetv2.py:205-215 (norm3 -> act3(x + shortcut)).
  * act: 0 = none, 1 = ReLU, 2 = ReLU(gn(x) + resid).  x/resid/y: (N,C,H,W) contiguous, HW = H*W (multiple of 8),
@@ -234,6 +240,8 @@ int acr_groupnorm_bwd_bf16(const void* dy, const void* x, const void* resid, con
  * backward: p0 = w, p1 = dL/dw_hat, p2 = dL/dw out.  bf16 tensors, fp32 statistics. */
 int acr_weight_std_bf16(const void* desc_dev, int32_t n_conv, int32_t total_channels, float eps, int32_t backward,
                         void* stream);
+int acr_weight_std_f32(const void* desc_dev, int32_t n_conv, int32_t total_channels, float eps, int32_t backward,
+                       void* stream);                /* fp32 tensors, same descriptor table */
 
 /* ---- attention-consistency regulariser (train_acr.py:143-161, inline in train()) ----
  * a1, a2: (B,L,T,T) fp32 head-mean stacks of view 1 / view 2 (T = p*p + 1), batch stride a_sb each

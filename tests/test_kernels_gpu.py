@@ -507,3 +507,49 @@ def test_fused_mlp_f32(M, D, Hd):
     for n, a, b in zip(["y", "dx", "dresid", "dW1", "db1", "dW2", "db2"], got, want):
         err = (a.double() - b).abs().max().item() / max(b.abs().max().item(), 1e-9)
         assert err <= 2e-5, (n, err)
+
+
+@pytest.mark.parametrize("M,C", [(1, 256), (37, 768), (25120, 768), (130, 1024)])
+def test_layernorm_f32(M, C):
+    """fp32 rows through the HIP LayerNorm (reference precision): forward, dx with the fused skip gradient, dgamma, dbeta
+    against fp64."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(dev).requires_grad_(True)
+    ln = torch.nn.LayerNorm(C, eps=1e-6).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+        ln.bias.copy_(0.3 * torch.randn(C, generator=g))
+    assert ops.layer_norm_fusable(x, ln)
+    y, skip = ops.layer_norm_skip(x, ln)
+    dy = torch.randn(M, C, generator=g).to(dev)
+    ds = torch.randn(M, C, generator=g).to(dev)
+    ((y * dy).sum() + (skip * ds).sum()).backward()
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = ln.weight.detach().double().requires_grad_(True), ln.bias.detach().double().requires_grad_(True)
+    ref = F.layer_norm(xd, (C,), wd, bd, 1e-6)
+    ((ref * dy.double()).sum() + (xd * ds.double()).sum()).backward()
+    for n, a, b in (("y", y, ref), ("dx", x.grad, xd.grad), ("dgamma", ln.weight.grad, wd.grad), ("dbeta", ln.bias.grad, bd.grad)):
+        err = (a.double() - b).abs().max() / b.abs().max()
+        assert err <= 2e-5, (n, float(err))
+
+
+def test_weight_std_all_f32():
+    """One-launch weight standardisation on fp32 weights vs the fp64 expression (std_conv.py:56-59), forward + backward."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    shapes = [(64, 3, 7, 7), (64, 64, 1, 1), (256, 64, 3, 3), (33, 5, 1, 1)]
+    ws = [(torch.randn(s, generator=g) * 0.3 + 0.05).to(dev).requires_grad_(True) for s in shapes]
+    outs = ops.weight_std_all(ws)
+    gs = [torch.randn(s, generator=g).to(dev) for s in shapes]
+    sum((o * gi).sum() for o, gi in zip(outs, gs)).backward()
+    for w, o, gi in zip(ws, outs, gs):
+        wd = w.detach().double().requires_grad_(True)
+        std, mean = torch.std_mean(wd, dim=[1, 2, 3], keepdim=True, unbiased=False)
+        ref = (wd - mean) / (std + 1e-5)
+        (ref * gi.double()).sum().backward()
+        assert (o.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+        assert (w.grad.double() - wd.grad).abs().max() <= 5e-5 * wd.grad.abs().max()
