@@ -712,14 +712,18 @@ def layer_norm_skip(x, ln, use_hip=True):
 
 
 GN_ACT = {"none": 0, "relu": 1, "add_relu": 2}
+F32_HIP_NORMS = os.environ.get("ACR_F32_HIP_NORMS", "1") != "0"      # A/B switch: fp32 GroupNorm on the HIP kernels vs torch
 
 
 def groupnorm_fusable(x, resid=None):
     """Shapes/dtypes the fused bf16 GroupNorm kernel handles (everything else stays on torch ops)."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()):
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.dim() == 4 and x.is_contiguous()):
         return False
     N, C, H, W = x.shape
-    if C % 32 or (H * W) % 8 or (C // 32) * H * W // 8 > 1024 * 13:
+    if x.dtype == torch.float32:                            # streaming fp32 kernels: any group size, HW % 4 == 0
+        if C % 32 or (H * W) % 4 or torch.is_autocast_enabled() or not F32_HIP_NORMS:
+            return False
+    elif C % 32 or (H * W) % 8 or (C // 32) * H * W // 8 > 1024 * 13:
         return False
     return resid is None or (resid.shape == x.shape and resid.dtype == x.dtype and resid.is_contiguous())
 
@@ -733,8 +737,9 @@ class GroupNormActFn(Function):
         lib = L.load()
         y = torch.empty_like(x)
         stats = torch.empty(N * 32 * 2, dtype=torch.float32, device=x.device)
-        L.check(lib.acr_groupnorm_fwd_bf16(L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats),
-                                           N, C, H * W, eps, act, L.stream_ptr()), "acr_groupnorm_fwd_bf16")
+        fwd = lib.acr_groupnorm_fwd_f32 if x.dtype == torch.float32 else lib.acr_groupnorm_fwd_bf16
+        L.check(fwd(L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), N, C, H * W, eps, act, L.stream_ptr()),
+                "acr_groupnorm_fwd")
         ctx.save_for_backward(x, weight, bias, stats, resid if act == 2 else None)
         ctx.act = act
         return y
@@ -744,15 +749,15 @@ class GroupNormActFn(Function):
         x, weight, bias, stats, resid = ctx.saved_tensors
         N, C, H, W = x.shape
         lib = L.load()
-        if not dy.is_contiguous():
-            dy = dy.contiguous()
+        if not dy.is_contiguous() or dy.dtype != x.dtype:
+            dy = dy.to(x.dtype).contiguous()
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.act == 2 else None
         part = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
-        dgb = torch.empty((2, C), dtype=torch.bfloat16, device=x.device)      # summed over samples inside the call
-        L.check(lib.acr_groupnorm_bwd_bf16(L.ptr(dy), L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(stats),
-                                           L.ptr(dx), L.ptr(dres), L.ptr(part[0]), L.ptr(part[1]), L.ptr(dgb[0]),
-                                           L.ptr(dgb[1]), N, C, H * W, ctx.act, L.stream_ptr()), "acr_groupnorm_bwd_bf16")
+        dgb = torch.empty((2, C), dtype=x.dtype, device=x.device)             # summed over samples inside the call
+        bwd = lib.acr_groupnorm_bwd_f32 if x.dtype == torch.float32 else lib.acr_groupnorm_bwd_bf16
+        L.check(bwd(L.ptr(dy), L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(stats), L.ptr(dx), L.ptr(dres), L.ptr(part[0]),
+                    L.ptr(part[1]), L.ptr(dgb[0]), L.ptr(dgb[1]), N, C, H * W, ctx.act, L.stream_ptr()), "acr_groupnorm_bwd")
         return dx, dgb[0], dgb[1], dres, None, None
 
 

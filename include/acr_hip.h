@@ -234,6 +234,14 @@ int acr_groupnorm_bwd_bf16(const void* dy, const void* x, const void* resid, con
                            const float* stats, void* dx, void* dresid, float* dgamma_part, float* dbeta_part,
                            void* dgamma, void* dbeta, int32_t N, int32_t C, int32_t HW, int32_t act, void* stream);
 
+/* The same at the reference precision (fp32 NCHW tensors, fp32 gamma / beta / gradients): a group is streamed twice instead
+ * of being held in registers; HW a multiple of 4; deterministic (fixed-order block reductions, no atomics). */
+int acr_groupnorm_fwd_f32(const float* x, const float* resid, const float* gamma, const float* beta, float* y, float* stats,
+                          int32_t N, int32_t C, int32_t HW, float eps, int32_t act, void* stream);
+int acr_groupnorm_bwd_f32(const float* dy, const float* x, const float* resid, const float* gamma, const float* beta,
+                          const float* stats, float* dx, float* dresid, float* dgamma_part, float* dbeta_part, float* dgamma,
+                          float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t act, void* stream);
+
 /* Weight standardisation of all StdConv2dSame weights of the stem in one launch (models/layers/std_conv.py:56-59).
  * desc_dev: device array of n_conv records {uint64 p0,p1,p2,p3; int32 cout, n, ch_start, pad} sorted by ch_start
  * (first global output-channel index of the conv), n = fan-in.  forward (backward = 0): p0 = w, p1 = w_hat out;

@@ -553,3 +553,42 @@ def test_weight_std_all_f32():
         (ref * gi.double()).sum().backward()
         assert (o.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
         assert (w.grad.double() - wd.grad).abs().max() <= 5e-5 * wd.grad.abs().max()
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 8, 8), (3, 256, 16, 24), (2, 1024, 28, 28), (1, 64, 224, 224), (2, 256, 112, 112),
+                                     (2, 96, 6, 6)])
+@pytest.mark.parametrize("act", ["none", "relu", "add_relu"])
+def test_groupnorm_f32(N, C, H, W, act):
+    """fp32 streaming GroupNorm(32) [+ residual] [+ ReLU] forward/backward (reference precision) vs fp64; includes the
+    largest groups of the 448^2 stem (8 x 112^2 and 2 x 224^2 floats = 401 KB) and tiny groups (3 x 36)."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.7 + 0.3).to(dev).requires_grad_(True)
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(dev).requires_grad_(True)
+    b = (0.3 * torch.randn(C, generator=g)).to(dev).requires_grad_(True)
+    r = torch.randn(N, C, H, W, generator=g).to(dev).requires_grad_(True) if act == "add_relu" else None
+    assert ops.groupnorm_fusable(x, r)
+    y = ops.groupnorm_act(x, w, b, act, r)
+    dy = torch.randn(N, C, H, W, generator=g).to(dev)
+    (y * dy).sum().backward()
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    ref = F.group_norm(xd, 32, wd, bd, 1e-5)
+    if r is not None:
+        rd = r.detach().double().requires_grad_(True)
+        ref = ref + rd
+    if act != "none":
+        ref = ref * (y.detach() > 0).double()               # the kernel's own mask: elements within 1e-7 of 0 may differ
+    (ref * dy.double()).sum().backward()
+    assert (y.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    assert (x.grad.double() - xd.grad).abs().max() <= 2e-5 * xd.grad.abs().max()
+    assert (w.grad.double() - wd.grad).abs().max() <= 2e-5 * wd.grad.abs().max() + 1e-6
+    assert (b.grad.double() - bd.grad).abs().max() <= 2e-5 * bd.grad.abs().max() + 1e-6
+    if r is not None:
+        assert (r.grad.double() - rd.grad).abs().max() <= 1e-6 * rd.grad.abs().max()
+    # deterministic
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = ops.groupnorm_act(x2, w.detach(), b.detach(), act, r.detach() if r is not None else None)
+    (y2 * dy).sum().backward()
+    assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad)
