@@ -41,6 +41,10 @@ struct GemmF32Args {
     float* cs;                     // TN: per-split column sums of A (bias gradient slabs) or null
     int M, N, K;
     int tiles_m, tiles_n, nsplit, kps;   // kps: contraction elements per split (multiple of F_BK)
+    // z-slices: workgroup slice z = split index.  K-split (weight gradient of a Linear): operands shared, k range z*k_zs..;
+    // batch (1x1 convolutions per sample): operands / outputs advance by *_zs per slice, k range the whole contraction
+    int64_t a_zs, b_zs, c_zs, aux_zs;
+    int k_zs, ksplit;                    // slice z = split / ksplit (operand / output offsets), contraction part split % ksplit
 #ifdef LAB_STAMP
     unsigned long long* stamp;
 #endif
@@ -147,7 +151,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
     const int split = t / ntile, tt = t - split * ntile;
     const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
     const int m0 = tm * F_BM, n0 = tn * F_BN;
-    const int kbeg = split * g.kps, kend = min(g.K, kbeg + g.kps);
+    const int zs = split / g.ksplit;
+    const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);
+    const float* __restrict__ pa = g.a + (int64_t)zs * g.a_zs;
+    const float* __restrict__ pb = g.b + (int64_t)zs * g.b_zs;
 
 #ifdef LAB_STAMP
     const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
@@ -195,8 +202,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
     // k0 + BK from (sa_, sb_) to LDS[buf ^ 1]
     auto step = [&](f32x4 (&la)[4], f32x4 (&lb)[4], f32x4 (&sa_)[4], f32x4 (&sb_)[4], int k0, int buf) {
         if (k0 + 2 * F_BK < kend) {
-            load_chunk<A_KC>(la, g.a, g.lda, m0, g.M, k0 + 2 * F_BK, kend, tid);
-            load_chunk<B_KC>(lb, g.b, g.ldb, n0, g.N, k0 + 2 * F_BK, kend, tid);
+            load_chunk<A_KC>(la, pa, g.lda, m0, g.M, k0 + 2 * F_BK, kend, tid);
+            load_chunk<B_KC>(lb, pb, g.ldb, n0, g.N, k0 + 2 * F_BK, kend, tid);
         }
         compute(buf);
         if (k0 + F_BK < kend) {
@@ -207,11 +214,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
         }
         __syncthreads();
     };
-    load_chunk<A_KC>(ra0, g.a, g.lda, m0, g.M, kbeg, kend, tid);
-    load_chunk<B_KC>(rb0, g.b, g.ldb, n0, g.N, kbeg, kend, tid);
+    load_chunk<A_KC>(ra0, pa, g.lda, m0, g.M, kbeg, kend, tid);
+    load_chunk<B_KC>(rb0, pb, g.ldb, n0, g.N, kbeg, kend, tid);
     if (kbeg + F_BK < kend) {
-        load_chunk<A_KC>(ra1, g.a, g.lda, m0, g.M, kbeg + F_BK, kend, tid);
-        load_chunk<B_KC>(rb1, g.b, g.ldb, n0, g.N, kbeg + F_BK, kend, tid);
+        load_chunk<A_KC>(ra1, pa, g.lda, m0, g.M, kbeg + F_BK, kend, tid);
+        load_chunk<B_KC>(rb1, pb, g.ldb, n0, g.N, kbeg + F_BK, kend, tid);
     }
     store_chunk<A_KC>(smem, ra0, kbeg, kend, tid);
     store_chunk<B_KC>(smem + F_STAGE, rb0, kbeg, kend, tid);
@@ -256,10 +263,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
         }
         return;
     }
+    GemmF32Args gz = g;                                     // this slice's output / addend
+    gz.c += (int64_t)zs * g.c_zs;
+    if (gz.aux) gz.aux += (int64_t)zs * g.aux_zs;
     if (m0 + F_BM <= g.M && n0 + F_BN <= g.N)
-        epilogue_f32<ACT, false>(g, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+        epilogue_f32<ACT, false>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
     else
-        epilogue_f32<ACT, true>(g, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+        epilogue_f32<ACT, true>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
 }
 
 
@@ -318,7 +328,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
     const int split = t / ntile, tt = t - split * ntile;
     const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
     const int m0 = tm * F_BM, n0 = tn * F_BN;
-    const int kbeg = split * g.kps, kend = min(g.K, kbeg + g.kps);      // host guarantees (kend - kbeg) % F_BK == 0
+    const int zs = split / g.ksplit;
+    const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);      // host: (kend - kbeg) % F_BK == 0
+    const float* __restrict__ pa = g.a + (int64_t)zs * g.a_zs;
+    const float* __restrict__ pb = g.b + (int64_t)zs * g.b_zs;
 #ifdef LAB_STAMP
     const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -332,15 +345,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
     float csum = 0.f;          // TN bias gradient: column tid & 127 of the A chunks, k rows of parity tid >> 7
     const bool want_cs = ACT == 3 && !A_KC && g.cs && tn == 0;
 
-    dma_chunk<A_KC>(smem, g.a, g.lda, m0, g.M, kbeg, wave, lane);
-    dma_chunk<B_KC>(smem + F_DTILE, g.b, g.ldb, n0, g.N, kbeg, wave, lane);
+    dma_chunk<A_KC>(smem, pa, g.lda, m0, g.M, kbeg, wave, lane);
+    dma_chunk<B_KC>(smem + F_DTILE, pb, g.ldb, n0, g.N, kbeg, wave, lane);
     acr_dma_barrier();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += F_BK, cur ^= 1) {
         if (k0 + F_BK < kend) {
             float* d = smem + (cur ^ 1) * 2 * F_DTILE;
-            dma_chunk<A_KC>(d, g.a, g.lda, m0, g.M, k0 + F_BK, wave, lane);
-            dma_chunk<B_KC>(d + F_DTILE, g.b, g.ldb, n0, g.N, k0 + F_BK, wave, lane);
+            dma_chunk<A_KC>(d, pa, g.lda, m0, g.M, k0 + F_BK, wave, lane);
+            dma_chunk<B_KC>(d + F_DTILE, pb, g.ldb, n0, g.N, k0 + F_BK, wave, lane);
         }
         const float* sa = smem + cur * 2 * F_DTILE;
         const float* sb = sa + F_DTILE;
@@ -392,10 +405,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
         }
         return;
     }
+    GemmF32Args gz = g;
+    gz.c += (int64_t)zs * g.c_zs;
+    if (gz.aux) gz.aux += (int64_t)zs * g.aux_zs;
     if (m0 + F_BM <= g.M && n0 + F_BN <= g.N)
-        epilogue_f32<ACT, false>(g, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+        epilogue_f32<ACT, false>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
     else
-        epilogue_f32<ACT, true>(g, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+        epilogue_f32<ACT, true>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
 }
 
 // out[i] = sum_s slab[s][i] in split order (deterministic), float4 per thread; n4 = elements / 4
@@ -465,6 +481,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
     g.stamp = g_lab_stamp;
 #endif
     g.tiles_m = (M + F_BM - 1) / F_BM; g.tiles_n = (N + F_BN - 1) / F_BN; g.nsplit = 1; g.kps = (K + F_BK - 1) / F_BK * F_BK;
+    g.a_zs = g.b_zs = g.c_zs = g.aux_zs = 0; g.k_zs = g.kps; g.ksplit = 1 << 30;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
     if (mode == ACR_GEMM_TN) {
         // c[M,N] = a[K,M]^T b[K,N]: both operands contraction-strided; M, N are the weight's dims, K the token count
@@ -472,7 +489,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         ACR_CHECK_ARG(ws, "acr_gemm_f32: TN needs the acr_gemm_f32_ws_floats workspace");
         ACR_CHECK_ARG((M % 4) == 0 && (N % 4) == 0 && M >= 4 && N >= 4 && ldc == N && al16(c), "acr_gemm_f32: TN needs M, N %% 4 == 0 and a dense output (ldc == N)");
         const TnPlan p = tn_plan(M, N, K);
-        g.nsplit = p.nsplit; g.kps = p.kps;
+        g.nsplit = p.nsplit; g.kps = p.kps; g.k_zs = p.kps;
         g.c = ws; g.ldc = N;
         g.cs = colsum ? ws + (size_t)p.nsplit * M * N : nullptr;
         if ((K % F_BK) == 0)
@@ -506,4 +523,90 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
     }
 #undef ACR_F32_LAUNCH
     return acr_check_launch("acr_gemm_f32");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions of the ResNetV2 stem at the reference precision (models/resnetv2.py:186-190, fp32 NCHW, stride 1) on the
+// same kernels, one z-slice per sample, no layout change:
+//   forward  y[n] (co x hw) = W (co x ci) . x[n] (ci x hw)            A = W  [i][k] contiguous in k, B = x[n]  [k][i]
+//   input    dx[n] (ci x hw) = W^T . dy[n] (co x hw) (+ addend[n])     A = W  read as [k = co][i = ci],  B = dy[n] [k][i]
+//   weight   dW (co x ci) = sum_n dy[n] (co x hw) . x[n]^T            A = dy[n], B = x[n], both contiguous in the contraction
+//            (hw): one fp32 slab per sample, summed in sample order (deterministic)
+// ---------------------------------------------------------------------------------------------------------------
+static void conv_args(GemmF32Args& g, int M, int N, int K) {
+    g.bias = nullptr; g.aux = nullptr; g.ldaux = 0; g.c2 = nullptr; g.cs = nullptr; g.M = M; g.N = N; g.K = K;
+    g.tiles_m = (M + F_BM - 1) / F_BM; g.tiles_n = (N + F_BN - 1) / F_BN; g.kps = (K + F_BK - 1) / F_BK * F_BK; g.k_zs = 0;
+    g.a_zs = g.b_zs = g.c_zs = g.aux_zs = 0; g.ksplit = 1;
+}
+
+extern "C" int acr_conv1x1_f32(const float* w, int32_t w_transposed, const float* x, const float* addend, float* y, int32_t nsamp,
+                               int32_t cout, int32_t cin, int32_t hw, void* stream) {
+    // cout / cin are the channel counts of THIS product.  w_transposed = 0: w is (cout, cin).  w_transposed = 1: w is stored
+    // (cin, cout) -- the forward convolution's weight handed over as is for the input gradient, where the roles swap.
+    ACR_CHECK_ARG(w && x && y, "acr_conv1x1_f32: null pointer");
+    ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && hw > 0 && (hw % 4) == 0 && (cin % 4) == 0 && (cout % 4) == 0,
+                  "acr_conv1x1_f32: need hw, cin, cout %% 4 == 0 (n=%d co=%d ci=%d hw=%d)", nsamp, cout, cin, hw);
+    ACR_CHECK_ARG(al16(w) && al16(x) && al16(y) && al16(addend), "acr_conv1x1_f32: 16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    GemmF32Args g;
+    conv_args(g, cout, hw, cin);
+    g.a = w; g.b = x; g.ldb = hw; g.b_zs = (int64_t)cin * hw;
+    g.c = y; g.ldc = hw; g.c_zs = (int64_t)cout * hw;
+    g.aux = addend; g.ldaux = hw; g.aux_zs = (int64_t)cout * hw;
+    g.nsplit = nsamp;
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n * nsamp));
+    const bool dma = (cin % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0;
+    if (!w_transposed) {                    // w = (cout, cin): rows = output channels, k contiguous
+        g.lda = cin;
+        if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 0>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<true, false, 0>), grid, dim3(256), 0, st, g);
+    } else {                                                // w = (cin, cout) as stored by the forward conv: A[i][k] = w[k][i]
+        g.lda = cout;
+        if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false, 0>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<false, false, 0>), grid, dim3(256), 0, st, g);
+    }
+    return acr_check_launch("acr_conv1x1_f32");
+}
+
+// pixels of a sample are additionally split so that tiles x samples x parts fills the chip's 512 workgroup slots (a 64x64
+// weight at 112^2 is ONE tile per sample: 32 workgroups of 392 chunks each otherwise); at least 512 pixels per part
+static int conv_wgrad_ksplit(int nsamp, int cout, int cin, int hw) {
+    const int tiles = ((cout + F_BM - 1) / F_BM) * ((cin + F_BN - 1) / F_BN) * nsamp;
+    int ks = 512 / tiles;
+    const int maxs = hw / 512;
+    if (ks > maxs) ks = maxs;
+    if (ks < 1) ks = 1;
+    const int kps = ((hw + ks - 1) / ks + F_BK - 1) / F_BK * F_BK;
+    return (hw + kps - 1) / kps;                            // every part non-empty
+}
+extern "C" size_t acr_conv1x1_wgrad_f32_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t hw) {
+    return (size_t)nsamp * conv_wgrad_ksplit(nsamp, cout, cin, hw) * cout * cin;
+}
+
+extern "C" int acr_conv1x1_wgrad_f32(const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw, float* ws,
+                                     float* dw, void* stream) {
+    ACR_CHECK_ARG(dy && x && ws && dw, "acr_conv1x1_wgrad_f32: null pointer");
+    ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && hw > 0 && (hw % 4) == 0 && (cin % 4) == 0 && (cout % 4) == 0,
+                  "acr_conv1x1_wgrad_f32: need hw, cin, cout %% 4 == 0");
+    ACR_CHECK_ARG(al16(dy) && al16(x) && al16(dw) && al16(ws), "acr_conv1x1_wgrad_f32: 16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    GemmF32Args g;
+    conv_args(g, cout, cin, hw);
+    g.a = dy; g.lda = hw; g.a_zs = (int64_t)cout * hw;
+    g.b = x; g.ldb = hw; g.b_zs = (int64_t)cin * hw;
+    g.c = ws; g.ldc = cin;
+    const int ks = conv_wgrad_ksplit(nsamp, cout, cin, hw);
+    g.ksplit = ks;
+    g.kps = ((hw + ks - 1) / ks + F_BK - 1) / F_BK * F_BK;
+    ACR_CHECK_ARG((int64_t)(ks - 1) * g.kps < hw, "acr_conv1x1_wgrad_f32: internal split plan");
+    g.k_zs = g.kps;
+    g.nsplit = nsamp * ks;
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.nsplit));
+    if ((hw % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0)
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 3>), grid, dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<true, true, 3>), grid, dim3(256), 0, st, g);
+    const int64_t n4 = (int64_t)cout * cin / 4;
+    hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, g.nsplit, n4, dw);
+    return acr_check_launch("acr_conv1x1_wgrad_f32");
 }

@@ -576,11 +576,16 @@ def maxpool3x3s2_same(x, pt, pl, ph, pw):
     return MaxPoolSameFn.apply(x, pt, pl, ph, pw)
 
 
+F32_HIP_CONV1X1 = os.environ.get("ACR_F32_HIP_CONV1X1", "1") != "0"      # A/B switch: fp32 1x1 convolutions on acr_conv1x1_f32 vs MIOpen
+
+
 def conv1x1_fusable(x, weight, stride):
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()):
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and weight.dtype == x.dtype and x.dim() == 4 and x.is_contiguous()):
         return False
     N, C, H, W = x.shape
     co, ci = weight.shape[0], weight.shape[1]
+    if x.dtype == torch.float32 and (not F32_HIP_CONV1X1 or torch.is_autocast_enabled()):
+        return False
     return (stride == 1 and weight.shape[2] == 1 and weight.shape[3] == 1 and ci % 64 == 0 and co % 64 == 0
             and (H * W) % 8 == 0)
 
@@ -597,8 +602,12 @@ class Conv1x1Fn(Function):
         co = weight.shape[0]
         w2 = weight.reshape(co, C)
         y = torch.empty((N, co, H, W), dtype=x.dtype, device=x.device)
-        L.check(L.load().acr_conv1x1_bf16(L.ptr(w2), w2.stride(0), L.ptr(x), None, L.ptr(y), N, co, C, H * W, L.stream_ptr()),
-                "acr_conv1x1_bf16")
+        if x.dtype == torch.float32:
+            w2 = w2.contiguous()
+            L.check(L.load().acr_conv1x1_f32(L.ptr(w2), 0, L.ptr(x), None, L.ptr(y), N, co, C, H * W, L.stream_ptr()), "acr_conv1x1_f32")
+        else:
+            L.check(L.load().acr_conv1x1_bf16(L.ptr(w2), w2.stride(0), L.ptr(x), None, L.ptr(y), N, co, C, H * W, L.stream_ptr()),
+                    "acr_conv1x1_bf16")
         ctx.save_for_backward(x, weight)
         ctx.set_materialize_grads(False)
         return y, x.view_as(x)
@@ -616,6 +625,20 @@ class Conv1x1Fn(Function):
         if dskip is not None and (not dskip.is_contiguous() or dskip.dtype != x.dtype):
             dskip = dskip.to(x.dtype).contiguous()
         dx = dw = None
+        if x.dtype == torch.float32:                                          # reference precision: fp32 GEMM kernels, W as stored
+            if dy.dtype != torch.float32:
+                dy = dy.float()
+            if ctx.needs_input_grad[0]:
+                w2 = weight.reshape(co, C).contiguous()
+                dx = torch.empty_like(x)
+                L.check(lib.acr_conv1x1_f32(L.ptr(w2), 1, L.ptr(dy), L.ptr(dskip), L.ptr(dx), N, C, co, H * W, L.stream_ptr()),
+                        "acr_conv1x1_f32")
+            if ctx.needs_input_grad[1]:
+                ws = torch.empty(lib.acr_conv1x1_wgrad_f32_ws_floats(N, co, C, H * W), dtype=torch.float32, device=x.device)
+                dw = torch.empty((co, C, 1, 1), dtype=torch.float32, device=x.device)
+                L.check(lib.acr_conv1x1_wgrad_f32(L.ptr(dy), L.ptr(x), N, co, C, H * W, L.ptr(ws), L.ptr(dw), L.stream_ptr()),
+                        "acr_conv1x1_wgrad_f32")
+            return dx, dw
         if ctx.needs_input_grad[0]:
             wt = weight.reshape(co, C).t().contiguous()                       # (cin, cout): dX = W^T . dY
             dx = torch.empty_like(x)

@@ -170,6 +170,16 @@ size_t acr_conv1x1_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int
 int acr_conv1x1_wgrad_bf16(const void* dy, const void* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw,
                            float* ws, void* dw, void* stream);
 
+/* The same 1x1 convolutions at the reference precision (fp32 NCHW) on the fp32 GEMM kernels, one slice per sample.
+ * acr_conv1x1_f32: y[n] = W . x[n] (+ addend[n]); w_transposed = 0: w is (cout, cin); w_transposed = 1: w is stored (cin, cout),
+ * i.e. the forward weight handed over as is for the input gradient (no transposed copy).  cout / cin / hw multiples of 4.
+ * acr_conv1x1_wgrad_f32: dw (cout, cin) = sum_n dy[n] . x[n]^T through one fp32 slab per sample (ws: nsamp*cout*cin floats). */
+int acr_conv1x1_f32(const float* w, int32_t w_transposed, const float* x, const float* addend, float* y, int32_t nsamp,
+                    int32_t cout, int32_t cin, int32_t hw, void* stream);
+size_t acr_conv1x1_wgrad_f32_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t hw);
+int acr_conv1x1_wgrad_f32(const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw, float* ws,
+                          float* dw, void* stream);
+
 /* ---- 3x3 stride-2 max-pool of the stem with TF-SAME -inf padding folded in (models/resnetv2.py:322-328) ----
  * x (nc, h, w) -> y (nc, ho, wo); amax = 1-byte window argmax (i*3+j, first maximum like ATen) kept for the backward,
  * which gathers (no atomics).  Window (ho, wo) starts at (2 ho - pad_top, 2 wo - pad_left). */

@@ -592,3 +592,28 @@ def test_groupnorm_f32(N, C, H, W, act):
     y2 = ops.groupnorm_act(x2, w.detach(), b.detach(), act, r.detach() if r is not None else None)
     (y2 * dy).sum().backward()
     assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad)
+
+
+@pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 64, 8, 8), (3, 64, 256, 16, 24), (2, 256, 64, 28, 28), (2, 1024, 256, 28, 28),
+                                             (2, 128, 512, 56, 56), (1, 64, 256, 112, 112), (2, 1024, 768, 28, 28)])
+def test_conv1x1_f32(N, cin, cout, H, W):
+    """fp32 NCHW 1x1 convolution on the fp32 GEMM kernels (one z-slice per sample): forward, input gradient with the shortcut's
+    gradient added in the epilogue, weight gradient through per-sample slabs -- vs fp64 conv2d.  28x28 = 784 pixels is not a
+    multiple of the 32-deep chunk (register-staged kernel for the weight gradient), cout = 64 fills half a tile."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * cin ** -0.5).to(dev).requires_grad_(True)
+    assert ops.conv1x1_fusable(x, w, 1)
+    y, skip = ops.conv1x1_skip(x, w)
+    dy = torch.randn(N, cout, H, W, generator=g).to(dev)
+    ds = torch.randn(N, cin, H, W, generator=g).to(dev)
+    ((y * dy).sum() + (skip * ds).sum()).backward()
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    ref = F.conv2d(xd, wd)
+    ((ref * dy.double()).sum() + (xd * ds.double()).sum()).backward()
+    for n, a, b in (("y", y, ref), ("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad)):
+        err = (a.double() - b).abs().max() / b.abs().max()
+        assert err <= 1e-5, (n, float(err))
