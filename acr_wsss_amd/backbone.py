@@ -55,7 +55,7 @@ class StdConv2dSame(nn.Conv2d):
             x = pad_same(x, self.kernel_size[0], self.stride[0])
         w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
         if self.hip_1x1 and ops.conv1x1_fusable(x, w_hat, self.stride[0]):
-            return ops.conv1x1(x, w_hat)                    # NCHW 1x1 conv = per-sample MFMA GEMM, no layout transposes
+            return ops.conv1x1(x, w_hat, self._w_hat_t)     # NCHW 1x1 conv = per-sample MFMA GEMM, no layout transposes
         return F.conv2d(x, w_hat, None, self.stride, self.padding)
 
     def forward_skip(self, x):
@@ -63,12 +63,13 @@ class StdConv2dSame(nn.Conv2d):
         gradient is then added inside the input-gradient GEMM."""
         w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
         if self.hip_1x1 and x.requires_grad and ops.conv1x1_fusable(x, w_hat, self.stride[0]):
-            return ops.conv1x1_skip(x, w_hat)
+            return ops.conv1x1_skip(x, w_hat, self._w_hat_t)
         return self.forward(x), x
 
     hip_1x1 = True
 
     _w_hat = None           # set for one forward by ResNetV2 when all weights are standardised in one fused launch
+    _w_hat_t = None         # bf16 1x1 convolutions: its (cin, cout) copy, written by the same launch
 
 
 class GroupNormAct(nn.GroupNorm):
@@ -169,8 +170,9 @@ class ResNetV2(nn.Module):
             # kernels per convolution and direction
             convs = [m for m in self.modules() if isinstance(m, StdConv2dSame)]
             if all(c.weight.dtype == x.dtype for c in convs):
-                for c, w_hat in zip(convs, ops.weight_std_all([c.weight for c in convs], convs[0].eps)):
-                    c._w_hat = w_hat
+                w_hats = ops.weight_std_all([c.weight for c in convs], convs[0].eps)
+                for c, w_hat, wt in zip(convs, w_hats, ops.WeightStdAllFn.last_transposed):
+                    c._w_hat, c._w_hat_t = w_hat, wt
             else:
                 convs = None
         try:
@@ -182,7 +184,7 @@ class ResNetV2(nn.Module):
         finally:
             if convs is not None:
                 for c in convs:
-                    c._w_hat = None
+                    c._w_hat = c._w_hat_t = None
         return x
 
 

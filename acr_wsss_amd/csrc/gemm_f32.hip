@@ -285,25 +285,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
 // ---------------------------------------------------------------------------------------------------------------
 #define F_DTILE (F_BM * F_BK)        // floats per operand per stage, unpadded (16 KiB)
 
+// Per-lane element offsets of this wave's 4 DMA pieces inside one operand, relative to (row 0 of the tile, contraction index
+// 0 of the chunk): computed ONCE per workgroup.  Per chunk the source is then  uniform base (+ k advance, scalar) + this
+// offset -- no vector arithmetic inside the loop (VALU instructions run on the lanes the fp32 MFMA uses; the per-chunk
+// address math was ~40 of the loop's 58 VALU instructions).  Offsets are 32-bit: the host checks dim * ld < 2^31.
 template <bool KC>
-__device__ __forceinline__ void dma_chunk(float* s, const float* __restrict__ p, int64_t ld, int i0, int dim, int k0, int wave,
-                                          int lane) {
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    typedef const __attribute__((address_space(1))) void* glb_vp;
+__device__ __forceinline__ void dma_offsets(int (&off)[4], int64_t ld, int i0, int dim, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int piece = wave * 4 + i;
         if (KC) {
             const int row = piece * 8 + (lane >> 3);
             const int lc = (lane & 7) ^ ((row >> 1) & 7);
-            const float* src = p + (int64_t)min(i0 + row, dim - 1) * ld + k0 + lc * 4;
-            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(s + piece * 256), 16, 0, 0);
+            off[i] = min(i0 + row, dim - 1) * (int)ld + lc * 4;
         } else {
             const int kr = piece * 2 + (lane >> 5);
-            const float* src = p + (int64_t)(k0 + kr) * ld + min(i0 + 4 * (lane & 31), dim - 4);
-            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(s + piece * 256), 16, 0, 0);
+            off[i] = kr * (int)ld + min(i0 + 4 * (lane & 31), dim - 4);
         }
     }
+}
+// ub: uniform pointer to (row 0, contraction index k0) of the operand: p + k0 (KC) or p + k0 * ld (KS)
+__device__ __forceinline__ void dma_chunk(float* s, const float* __restrict__ ub, const int (&off)[4], int wave) {
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((glb_vp)(ub + off[i]), (lds_vp)(s + (wave * 4 + i) * 256), 16, 0, 0);
 }
 
 template <bool KC>
@@ -345,15 +352,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
     float csum = 0.f;          // TN bias gradient: column tid & 127 of the A chunks, k rows of parity tid >> 7
     const bool want_cs = ACT == 3 && !A_KC && g.cs && tn == 0;
 
-    dma_chunk<A_KC>(smem, pa, g.lda, m0, g.M, kbeg, wave, lane);
-    dma_chunk<B_KC>(smem + F_DTILE, pb, g.ldb, n0, g.N, kbeg, wave, lane);
+    int offa[4], offb[4];
+    dma_offsets<A_KC>(offa, g.lda, m0, g.M, wave, lane);
+    dma_offsets<B_KC>(offb, g.ldb, n0, g.N, wave, lane);
+    const int64_t ka = A_KC ? 1 : g.lda, kb = B_KC ? 1 : g.ldb;      // operand advance per contraction index
+    dma_chunk(smem, pa + kbeg * ka, offa, wave);
+    dma_chunk(smem + F_DTILE, pb + kbeg * kb, offb, wave);
     acr_dma_barrier();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += F_BK, cur ^= 1) {
         if (k0 + F_BK < kend) {
             float* d = smem + (cur ^ 1) * 2 * F_DTILE;
-            dma_chunk<A_KC>(d, pa, g.lda, m0, g.M, k0 + F_BK, wave, lane);
-            dma_chunk<B_KC>(d + F_DTILE, pb, g.ldb, n0, g.N, k0 + F_BK, wave, lane);
+            dma_chunk(d, pa + (k0 + F_BK) * ka, offa, wave);
+            dma_chunk(d + F_DTILE, pb + (k0 + F_BK) * kb, offb, wave);
         }
         const float* sa = smem + cur * 2 * F_DTILE;
         const float* sb = sa + F_DTILE;
@@ -438,6 +449,12 @@ __global__ __launch_bounds__(256) void gemm_f32_reduce1_kernel(const float* __re
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// the LDS-DMA kernels address operands with 32-bit element offsets inside one operand
+static bool off32_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int mode) {
+    const int64_t lim = (1ll << 31) - (1 << 20);
+    const int64_t ea = (mode == ACR_GEMM_TN ? K : M) * lda, eb = (mode == ACR_GEMM_NT ? N : K) * ldb;
+    return ea < lim && eb < lim;
+}
 struct TnPlan { int nsplit, kps; };
 // Weight gradient: the token contraction is split over workgroups.  The chip holds 512 workgroups at a time (two per CU),
 // so tiles x splits should fill whole rounds of 512: 576 workgroups take as long as 1024 (measured: fc1's dW with 4
@@ -492,7 +509,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         g.nsplit = p.nsplit; g.kps = p.kps; g.k_zs = p.kps;
         g.c = ws; g.ldc = N;
         g.cs = colsum ? ws + (size_t)p.nsplit * M * N : nullptr;
-        if ((K % F_BK) == 0)
+        if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0)
             hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
         else
             hipLaunchKernelGGL((gemm_f32_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
@@ -511,7 +528,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);   \
         else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);           \
     } while (0)
-    const bool dma = (K % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0;
+    const bool dma = (K % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && off32_ok(M, N, K, lda, ldb, mode);
     if (mode == ACR_GEMM_NT) {
         if (act == 0) ACR_F32_LAUNCH(true, true, 0);
         else if (act == 1) ACR_F32_LAUNCH(true, true, 1);

@@ -3,7 +3,7 @@
 // every forward).  The stock path is ~10 tiny elementwise/reduction kernels per convolution and direction
 // (~500 launches of ~5 us per step for the 52 convolutions); here one workgroup owns one output channel of one
 // convolution, found through a small descriptor table, and does the two-pass statistics in fp32.
-//   forward : p0 = w (cout, n) bf16, p1 = w_hat out
+//   forward : p0 = w (cout, n) bf16, p1 = w_hat out, p3 (nullable, 1x1 convolutions) = w_hat^T (n, cout) out
 //   backward: p0 = w, p1 = g = dL/dw_hat, p2 = dL/dw out:
 //             dw = [g - mean(g) - w_hat * mean(g * w_hat) * (std + eps) / std] / (std + eps)
 #include "acr_common.h"
@@ -43,7 +43,12 @@ __global__ __launch_bounds__(256) void wstd_kernel(const WStdDesc* __restrict__ 
     const float inv = 1.f / (sd + eps);
     if (!BWD) {
         T* out = reinterpret_cast<T*>(d.p1) + (int64_t)c * n;
-        for (int i = tid; i < n; i += 256) out[i] = (T)(((float)w[i] - mean) * inv);
+        T* out_t = reinterpret_cast<T*>(d.p3);               // 1x1 convolutions: also the (cin, cout) copy the input-gradient
+        for (int i = tid; i < n; i += 256) {                 // GEMM reads, written here instead of 33 transposes per step
+            const T v = (T)(((float)w[i] - mean) * inv);
+            out[i] = v;
+            if (out_t) out_t[(int64_t)i * d.cout + c] = v;
+        }
     } else {
         const T* g = reinterpret_cast<const T*>(d.p1) + (int64_t)c * n;
         T* dw = reinterpret_cast<T*>(d.p2) + (int64_t)c * n;

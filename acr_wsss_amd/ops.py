@@ -597,7 +597,8 @@ class Conv1x1Fn(Function):
     the shortcut is added in the epilogue of the input-gradient GEMM (no separate accumulation pass)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, wt=None):
+        ctx.wt = wt                                          # (cin, cout) copy of the weight, or None
         N, C, H, W = x.shape
         co = weight.shape[0]
         w2 = weight.reshape(co, C)
@@ -619,7 +620,7 @@ class Conv1x1Fn(Function):
         co = weight.shape[0]
         lib = L.load()
         if dy is None:
-            return dskip, None
+            return dskip, None, None
         if not dy.is_contiguous():
             dy = dy.contiguous()
         if dskip is not None and (not dskip.is_contiguous() or dskip.dtype != x.dtype):
@@ -638,9 +639,9 @@ class Conv1x1Fn(Function):
                 dw = torch.empty((co, C, 1, 1), dtype=torch.float32, device=x.device)
                 L.check(lib.acr_conv1x1_wgrad_f32(L.ptr(dy), L.ptr(x), N, co, C, H * W, L.ptr(ws), L.ptr(dw), L.stream_ptr()),
                         "acr_conv1x1_wgrad_f32")
-            return dx, dw
+            return dx, dw, None
         if ctx.needs_input_grad[0]:
-            wt = weight.reshape(co, C).t().contiguous()                       # (cin, cout): dX = W^T . dY
+            wt = ctx.wt if ctx.wt is not None else weight.reshape(co, C).t().contiguous()     # (cin, cout): dX = W^T . dY
             dx = torch.empty_like(x)
             L.check(lib.acr_conv1x1_bf16(L.ptr(wt), wt.stride(0), L.ptr(dy), L.ptr(dskip), L.ptr(dx), N, C, co, H * W,
                                          L.stream_ptr()), "acr_conv1x1_bf16")
@@ -649,18 +650,18 @@ class Conv1x1Fn(Function):
             dw = torch.empty((co, C, 1, 1), dtype=weight.dtype, device=x.device)
             L.check(lib.acr_conv1x1_wgrad_bf16(L.ptr(dy), L.ptr(x), N, co, C, H * W, L.ptr(ws), L.ptr(dw), L.stream_ptr()),
                     "acr_conv1x1_wgrad_bf16")
-        return dx, dw
+        return dx, dw, None
 
 
-def conv1x1(x, weight):
-    return Conv1x1Fn.apply(x, weight)[0]
+def conv1x1(x, weight, wt=None):
+    return Conv1x1Fn.apply(x, weight, wt)[0]
 
 
-def conv1x1_skip(x, weight):
-    """(conv(x), x_skip): see Conv1x1Fn."""
+def conv1x1_skip(x, weight, wt=None):
+    """(conv(x), x_skip): see Conv1x1Fn.  ``wt``: the (cin, cout) copy of the weight when the caller already has one."""
     if not SKIP_FUSION:
-        return Conv1x1Fn.apply(x, weight)[0], x
-    return Conv1x1Fn.apply(x, weight)
+        return Conv1x1Fn.apply(x, weight, wt)[0], x
+    return Conv1x1Fn.apply(x, weight, wt)
 
 
 class LayerNormFn(Function):
@@ -788,15 +789,15 @@ def groupnorm_act(x, weight, bias, act="relu", resid=None, eps=1e-5):
     return GroupNormActFn.apply(x, weight.to(x.dtype), bias.to(x.dtype), resid, GN_ACT[act], eps)
 
 
-def _wstd_desc(p0s, p1s, p2s, device):
+def _wstd_desc(p0s, p1s, p2s, device, p3s=None):
     import numpy as np
     rec = np.zeros(len(p0s), dtype=[("p0", "<u8"), ("p1", "<u8"), ("p2", "<u8"), ("p3", "<u8"), ("cout", "<i4"),
                                     ("n", "<i4"), ("ch_start", "<i4"), ("pad", "<i4")])
     ch = 0
     for i, w in enumerate(p0s):
         cout = w.shape[0]
-        rec[i] = (w.data_ptr(), p1s[i].data_ptr(), p2s[i].data_ptr() if p2s is not None else 0, 0, cout,
-                  w.numel() // cout, ch, 0)
+        rec[i] = (w.data_ptr(), p1s[i].data_ptr(), p2s[i].data_ptr() if p2s is not None else 0,
+                  p3s[i].data_ptr() if (p3s is not None and p3s[i] is not None) else 0, cout, w.numel() // cout, ch, 0)
         ch += cout
     return torch.from_numpy(rec.view(np.uint8)).to(device), ch
 
@@ -809,12 +810,18 @@ class WeightStdAllFn(Function):
     def forward(ctx, eps, *weights):
         ws = [w.contiguous() for w in weights]
         outs = [torch.empty_like(w) for w in ws]
-        desc, total = _wstd_desc(ws, outs, None, ws[0].device)
+        # bf16 1x1 convolutions: the standardised weight is also written transposed, (cin, cout), for Conv1x1Fn's input
+        # gradient (the fp32 kernels read W as stored and need no copy)
+        outs_t = [torch.empty((w.shape[1], w.shape[0]), dtype=w.dtype, device=w.device)
+                  if (w.dtype == torch.bfloat16 and w.shape[2] == 1 and w.shape[3] == 1) else None for w in ws]
+        desc, total = _wstd_desc(ws, outs, None, ws[0].device, outs_t)
+        ctx.transposed = outs_t
         fn = L.load().acr_weight_std_f32 if ws[0].dtype == torch.float32 else L.load().acr_weight_std_bf16
         L.check(fn(L.ptr(desc), len(ws), total, eps, 0, L.stream_ptr()), "acr_weight_std")
         ctx.save_for_backward(*ws)
         ctx.eps = eps
         ctx._keep = desc
+        WeightStdAllFn.last_transposed = outs_t              # picked up by the caller right after apply()
         return tuple(outs)
 
     @staticmethod

@@ -254,7 +254,8 @@ int acr_groupnorm_bwd_f32(const float* dy, const float* x, const float* resid, c
 
 /* Weight standardisation of all StdConv2dSame weights of the stem in one launch (models/layers/std_conv.py:56-59).
  * desc_dev: device array of n_conv records {uint64 p0,p1,p2,p3; int32 cout, n, ch_start, pad} sorted by ch_start
- * (first global output-channel index of the conv), n = fan-in.  forward (backward = 0): p0 = w, p1 = w_hat out;
+ * (first global output-channel index of the conv), n = fan-in.  forward (backward = 0): p0 = w, p1 = w_hat out, p3
+ * (nullable) = w_hat^T (n, cout) out -- the copy a 1x1 convolution's input-gradient GEMM reads;
  * backward: p0 = w, p1 = dL/dw_hat, p2 = dL/dw out.  bf16 tensors, fp32 statistics. */
 int acr_weight_std_bf16(const void* desc_dev, int32_t n_conv, int32_t total_channels, float eps, int32_t backward,
                         void* stream);

@@ -310,6 +310,10 @@ def test_weight_std_all_fused():
     shapes = [(64, 3, 7, 7), (64, 64, 1, 1), (256, 64, 3, 3), (33, 5, 1, 1)]
     ws = [(torch.randn(s, generator=g) * 0.3 + 0.05).to(dev).bfloat16().requires_grad_(True) for s in shapes]
     outs = ops.weight_std_all(ws)
+    # 1x1 convolutions also get their standardised weight transposed, (cin, cout), from the same launch
+    tr = ops.WeightStdAllFn.last_transposed
+    assert [t is not None for t in tr] == [False, True, False, True]
+    assert torch.equal(tr[1], outs[1].reshape(64, 64).t()) and torch.equal(tr[3], outs[3].reshape(33, 5).t())
     gs = [torch.randn(s, generator=g).to(dev).bfloat16() for s in shapes]
     sum((o.float() * gi.float()).sum() for o, gi in zip(outs, gs)).backward()
     for w, o, gi in zip(ws, outs, gs):
