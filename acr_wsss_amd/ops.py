@@ -802,6 +802,9 @@ def _wstd_desc(p0s, p1s, p2s, device, p3s=None):
     return torch.from_numpy(rec.view(np.uint8)).to(device), ch
 
 
+WSTD_TRANSPOSED = os.environ.get("ACR_WSTD_TRANSPOSED", "1") != "0"      # A/B: transposed 1x1 weights from the weight-std launch
+
+
 class WeightStdAllFn(Function):
     """w_hat_i = (w_i - mean) / (std + eps) for ALL conv weights of the stem at once (one launch forward, one
     backward) on acr_weight_std_bf16.  Inputs and outputs are tuples of (cout, cin, k, k) bf16 tensors."""
@@ -813,7 +816,7 @@ class WeightStdAllFn(Function):
         # bf16 1x1 convolutions: the standardised weight is also written transposed, (cin, cout), for Conv1x1Fn's input
         # gradient (the fp32 kernels read W as stored and need no copy)
         outs_t = [torch.empty((w.shape[1], w.shape[0]), dtype=w.dtype, device=w.device)
-                  if (w.dtype == torch.bfloat16 and w.shape[2] == 1 and w.shape[3] == 1) else None for w in ws]
+                  if (WSTD_TRANSPOSED and w.dtype == torch.bfloat16 and w.shape[2] == 1 and w.shape[3] == 1) else None for w in ws]
         desc, total = _wstd_desc(ws, outs, None, ws[0].device, outs_t)
         ctx.transposed = outs_t
         fn = L.load().acr_weight_std_f32 if ws[0].dtype == torch.float32 else L.load().acr_weight_std_bf16

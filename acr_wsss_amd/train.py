@@ -55,6 +55,10 @@ class PolyOptimizer(torch.optim.SGD):
         self.global_step += 1
 
 
+import os
+TABLE_CHECK = os.environ.get("ACR_SGD_TABLE_CHECK", "1") != "0"      # A/B (timing only): per-step refresh of the pointer table
+
+
 class MasterWeights:
     """bf16 model, fp32 master weights: the MI355X training precision of this build.
 
@@ -173,12 +177,17 @@ class MasterWeights:
         hn[:, 3] = [p.data_ptr() for p in self.model_params]
         # masters / momentum buffers may have been replaced since the table was built (optimizer.load_state_dict on
         # resume does exactly that): every column is refreshed from the live tensors, so a stale pointer cannot survive
-        for i, m in enumerate(self.masters):
-            st = opt.state[m]
-            if st.get("momentum_buffer") is None:
-                st["momentum_buffer"] = torch.zeros_like(m)
-        hn[:, 1] = [m.data_ptr() for m in self.masters]
-        hn[:, 2] = [opt.state[m]["momentum_buffer"].data_ptr() for m in self.masters]
+        if TABLE_CHECK:
+            # one pass over the state dict's items (no tensor hashing): ~0.1 ms for 315 tensors
+            mom_of = {id(p): st.get("momentum_buffer") for p, st in opt.state.items()}
+            moms = []
+            for m in self.masters:
+                buf = mom_of.get(id(m))
+                if buf is None:
+                    buf = opt.state[m]["momentum_buffer"] = torch.zeros_like(m)
+                moms.append(buf)
+            hn[:, 1] = [m.data_ptr() for m in self.masters]
+            hn[:, 2] = [b.data_ptr() for b in moms]
         self._sgd_tab.copy_(host, non_blocking=True)
         self._sgd_evt = torch.cuda.Event()
         self._sgd_evt.record()
