@@ -91,15 +91,15 @@ class DPT(BaseModel):
 
     def forward_cls(self, x):
         layer_4, stack = self._encode(x)
-        nt = self.pretrained.model.num_tokens
         x_cls = self.cls_head(layer_4[:, 0, :])
-        x_patch_cls = self.cls_head(layer_4[:, nt:, :].mean(dim=1))
+        # DPT/ACR.py:100-105 slices [:, 1:] for EVERY backbone -- also for the distilled DeiT, whose distillation token
+        # therefore counts as a "patch" here (only getam skips it, :210-211); kept as is
+        x_patch_cls = self.cls_head(layer_4[:, 1:, :].mean(dim=1))
         return x_cls, x_patch_cls, self._stack_tensor(stack), None
 
     def forward_cam(self, x):
         layer_4, stack = self._encode(x)
-        nt = self.pretrained.model.num_tokens
-        x_patch = layer_4[:, nt:, :]
+        x_patch = layer_4[:, 1:, :]                      # DPT/ACR.py:129: [:, 1:] for every backbone (see forward_cls)
         x_cls = self.cls_head(layer_4[:, 0, :])
         x_patch_cls = self.cls_head(x_patch.mean(dim=1))
         if x_patch.requires_grad and torch.is_grad_enabled():
@@ -143,7 +143,8 @@ class ACR(DPT):
                 continue
             saved = blk.attn.saved_for_getam()
             if saved is None:
-                raise RuntimeError("getam(): block %d has no saved forward/backward (call forward_cam + backward first)" % i)
+                raise RuntimeError("getam(): block %d has no saved forward/backward: call forward_cam + backward first, in eval() mode "
+                                   "(a train()-mode forward keeps no attention state unless Attention.keep_state_in_training is set)" % i)
             qkv, d_o, lse2, heads = saved
             row = torch.zeros(qkv.shape[1], dtype=torch.float32, device=qkv.device)
             ops.getam_row_accum(qkv, d_o, lse2, heads, batch, func, row)

@@ -250,7 +250,8 @@ class Attention(nn.Module):
         self._override = {}
         self.last_pm = None         # (B,T,T) head-mean map of the last forward (slice of the MeanStack)
 
-    hip_linear = True       # bf16 mode: qkv / proj on the hand-written MFMA GEMM (acr_linear_bf16)
+    hip_linear = True       # qkv / proj on the hand-written MFMA GEMMs (acr_linear_bf16 / acr_gemm_f32)
+    keep_state_in_training = False      # True: get_attn() / get_attn_gradients() also work after a train()-mode forward
 
     def forward(self, x, stack=None, layer=0, resid=None):
         """Returns proj(attention(qkv(x))) (+ resid when given: the block's residual add is fused into the

@@ -11,10 +11,20 @@
 //     bank-conflict free.
 // Numerics are unchanged: every product is a k-ordered fp32 fmaf chain on v_mfma_f32_32x32x2_f32, fp32 softmax; nothing is
 // summed with atomics.  Operand conventions (rowop / accop) as in attn_f32.hip.
+#include <type_traits>
+
 #include "acr_common.h"
 #include "attn_f32.h"
 
 #define DT_FLOATS 2048             // one 32-row x 64-float tile
+
+#ifdef LAB_STAMP                   // lab builds only (scripts/lab): per-phase cycle sums of wave 0 of every forward workgroup
+__device__ unsigned long long g_lab_stamp[8 * 16384];
+extern "C" int acr_lab_read_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_stamp), (size_t)n * 8);
+}
+#define LAB_T() __builtin_amdgcn_s_memtime()
+#endif
 
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
@@ -87,6 +97,79 @@ __device__ __forceinline__ void rows_from_global(float (&reg)[32], const float* 
     }
 }
 
+// ---- immediate-offset addressing --------------------------------------------------------------------------------
+// VALU instructions do not overlap the fp32 MFMA, so the loops keep NO vector address arithmetic: every LDS read is
+// (lane base register) + (compile-time immediate).  With the chunk-XOR swizzle the lane-dependent part of a read address
+// takes only a few values, precomputed once per wave (byte offsets inside a tile):
+//   row reads  (rowop, rows_from_lds): row = r, chunk 8h + i        ->  rowb[i] = r*256 + (((8h) ^ (r & 15) ^ i) << 4)
+//   col reads  (accop): row = krow(reg, h) = c_reg + 4h, column 32*blk + r; with L = (r >> 2) ^ 4h and
+//              C = 8*blk ^ (c_reg & 15) (bit 2 of C is always 0):  address = colb[C & 3] + c_reg*256 + (C & 8)*16,
+//              colb[c] = 4h*256 + ((L ^ c) << 4) + (r & 3)*4
+// and the ring slots are unrolled (SLOT is a template parameter), so tile base offsets are immediates too.
+struct LaneBases { int rowb[8]; int colb[4]; };
+__device__ __forceinline__ LaneBases lane_bases(int r, int h) {
+    LaneBases lb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lb.rowb[i] = r * 256 + ((((8 * h) ^ (r & 15)) ^ i) << 4);
+    const int L = (r >> 2) ^ (4 * h);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lb.colb[c] = h * 1024 + ((L ^ c) << 4) + (r & 3) * 4;
+    return lb;
+}
+template <int TILE_OFF>            // TILE_OFF: byte offset of the tile inside the workgroup's LDS block `sm`
+__device__ __forceinline__ void rowop_i(f32x16& acc, const char* sm, const LaneBases& lb, const float (&y)[32]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sm + lb.rowb[i] + TILE_OFF);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], y[4 * i + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], y[4 * i + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], y[4 * i + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], y[4 * i + 3], acc, 0, 0, 0);
+    }
+}
+template <int TILE_OFF, int BLK, int REG>
+__device__ __forceinline__ float col_elem(const char* sm, const LaneBases& lb) {
+    constexpr int c_reg = (REG & 3) + 8 * (REG >> 2);
+    constexpr int C = (8 * BLK) ^ (c_reg & 15);
+    return *reinterpret_cast<const float*>(sm + lb.colb[C & 3] + (TILE_OFF + c_reg * 256 + (C & 8) * 16));
+}
+template <int TILE_OFF, int BLK, int REG = 0>
+__device__ __forceinline__ void accop_b_i(f32x16& acc, const f32x16& z, const char* sm, const LaneBases& lb) {
+    if constexpr (REG < 16) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(col_elem<TILE_OFF, BLK, REG>(sm, lb), z[REG], acc, 0, 0, 0);
+        accop_b_i<TILE_OFF, BLK, REG + 1>(acc, z, sm, lb);
+    }
+}
+template <int TILE_OFF, int BLK, int REG = 0>
+__device__ __forceinline__ void accop_a_i(f32x16& acc, const f32x16& z, const char* sm, const LaneBases& lb) {
+    if constexpr (REG < 16) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z[REG], col_elem<TILE_OFF, BLK, REG>(sm, lb), acc, 0, 0, 0);
+        accop_a_i<TILE_OFF, BLK, REG + 1>(acc, z, sm, lb);
+    }
+}
+template <int TILE_OFF>
+__device__ __forceinline__ void rows_from_lds_i(float (&reg)[32], const char* sm, const LaneBases& lb) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sm + lb.rowb[i] + TILE_OFF);
+        reg[4 * i + 0] = v[0]; reg[4 * i + 1] = v[1]; reg[4 * i + 2] = v[2]; reg[4 * i + 3] = v[3];
+    }
+}
+// DMA of a 32-row tile with the lane part of the source address precomputed (element offsets of the wave's two pieces
+// relative to row 0 of the tile): src = uniform row-0 pointer + off[i].  Only valid for tiles fully inside [0, T).
+__device__ __forceinline__ void dma_offsets32(int (&off)[2], int64_t st, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 4 + (lane >> 4);
+        off[i] = row * (int)st + (((lane & 15) ^ (row & 15)) << 2);
+    }
+}
+__device__ __forceinline__ void dma_tile32_i(float* lds, const float* __restrict__ row0ptr, const int (&off)[2], int wave) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((glb_vp)(row0ptr + off[i]), (lds_vp)(lds + (wave * 2 + i) * 256), 16, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: one workgroup = (b, h, 128 queries); wave w owns queries q0 + 32w ..; K/V tiles of 32 keys stream through LDS
 // ---------------------------------------------------------------------------------------------
@@ -113,18 +196,48 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(AttnGeom g, const 
     rows_from_global(qreg, q + base, g.st, q0, g.T, r, h, g.scale * ACR_LOG2E);
     float m = -INFINITY, l = 0.f;
     f32x16 o0 = {0}, o1 = {0};
-    int cur = 0;
-    for (int k0 = 0; k0 < g.T; k0 += 32, cur ^= 1) {
-        acr_dma_barrier();                                 // slot `cur` has landed; slot cur^1 is free
-        if (k0 + 32 < g.T) {
-            dma_tile32(smem + (cur ^ 1) * 2 * DT_FLOATS, kb, g.st, k0 + 32, g.T, wave, lane);
-            dma_tile32(smem + (cur ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb, g.st, k0 + 32, g.T, wave, lane);
+    const LaneBases lb = lane_bases(r, h);
+    int doff[2];
+    dma_offsets32(doff, g.st, wave, lane);
+    const char* sm = reinterpret_cast<const char*>(smem);
+#ifdef LAB_STAMP
+    unsigned long long st_bar = 0, st_dma = 0, st_s = 0, st_sm = 0, st_pv = 0, st_n = 0;
+#endif
+    // one 32-key step on ring slot SLOT (compile time: every LDS address below is lane base + immediate)
+    auto step = [&](int k0, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr int KOFF = SLOT * 2 * DT_FLOATS * 4, VOFF = KOFF + DT_FLOATS * 4;
+#ifdef LAB_STAMP
+        const unsigned long long tb = LAB_T();
+#endif
+        acr_dma_barrier();                                 // slot SLOT has landed; the other slot is free
+#ifdef LAB_STAMP
+        const unsigned long long t0 = LAB_T();
+#endif
+        // The co-resident wave of the other workgroup streams 64-cycle fp32 MFMAs through this SIMD; at equal priority this
+        // wave's DMA issue and softmax VALU get one issue slot per MFMA gap (measured with s_memtime stamps: 4 DMA
+        // instructions 1 280 cycles, ~100 VALU instructions 2 750 cycles).  VALU cannot overlap the fp32 MFMA anyway, so the
+        // short non-matrix phases run at raised priority and the partner's chain resumes right after.
+        __builtin_amdgcn_s_setprio(2);
+        if (k0 + 64 <= g.T) {                              // next tile fully inside: precomputed lane offsets, uniform base
+            dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb + (int64_t)(k0 + 32) * g.st, doff, wave);
+            dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb + (int64_t)(k0 + 32) * g.st, doff, wave);
+        } else if (k0 + 32 < g.T) {                        // partial last tile: clamped rows
+            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb, g.st, k0 + 32, g.T, wave, lane);
+            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb, g.st, k0 + 32, g.T, wave, lane);
         }
-        if (!live) continue;
-        const float* kt = smem + cur * 2 * DT_FLOATS;
-        const float* vt = kt + DT_FLOATS;
+        __builtin_amdgcn_s_setprio(0);
+        if (!live) return;
         f32x16 s = {0};
-        rowop(s, kt, qreg, r, h);                          // s[reg] = S2[key = k0 + krow][query = q0 + r]
+#ifdef LAB_STAMP
+        const unsigned long long t1 = LAB_T();
+#endif
+        rowop_i<KOFF>(s, sm, lb, qreg);                    // s[reg] = S2[key = k0 + krow][query = q0 + r]
+#ifdef LAB_STAMP
+        asm volatile("" :: "v"(s[15]));
+        const unsigned long long t2 = LAB_T();
+#endif
+        __builtin_amdgcn_s_setprio(2);
         if (k0 + 32 > g.T) {                               // only the last key tile has keys beyond T (uniform branch)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
@@ -136,8 +249,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(AttnGeom g, const 
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         // Deferred rescale: the running reference m moves only when some row's maximum has grown by more than 2^8 since
         // it was set (p then stays below 2^8: no overflow, full fp32 precision); most steps skip the 32 multiplies of O and
-        // the exp2 of alpha.  exp2 = one v_exp_f32 (VALU instructions run on the same lanes as the fp32 MFMA: they do not
-        // overlap it, every instruction saved is matrix time won).
+        // the exp2 of alpha.  exp2 = one v_exp_f32.
         if (__any(mx > m + 8.f)) {
             const float mn = fmaxf(m, mx);
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
@@ -151,9 +263,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(AttnGeom g, const 
         for (int reg = 0; reg < 16; ++reg) { p[reg] = __builtin_amdgcn_exp2f(s[reg] - m); rs += p[reg]; }
         rs += __shfl_xor(rs, 32);
         l += rs;
-        accop_b(o0, p, vt, 0, r, h);                       // o[reg] = O^T[d = 32*blk + krow][query = r]
-        accop_b(o1, p, vt, 1, r, h);
+        __builtin_amdgcn_s_setprio(0);
+#ifdef LAB_STAMP
+        asm volatile("" :: "v"(p[15]), "v"(l));
+        const unsigned long long t3 = LAB_T();
+#endif
+        accop_b_i<VOFF, 0>(o0, p, sm, lb);                 // o[reg] = O^T[d = 32*blk + krow][query = r]
+        accop_b_i<VOFF, 1>(o1, p, sm, lb);
+#ifdef LAB_STAMP
+        asm volatile("" :: "v"(o0[15]), "v"(o1[15]));
+        const unsigned long long t4 = LAB_T();
+        st_bar += t0 - tb; st_dma += t1 - t0; st_s += t2 - t1; st_sm += t3 - t2; st_pv += t4 - t3; st_n += 1;
+#endif
+    };
+#ifdef LAB_STAMP
+    const unsigned long long tk0 = LAB_T();
+#endif
+    for (int k0 = 0; k0 < g.T; k0 += 64) {
+        step(k0, std::integral_constant<int, 0>{});
+        if (k0 + 32 < g.T) step(k0 + 32, std::integral_constant<int, 1>{});
     }
+#ifdef LAB_STAMP
+    if (tid == 0 && blockIdx.x < 16384) {
+        unsigned long long* d = g_lab_stamp + 8 * blockIdx.x;
+        d[0] = st_bar; d[1] = st_dma; d[2] = st_s; d[3] = st_sm; d[4] = st_pv; d[5] = st_n; d[6] = LAB_T() - tk0; d[7] = live;
+    }
+#endif
     if (live && q0 + r < g.T) {
         const float inv = 1.f / l;
         float* ob = o + (int64_t)b * g.osb + (int64_t)(q0 + r) * g.ost + (int64_t)hd * g.osh;

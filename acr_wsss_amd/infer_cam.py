@@ -45,6 +45,10 @@ def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", 
     frozen = [p for p in model.parameters() if p.requires_grad] if truncate else []
     for p in frozen:
         p.requires_grad_(False)
+    # getam reads the attention state of the forward/backward pair; a train()-mode module drops it by default
+    attns = [blk.attn for blk in vit.blocks]
+    for a in attns:
+        a.keep_state_in_training = True
     try:
         for scale in scales:
             base = F.interpolate(imgs, size=(int(h * scale), int(w * scale)), mode="bilinear", align_corners=False)
@@ -87,6 +91,8 @@ def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", 
         model.truncate_at = old_trunc
         for p in frozen:
             p.requires_grad_(True)
+        for a in attns:
+            del a.keep_state_in_training                  # back to the class default
     out = []
     for i in range(B):
         ca, pa = cam_acc[i], patch_acc[i]

@@ -73,9 +73,13 @@ class AttnCoreFn(Function):
                                  L.stream_ptr()), "acr_attn_fwd")
         ctx.save_for_backward(qkv, o, lse2)
         ctx.heads = heads
-        ctx.owner = owner
+        # the state API (get_attn / get_attn_gradients / getam) needs q, k, lse2 and later dO; in training mode nobody reads
+        # it and keeping it would pin qkv + dO of all 12 layers between steps (2.8 GB at B = 32 views in fp32), so it is
+        # only recorded in eval mode (CAM inference) or when the module asks for it (keep_state_in_training)
+        keep = owner is not None and (not owner.training or getattr(owner, "keep_state_in_training", False))
+        ctx.owner = owner if keep else None
         if owner is not None:
-            owner._saved = (qkv, lse2, heads)
+            owner._saved = (qkv, lse2, heads) if keep else None
             owner._saved_do = None
         if pm is None:
             return o, None
