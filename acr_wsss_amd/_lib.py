@@ -98,6 +98,16 @@ SIGNATURES = {
                                         c_void_p, c_int32, c_int32, c_void_p]),
     "acr_preprocess_batch": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
                                        c_int32, c_void_p, c_void_p]),
+    "acr_lattice_ws_bytes": (c_int64, [c_int32, c_int32]),
+    "acr_lattice_build": (c_int32, [c_void_p, c_int32, c_int32, c_float, c_float, c_void_p, c_int64, c_void_p]),
+    "acr_lattice_info": (c_int32, [c_void_p, ctypes.POINTER(c_int32), ctypes.POINTER(c_int32), c_void_p]),
+    "acr_lattice_tables": (c_int32, [c_void_p, c_int32, c_int32, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                     ctypes.POINTER(c_void_p)]),
+    "acr_lattice_filter": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32,
+                                     c_int32, c_void_p, c_void_p]),
+    "acr_crf_unary": (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "acr_crf_norm": (c_int32, [c_void_p, c_int32, c_void_p]),
+    "acr_crf_update": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "acr_getam_row_accum": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       c_void_p, c_void_p]),
     "acr_aff_refine": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),

@@ -123,11 +123,14 @@ def seeds_from_cam_dict(cam_dict, threshold, num_cls=21):
     return np.argmax(tensor, axis=0).astype(np.uint8)
 
 
-def infer_cam_list(model, items, out_cam=None, rank=0, world=1, batch_size=1, **kw):
-    """Shard ``items`` -- an indexable of (name, img (1,3,h,w), label (1,C), (W,H)) -- over ranks and write
-    ``<out_cam>/<name>.npy`` in the reference's wire format: a pickled {class: float32 (W,H)} dict
+def infer_cam_list(model, items, out_cam=None, rank=0, world=1, batch_size=1, out_crf=None, low_alpha=1, high_alpha=12, **kw):
+    """Shard ``items`` -- an indexable of (name, img (1,3,h,w), label (1,C), (W,H)[, orig uint8 (W,H,3)]) -- over ranks and
+    write ``<out_cam>/<name>.npy`` in the reference's wire format: a pickled {class: float32 (W,H)} dict
     (infer_cam.py:227-228, read back by evaluation.py:23-25).  Returns {name: cam_dict} of this rank.
-    ``batch_size`` > 1 groups consecutive images of this rank whose network inputs have the same size."""
+    ``batch_size`` > 1 groups consecutive images of this rank whose network inputs have the same size.
+    ``out_crf`` (infer_cam.py:68,218-225, defaults of --low_alpha / --high_alpha :72-73): also run the dense CRF on every
+    cam_dict at both alphas, on the GPU (crf.crf_with_alpha), and write ``<out_crf>_<alpha>/<name>.npy``; needs the
+    original image as the fifth item element."""
     dev = next(model.parameters()).device
     model.eval()
     results = {}
@@ -147,5 +150,13 @@ def infer_cam_list(model, items, out_cam=None, rank=0, world=1, batch_size=1, **
             if out_cam is not None:
                 os.makedirs(out_cam, exist_ok=True)
                 np.save(os.path.join(out_cam, name + ".npy"), cam_dict)
+            if out_crf is not None and cam_dict:
+                if len(items[i]) < 5:
+                    raise ValueError("out_crf needs the original uint8 image as items[i][4] (infer_cam.py:217)")
+                from .crf import crf_with_alpha
+                for alpha in (low_alpha, high_alpha):
+                    folder = out_crf + ("_%s" % alpha)
+                    os.makedirs(folder, exist_ok=True)
+                    np.save(os.path.join(folder, name + ".npy"), crf_with_alpha(cam_dict, alpha, np.asarray(items[i][4]), device=dev))
             results[name] = cam_dict
     return results

@@ -311,6 +311,31 @@ typedef struct acr_pre_image {
 int acr_preprocess_batch(const void* packed_u8, const void* table, int32_t batch, int32_t S, const float* mean3,
                          const float* std3, int32_t out_dtype, void* out, void* stream);
 
+/* ---- dense-CRF refinement of CAMs (tool/imutils.py:345-362 crf_inference = pydensecrf DenseCRF2D with
+ * addPairwiseGaussian + addPairwiseBilateral + inference(t), called by infer_cam.py:27-40,218-225) ----
+ * The permutohedral lattice follows wrapper/bilateralfilter/permutohedral.cpp:112-283 (init) and :441-520 (compute).
+ * acr_lattice_build: lattice over the H x W pixels with features (x / sxy, y / sxy) when rgb is NULL (d = 2,
+ * addPairwiseGaussian) or (x / sxy, y / sxy, r / srgb, g / srgb, b / srgb) for rgb = (H, W, 3) uint8 (d = 5,
+ * addPairwiseBilateral; bilateralfilter.cpp:4-20).  ws = acr_lattice_ws_bytes(H * W, d) bytes of device memory (opaque).
+ * acr_lattice_info synchronises the stream and returns the number of lattice points (ACR_ERR_INVALID if a key did not
+ * fit the 12-bit-per-coordinate packing).  acr_lattice_tables returns device pointers INTO ws: offsets (n, d+1) int32,
+ * weights (n, d+1) float, point_keys (n_points) uint64 (coordinate c of a key = ((k >> 12 (d-1-c)) & 4095) - 2048).
+ * acr_lattice_filter: out[k][p] = post_scale * post[p] * sum_q kernel(p, q) * pre[q] * in[k][q] for K planes of n pixels
+ * (Permutohedral::compute; pre / post nullable, post_scale applied when apply_scale != 0); vals = scratch of
+ * 2 * K * (n_points + 2) floats.  Sums run in the CPU code's order: results equal the reference lattice bit for bit. */
+int64_t acr_lattice_ws_bytes(int32_t n_pixels, int32_t d);
+int acr_lattice_build(const void* rgb, int32_t H, int32_t W, float sxy, float srgb, void* ws, int64_t ws_bytes, void* stream);
+int acr_lattice_info(const void* ws, int32_t* n_points, int32_t* key_overflow, void* stream);
+int acr_lattice_tables(void* ws, int32_t n_pixels, int32_t d, void** offsets, void** weights, void** point_keys);
+int acr_lattice_filter(const void* ws, int32_t n_pixels, int32_t d, int32_t n_points, const void* in, const void* pre, void* out,
+                       const void* post, float post_scale, int32_t apply_scale, int32_t K, void* vals, void* stream);
+/* mean field (densecrf v2: unary_from_softmax, DenseKernel NORMALIZE_SYMMETRIC, DenseCRF::inference + expAndNormalize):
+ * unary = -log(clamp(probs, clip, 1)); norm = 1 / sqrt(norm + 1e-20) in place; q[:, p] = softmax_k(-unary + msg0 + msg1)
+ * over K planes of n pixels (msg0 / msg1 nullable). */
+int acr_crf_unary(const void* probs, void* unary, int64_t n, float clip, void* stream);
+int acr_crf_norm(void* norm, int32_t n_pixels, void* stream);
+int acr_crf_update(const void* unary, const void* msg0, const void* msg1, void* q, int32_t n_pixels, int32_t K, void* stream);
+
 /* ---- CAM read-outs ----
  * Patch-token -> class activation (DPT/ACR.py:133-134): out[n][c] = relu(x[n,:] . w[c,:] + bias[c]),
  * x (N, D) with row stride x_st, w (C, D) contiguous, out (N, C) contiguous; dtype of x/w/bias. */
