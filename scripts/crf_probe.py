@@ -22,8 +22,46 @@ def scene(h, w, k, seed):
     return img, probs
 
 
+def cpu_reference_filter(img, k):
+    """the reference's own lattice (oracle/_ref, built from wrapper/bilateralfilter/*.cpp) on one host core: init + K planes"""
+    from oracle import crf_oracle as C
+    lib = C.load_ref()
+    if lib is None:
+        return None
+    h, w = img.shape[:2]
+    planes = np.random.default_rng(1).random((k, h, w)).astype(np.float32)
+    C.ref_bilateralfilter(lib, img, planes[:1], 13.0, 80.0)
+    t0 = time.time()
+    C.ref_bilateralfilter(lib, img, planes, 13.0, 80.0)
+    return time.time() - t0
+
+
+def gpu_filter(img, k, reps):
+    from acr_wsss_amd.crf import PermutohedralLattice
+    h, w = img.shape[:2]
+    x = torch.rand(k, h * w, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    lat = PermutohedralLattice(h, w, 80, rgb=img, srgb=13)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    lat.filter(x)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(reps):
+        lat.filter(x)
+    torch.cuda.synchronize()
+    return t_build, (time.time() - t0) / reps, lat.n_points
+
+
 if __name__ == "__main__":
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    img, _ = scene(375, 500, 21, 0)
+    tb, tf, m = gpu_filter(img, 21, reps)
+    print("bilateral lattice 375x500 (sxy 80, srgb 13): %d points, build %.2f ms, filter of 21 planes %.3f ms" % (m, 1e3 * tb, 1e3 * tf))
+    tc = cpu_reference_filter(img, 21)
+    if tc is not None:
+        print("reference C++ lattice (bilateralfilter.cpp:22-41, 1 core, init + 21 planes): %.1f ms" % (1e3 * tc))
     for k in (3, 21):
         img, probs = scene(375, 500, k, 0)
         crf_inference(img, probs, labels=k)
