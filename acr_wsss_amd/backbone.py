@@ -96,7 +96,7 @@ class MaxPool2dSame(nn.Module):
     hip_pool = True
 
     def forward(self, x):
-        if self.hip_pool and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4:
+        if self.hip_pool and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.dim() == 4 and not torch.is_autocast_enabled():
             ph, pw = _same_pad(x.shape[-2], 3, 2), _same_pad(x.shape[-1], 3, 2)
             return ops.maxpool3x3s2_same(x, ph // 2, pw // 2, ph, pw)       # -inf SAME padding folded into the kernel
         return F.max_pool2d(pad_same(x, 3, 2, value=-float("inf")), 3, 2)

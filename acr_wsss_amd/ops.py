@@ -559,8 +559,8 @@ class MaxPoolSameFn(Function):
         Ho, Wo = (H + ph - 3) // 2 + 1, (W + pw - 3) // 2 + 1
         y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device)
         amax = torch.empty((N, C, Ho, Wo), dtype=torch.uint8, device=x.device)
-        L.check(L.load().acr_maxpool3x3s2_fwd_bf16(L.ptr(x), L.ptr(y), L.ptr(amax), N * C, H, W, Ho, Wo, pt, pl, L.stream_ptr()),
-                "acr_maxpool3x3s2_fwd_bf16")
+        fn = L.load().acr_maxpool3x3s2_fwd_f32 if x.dtype == torch.float32 else L.load().acr_maxpool3x3s2_fwd_bf16
+        L.check(fn(L.ptr(x), L.ptr(y), L.ptr(amax), N * C, H, W, Ho, Wo, pt, pl, L.stream_ptr()), "acr_maxpool3x3s2_fwd")
         ctx.save_for_backward(amax)
         ctx.geom = (N, C, H, W, Ho, Wo, pt, pl)
         return y
@@ -571,8 +571,8 @@ class MaxPoolSameFn(Function):
         N, C, H, W, Ho, Wo, pt, pl = ctx.geom
         dy = dy.contiguous()
         dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device)
-        L.check(L.load().acr_maxpool3x3s2_bwd_bf16(L.ptr(dy), L.ptr(amax), L.ptr(dx), N * C, H, W, Ho, Wo, pt, pl, L.stream_ptr()),
-                "acr_maxpool3x3s2_bwd_bf16")
+        fn = L.load().acr_maxpool3x3s2_bwd_f32 if dy.dtype == torch.float32 else L.load().acr_maxpool3x3s2_bwd_bf16
+        L.check(fn(L.ptr(dy), L.ptr(amax), L.ptr(dx), N * C, H, W, Ho, Wo, pt, pl, L.stream_ptr()), "acr_maxpool3x3s2_bwd")
         return dx, None, None, None, None
 
 

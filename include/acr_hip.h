@@ -187,6 +187,11 @@ int acr_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* amax, int64_t nc,
                               int32_t wo, int32_t pad_top, int32_t pad_left, void* stream);
 int acr_maxpool3x3s2_bwd_bf16(const void* dy, const uint8_t* amax, void* dx, int64_t nc, int32_t h, int32_t w,
                               int32_t ho, int32_t wo, int32_t pad_top, int32_t pad_left, void* stream);
+/* the same for fp32 maps (the reference's precision) */
+int acr_maxpool3x3s2_fwd_f32(const void* x, void* y, uint8_t* amax, int64_t nc, int32_t h, int32_t w, int32_t ho,
+                             int32_t wo, int32_t pad_top, int32_t pad_left, void* stream);
+int acr_maxpool3x3s2_bwd_f32(const void* dy, const uint8_t* amax, void* dx, int64_t nc, int32_t h, int32_t w,
+                             int32_t ho, int32_t wo, int32_t pad_top, int32_t pad_left, void* stream);
 
 /* ---- Fused optimizer step, bf16 weights + fp32 masters (tool/torchutils.py:10-31 PolyOptimizer = SGD with
  * momentum slot = wt_dec, weight decay 0):  mom = momentum*mom + g;  master -= lr*mom;  param = bf16(master).

@@ -374,10 +374,11 @@ def test_conv1x1_bf16(N, cin, cout, H, W):
     assert (w.grad.double() - wd.grad).abs().max() <= 1e-2 * wd.grad.abs().max()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("shape", [(2, 3, 8, 8), (2, 5, 9, 11), (1, 64, 224, 224), (2, 4, 7, 16)])
-def test_maxpool_same_bf16(shape):
-    """SAME-padded 3x3/2 max-pool (forward value, argmax routing of the gradient) vs F.pad(-inf)+max_pool2d; values are made
-    distinct so the argmax is unique and the comparison is exact."""
+def test_maxpool_same_bf16(shape, dtype):
+    """SAME-padded 3x3/2 max-pool (forward value, argmax routing of the gradient) vs F.pad(-inf)+max_pool2d, bf16 and fp32
+    maps; values are made distinct so the argmax is unique and the comparison is exact."""
     from acr_wsss_amd import ops
     from acr_wsss_amd.backbone import _same_pad, pad_same
     import torch.nn.functional as F
@@ -385,16 +386,17 @@ def test_maxpool_same_bf16(shape):
     g = torch.Generator(device="cpu").manual_seed(sum(shape))
     n = math.prod(shape)
     x = (torch.randperm(n, generator=g).float().reshape(shape) % 251 - 125.0) / 4.0      # bf16-exact, few ties
-    x = x.to(dev).bfloat16().requires_grad_(True)
+    x = x.to(dev).to(dtype).requires_grad_(True)
     ph, pw = _same_pad(shape[2], 3, 2), _same_pad(shape[3], 3, 2)
     y = ops.maxpool3x3s2_same(x, ph // 2, pw // 2, ph, pw)
     xr = x.detach().clone().requires_grad_(True)
     yr = F.max_pool2d(pad_same(xr, 3, 2, value=-float("inf")), 3, 2)
     assert y.shape == yr.shape and torch.equal(y, yr)
-    dy = torch.randn(y.shape, generator=g).to(dev).bfloat16()
+    dy = torch.randn(y.shape, generator=g).to(dev).to(dtype)
     y.backward(dy)
     yr.backward(dy)
-    assert torch.allclose(x.grad.float(), xr.grad.float(), atol=2e-2, rtol=2e-2)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-6          # a pixel collects up to 4 window gradients: summation order only
+    assert torch.allclose(x.grad.float(), xr.grad.float(), atol=tol, rtol=tol)
 
 
 @pytest.mark.parametrize("M,D,Hd", [(197 * 2, 192, 768), (785, 768, 3072), (320 * 3 + 17, 128, 256)])
