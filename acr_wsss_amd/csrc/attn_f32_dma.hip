@@ -11,6 +11,19 @@
 //     bank-conflict free.
 // Numerics are unchanged: every product is a k-ordered fp32 fmaf chain on v_mfma_f32_32x32x2_f32, fp32 softmax; nothing is
 // summed with atomics.  Operand conventions (rowop / accop) as in attn_f32.hip.
+//
+// Partial last tile (measured, scripts/lab/attn_tail.py): a workgroup costs about the same whether 4 or 1 of its waves have
+// rows -- a step is bound by its barrier / DMA / softmax latency chain, not by the matrix pipe -- so with T = 785 = 6 x 128 + 17
+// the seventh tile of every (b, h) costs 1/7 of a sweep for 2 % of the rows, and 7 x 384 workgroups are 3.5 / 5.25 rounds of
+// the 768 / 512 resident slots (T = 785 takes 29 % longer per image than T = 768; B = 96 is 14 % cheaper per image than
+// B = 32).  Tried and dropped, all correct but none faster over the four sweeps (3.36 ms per layer as is):
+//   * partial tiles last in the grid with their row-less waves exiting at once: the freed wave slots cannot be refilled (a
+//     workgroup is dispatched only when EVERY SIMD has a free slot) and the lone wave has to issue all 16 DMA pieces of a
+//     step itself: forward -2 %, dK/dV +7 %;
+//   * partial tiles as separate 64-thread workgroups after the full tiles: 3.35 ms (a lone wave is as slow per step);
+//   * the same concurrently on a low-priority helper stream: the narrow workgroups still keep a full one from being
+//     dispatched beside them: backward -3 %, forward +2 %;
+//   * dQ at 3 waves per SIMD (168 VGPRs): spills 82 registers, 2x slower.
 #include <type_traits>
 
 #include "acr_common.h"
