@@ -81,6 +81,7 @@ SIGNATURES = {
     "acr_wgrad_bias_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),
     "acr_transpose_many_bf16": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "acr_transpose_many_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "acr_layernorm_ws_floats": (c_size_t, [c_int32, c_int32]),
     "acr_layernorm_fwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float,
                                          c_void_p]),

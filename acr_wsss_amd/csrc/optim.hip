@@ -102,6 +102,42 @@ __global__ __launch_bounds__(256) void transpose_many_kernel(const acr_tr_tensor
     }
 }
 
+// the same for fp32 weights (rows, cols multiples of 4): 64x64 tile through LDS, 16-byte accesses both ways.  In fp32 the
+// input-gradient GEMM on W as stored (NN: the B tile is read one float at a time) runs at 105-110 TFLOP/s, on the
+// transposed copy (NT: 16-byte fragment reads) at 121-125 (scripts/lab/gemm_nn_vs_nt.py), bit-identical results.
+__global__ __launch_bounds__(256) void transpose_many_f32_kernel(const acr_tr_tensor* __restrict__ tab, const int32_t* __restrict__ blk_tensor) {
+    __shared__ float tile[64][68];
+    const acr_tr_tensor t = tab[blk_tensor[blockIdx.x]];
+    const int lt = blockIdx.x - t.tile0;
+    const int r0 = (lt / t.tiles_c) * 64, c0 = (lt % t.tiles_c) * 64;
+    const float* s = (const float*)t.src;
+    float* d = (float*)t.dst;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                            // 16 threads x 16 B per row, 16 rows per pass
+        const int r = p * 16 + (tid >> 4), c = (tid & 15) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < t.rows && c0 + c < t.cols) v = *reinterpret_cast<const f32x4*>(s + (int64_t)(r0 + r) * t.cols + c0 + c);
+        *reinterpret_cast<f32x4*>(&tile[r][c]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = p * 16 + (tid >> 4), r = (tid & 15) * 4;     // output row = source column c, 4 source rows r..r+3
+        if (c0 + c < t.cols && r0 + r < t.rows) {
+            const f32x4 v = {tile[r][c], tile[r + 1][c], tile[r + 2][c], tile[r + 3][c]};
+            *reinterpret_cast<f32x4*>(d + (int64_t)(c0 + c) * t.rows + r0 + r) = v;
+        }
+    }
+}
+
+extern "C" int acr_transpose_many_f32(const void* table, const int32_t* blk_tensor, int32_t nblocks, void* stream) {
+    ACR_CHECK_ARG(table && blk_tensor && nblocks > 0, "acr_transpose_many_f32: null pointer / empty launch");
+    hipLaunchKernelGGL(transpose_many_f32_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const acr_tr_tensor*)table,
+                       blk_tensor);
+    return acr_check_launch("acr_transpose_many_f32");
+}
+
 extern "C" int acr_transpose_many_bf16(const void* table, const int32_t* blk_tensor, int32_t nblocks, void* stream) {
     ACR_CHECK_ARG(table && blk_tensor && nblocks > 0, "acr_transpose_many_bf16: null pointer / empty launch");
     hipLaunchKernelGGL(transpose_many_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const acr_tr_tensor*)table,

@@ -49,6 +49,50 @@ class MeanStack:
         self.n_layers = Lyr
 
 
+
+class KernelTimer:
+    """bench.py only: HIP-event timing of selected launches INSIDE the timed training steps (the first matching launch of every
+    key in every step), on the stream the kernels are launched on -- so that a kernel's reported duration is the in-step one,
+    not that of an isolated replay.  Off (None) everywhere else; an `is None` test is all the product path pays."""
+
+    def __init__(self):
+        self.samples, self._seen, self._open = {}, set(), []
+
+    def next_step(self):
+        self._seen.clear()
+
+    def begin(self, key):
+        if key in self._seen:
+            return None
+        self._seen.add(key)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return key, e0, e1
+
+    def end(self, tok):
+        tok[2].record()
+        self._open.append(tok)
+
+    def collect(self):
+        """-> {key: [ms, ...]} (synchronises)"""
+        torch.cuda.synchronize()
+        for key, e0, e1 in self._open:
+            self.samples.setdefault(key, []).append(e0.elapsed_time(e1))
+        self._open = []
+        return self.samples
+
+
+KERNEL_TIMER = None
+
+
+def _t0(name, *dims):
+    return KERNEL_TIMER.begin("%s %s" % (name, "x".join(str(int(d)) for d in dims))) if KERNEL_TIMER is not None else None
+
+
+def _t1(tok):
+    if tok is not None:
+        KERNEL_TIMER.end(tok)
+
 class AttnCoreFn(Function):
     """o = softmax(q k^T d^-0.5) v  (+ head-mean side output), packed qkv in, (B,T,D) out."""
 
@@ -68,9 +112,11 @@ class AttnCoreFn(Function):
         if stack is not None:
             pm = stack.buf[:, layer]
         qp, kp, vp = _qkv_ptrs(qkv, heads)
+        tok = _t0("attn_fwd" if pm is not None else "attn_fwd_nomean", B, heads, T)
         L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm),
                                  pm.stride(0) if pm is not None else 0, pm.stride(1) if pm is not None else 0,
                                  L.stream_ptr()), "acr_attn_fwd")
+        _t1(tok)
         ctx.save_for_backward(qkv, o, lse2)
         ctx.heads = heads
         # the state API (get_attn / get_attn_gradients / getam) needs q, k, lse2 and later dO; in training mode nobody reads
@@ -113,8 +159,10 @@ class AttnCoreFn(Function):
         delta = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device)
         qp, kp, vp = _qkv_ptrs(qkv, heads)
         dqp, dkp, dvp = _qkv_ptrs(dqkv, heads)
+        tok = _t0("attn_bwd" if g_pm is not None else "attn_bwd_nomean", B, heads, T)
         L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(g_pm), gm_sb, gm_st,
                                  dqp, dkp, dvp, L.ptr(delta), L.stream_ptr()), "acr_attn_bwd")
+        _t1(tok)
         if ctx.owner is not None:
             ctx.owner._saved_do = d_o
         return dqkv, None, None, None, None
@@ -178,9 +226,11 @@ def linear_bf16(x, weight, bias=None, resid=None, out=None):
     assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.stride(1) == 1 and weight.stride(1) == 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    tok = _t0("linear_bf16", M, N, K)
     L.check(L.load().acr_linear_bf16(L.ptr(x), x.stride(0), L.ptr(weight), weight.stride(0), L.ptr(bias),
                                      L.ptr(resid), resid.stride(0) if resid is not None else 0, L.ptr(out),
                                      out.stride(0), M, N, K, L.stream_ptr()), "acr_linear_bf16")
+    _t1(tok)
     return out
 
 
@@ -208,8 +258,10 @@ def wgrad_bf16(dy2, x2):
         return torch.mm(dy2.t(), x2)
     ws = torch.empty(nws, dtype=torch.float32, device=dy2.device)
     dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy2.device)
+    tok = _t0("wgrad_bf16", M, N, K)
     L.check(lib.acr_wgrad_bf16(L.ptr(dy2), dy2.stride(0), L.ptr(x2), x2.stride(0), M, N, K, L.ptr(ws), L.ptr(dw),
                                L.stream_ptr()), "acr_wgrad_bf16")
+    _t1(tok)
     return dw
 
 
@@ -229,22 +281,28 @@ def wgrad_bias_bf16(dy2, x2):
     ws = torch.empty(nws, dtype=torch.float32, device=dy2.device)
     dw = torch.empty((N, K), dtype=torch.bfloat16, device=dy2.device)
     db = torch.empty(N, dtype=torch.bfloat16, device=dy2.device)
+    tok = _t0("wgrad_bf16", M, N, K)
     L.check(lib.acr_wgrad_bias_bf16(L.ptr(dy2), dy2.stride(0), L.ptr(x2), x2.stride(0), M, N, K, L.ptr(ws), L.ptr(dw), L.ptr(db),
                                     L.stream_ptr()), "acr_wgrad_bias_bf16")
+    _t1(tok)
     return dw, db
 
 
 class WeightTransposes:
-    """(in, out) copies of Linear weights for the input-gradient GEMMs, refreshed in ONE launch (acr_transpose_many_bf16).
+    """(in, out) copies of Linear weights for the input-gradient GEMMs, refreshed in ONE launch (acr_transpose_many_bf16 /
+    _f32; in fp32 the GEMM on the transposed copy is 12-17 % faster than on W as stored, scripts/lab/gemm_nn_vs_nt.py).
 
     ``refresh()`` is called by the training step's owner right after the optimizer step; a copy is used only while the
     weight's autograd version equals the one recorded at refresh (an in-place update by anything else makes the consumer
-    fall back to transposing on the fly), so a stale copy can never be read silently."""
+    fall back to W as stored / a transpose on the fly), so a stale copy can never be read silently."""
 
-    def __init__(self, modules):
+    def __init__(self, modules, dtype=torch.bfloat16):
         import numpy as np
-        self.lins = [m for m in modules if isinstance(m, torch.nn.Linear) and m.weight.is_cuda
-                     and m.weight.dtype == torch.bfloat16 and m.weight.shape[0] % 8 == 0 and m.weight.shape[1] % 8 == 0]
+        mult = 8 if dtype == torch.bfloat16 else 4
+        self.dtype = dtype
+        self.lins = [m for m in modules if isinstance(m, torch.nn.Linear) and m.weight.is_cuda and m.weight.dtype == dtype
+                     and m.weight.is_contiguous() and m.weight.shape[0] % mult == 0 and m.weight.shape[1] % mult == 0
+                     and m.weight.shape[0] >= 64 and m.weight.requires_grad]
         self.ok = bool(self.lins)
         if not self.ok:
             return
@@ -255,7 +313,7 @@ class WeightTransposes:
         self.bufs = []
         for i, m in enumerate(self.lins):
             rows, cols = m.weight.shape
-            wt = torch.empty((cols, rows), dtype=torch.bfloat16, device=dev)
+            wt = torch.empty((cols, rows), dtype=dtype, device=dev)
             self.bufs.append(wt)
             tr, tc = (rows + 63) // 64, (cols + 63) // 64
             rec[i] = (m.weight.data_ptr(), wt.data_ptr(), rows, cols, t0, tc)
@@ -275,18 +333,31 @@ class WeightTransposes:
             for m in self.lins:
                 m._acr_wt = None
             return
-        L.check(L.load().acr_transpose_many_bf16(L.ptr(self.table), L.ptr(self.blk), self.nblocks, L.stream_ptr()),
-                "acr_transpose_many_bf16")
+        fn = L.load().acr_transpose_many_bf16 if self.dtype == torch.bfloat16 else L.load().acr_transpose_many_f32
+        L.check(fn(L.ptr(self.table), L.ptr(self.blk), self.nblocks, L.stream_ptr()), "acr_transpose_many")
         for m, wt in zip(self.lins, self.bufs):
             m._acr_wt, m._acr_wt_ver = wt, m.weight._version
 
 
-def weight_t(weight, owner=None):
-    """weight^T contiguous: the cached copy of ``owner`` (an nn.Linear) when it is current, else a fresh transpose."""
+def weight_t(weight, owner=None, make=True):
+    """weight^T contiguous: the cached copy of ``owner`` (an nn.Linear) when it is current, else a fresh transpose
+    (``make`` = False: None instead, for callers that can work on W as stored)."""
     wt = getattr(owner, "_acr_wt", None) if owner is not None else None
-    if wt is not None and owner._acr_wt_ver == weight._version and wt.shape[0] == weight.shape[1]:
+    if (wt is not None and owner._acr_wt_ver == weight._version and wt.shape[0] == weight.shape[1] and wt.dtype == weight.dtype
+            and owner.weight.data_ptr() == weight.data_ptr()):
         return wt
-    return weight.t().contiguous()
+    return weight.t().contiguous() if make else None
+
+
+F32_WT = os.environ.get("ACR_F32_WT", "1") != "0"      # A/B switch: fp32 input gradients on the cached W^T (NT) vs W as stored (NN)
+
+
+def _dx_f32(dy2, weight, owner, out, aux=None, act=0):
+    """out = dy2 W (optionally * GELU'(aux)): NT on the cached (in, out) copy when it is current, else NN on W as stored."""
+    wt = weight_t(weight, owner, make=False) if F32_WT else None
+    if wt is not None:
+        return gemm_f32_raw("nt", dy2, wt, out, aux=aux, act=act)
+    return gemm_f32_raw("nn", dy2, weight, out, aux=aux, act=act)
 
 
 class LinearBf16Fn(Function):
@@ -355,8 +426,10 @@ class MlpFn(Function):
         lib = L.load()
         h = torch.empty((M, Hd), dtype=torch.bfloat16, device=x.device)
         a = torch.empty((M, Hd), dtype=torch.bfloat16, device=x.device)
+        tok = _t0("linear_bf16", M, Hd, K)
         L.check(lib.acr_linear_gelu_bf16(L.ptr(x2), x2.stride(0), L.ptr(w1), w1.stride(0), L.ptr(b1), L.ptr(h), L.ptr(a), Hd,
                                          M, Hd, K, L.stream_ptr()), "acr_linear_gelu_bf16")
+        _t1(tok)
         r2 = resid.reshape(-1, w2.shape[0]) if resid is not None else None
         y = linear_bf16(a, w2, b2, r2)
         ctx.save_for_backward(x2, h, a, w1, w2)
@@ -414,9 +487,11 @@ def gemm_f32_raw(mode, a, b, c, bias=None, aux=None, act=0, c2=None, colsum=None
     K = a.shape[0] if md == 2 else a.shape[1]
     nws = lib.acr_gemm_f32_ws_floats(md, M, N, K)
     ws = torch.empty(nws, dtype=torch.float32, device=a.device) if nws else None
+    tok = _t0("gemm_f32_" + mode, M, N, K)
     L.check(lib.acr_gemm_f32(md, act, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(bias), L.ptr(aux),
                              aux.stride(0) if aux is not None else 0, L.ptr(c), c.stride(0), L.ptr(c2), L.ptr(colsum), M, N, K,
                              L.ptr(ws), L.stream_ptr()), "acr_gemm_f32")
+    _t1(tok)
     return c
 
 
@@ -440,7 +515,7 @@ class LinearF32Fn(Function):
     in one TN sweep over dy (models/vision_transformer.py:200,212 and their autograd backward)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, resid):
+    def forward(ctx, x, weight, bias, resid, owner=None):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         N = weight.shape[0]
@@ -450,7 +525,7 @@ class LinearF32Fn(Function):
         y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
         gemm_f32_raw("nt", x2, weight, y, bias=bias, aux=r2)
         ctx.save_for_backward(x2, weight)
-        ctx.has_bias, ctx.has_resid = bias is not None, resid is not None
+        ctx.has_bias, ctx.has_resid, ctx.owner = bias is not None, resid is not None, owner
         return y.reshape(*shp[:-1], N)
 
     @staticmethod
@@ -463,7 +538,7 @@ class LinearF32Fn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((dy2.shape[0], K), dtype=torch.float32, device=dy.device)
-            gemm_f32_raw("nn", dy2, weight, dx)
+            _dx_f32(dy2, weight, ctx.owner, dx)
             dx = dx.reshape(*dy.shape[:-1], K)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
@@ -472,7 +547,7 @@ class LinearF32Fn(Function):
             gemm_f32_raw("tn", dy2, x2, dw, colsum=db)
         elif want_db:
             db = dy2.sum(0)
-        return dx, dw, db, (dy if ctx.has_resid else None)
+        return dx, dw, db, (dy if ctx.has_resid else None), None
 
 
 class MlpF32Fn(Function):
@@ -480,7 +555,8 @@ class MlpF32Fn(Function):
     epilogues: fc1 writes h and GELU(h) in one pass; fc2's input gradient comes out multiplied by GELU'(h)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, resid):
+    def forward(ctx, x, w1, b1, w2, b2, resid, fc1=None, fc2=None):
+        ctx.fc1, ctx.fc2 = fc1, fc2
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         M = x2.shape[0]
@@ -514,7 +590,7 @@ class MlpF32Fn(Function):
         elif need[4]:
             db2 = dy2.sum(0)
         dh = torch.empty_like(h)
-        gemm_f32_raw("nn", dy2, w2, dh, aux=h, act=2)                 # (dY W2) * GELU'(h)
+        _dx_f32(dy2, w2, ctx.fc2, dh, aux=h, act=2)                   # (dY W2) * GELU'(h)
         if need[1]:
             dw1 = torch.empty_like(w1)
             db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if need[2] else None
@@ -523,9 +599,9 @@ class MlpF32Fn(Function):
             db1 = dh.sum(0)
         if need[0]:
             dx = torch.empty_like(x2)
-            gemm_f32_raw("nn", dh, w1, dx)
+            _dx_f32(dh, w1, ctx.fc1, dx)
             dx = dx.reshape(*dy.shape[:-1], w1.shape[1])
-        return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None)
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None), None, None
 
 
 def mlp_f32_usable(x, fc1, fc2):
@@ -534,7 +610,7 @@ def mlp_f32_usable(x, fc1, fc2):
 
 
 def mlp_f32(x, fc1, fc2, resid=None):
-    return MlpF32Fn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, resid)
+    return MlpF32Fn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, resid, fc1, fc2)
 
 
 def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hip_fwd=True):
@@ -544,7 +620,7 @@ def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hi
             and lin.weight.shape[1] % 64 == 0 and x.is_contiguous()):
         return LinearBf16Fn.apply(x, lin.weight, lin.bias, resid, hip_dx, hip_dw, hip_fwd, lin)
     if use_hip and linear_f32_usable(x, lin.weight) and not torch.is_autocast_enabled():
-        return LinearF32Fn.apply(x, lin.weight, lin.bias, resid)
+        return LinearF32Fn.apply(x, lin.weight, lin.bias, resid, lin)
     y = torch.nn.functional.linear(x, lin.weight, lin.bias)
     return y if resid is None else resid + y
 

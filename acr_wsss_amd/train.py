@@ -222,4 +222,21 @@ def train_step(model, optimizer, img, label, alpha, grad_sync=None, amp_dtype=No
     if grad_sync is not None:
         grad_sync.finish()
     optimizer.step()
+    refresh_weight_transposes(model)
     return loss, terms
+
+
+def refresh_weight_transposes(model):
+    """fp32 mode: the (in, out) copies of the block Linears' weights that the input-gradient GEMMs read (one launch; created on
+    first use).  Optional -- a loop that does not call this (the reference's own, train_acr.py:135-174) simply runs those GEMMs
+    on W as stored, since a copy is only ever used while its weight's version matches.  The bf16 mode's MasterWeights keeps its
+    own set."""
+    from . import ops as _ops
+    wt = getattr(model, "_acr_wt_f32", None)
+    if wt is None:
+        p0 = next(model.parameters(), None)
+        if p0 is None or not p0.is_cuda or p0.dtype != torch.float32 or not _ops.F32_WT or not _ops.F32_HIP_LINEAR:
+            return
+        wt = _ops.WeightTransposes(model.modules(), dtype=torch.float32)
+        object.__setattr__(model, "_acr_wt_f32", wt)       # not a submodule / parameter: plain attribute
+    wt.refresh()

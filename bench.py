@@ -89,14 +89,16 @@ def _mfma_rec(name, alg_flops, exec_flops, t, peak, extra=None):
     return rec
 
 
-def roofline_probe(args, dev, dtype):
+def roofline_probe(args, dev, dtype, live=None):
     """The hand-written kernels of the step, launched one by one through the C ABI at the bench geometry and timed with
     HIP events on the launch stream.  ALGORITHMIC work per launch:
       attention forward  : S = q k^T and O = P v             -> 2 products of 2*T*T*64 FLOP per (sample, head)
       attention backward : dP = dO v^T, dV, dK, dQ           -> 4 products (what autograd's bmm backward executes)
       Linear / dX / dW   : 2*M*N*K
     `executed_*` additionally counts what the flash-style kernels recompute (S in both backward sweeps, the head-mean
-    pass of the forward).  `frac` is ALGORITHMIC work / time / dense matrix peak of the dtype.  Returns the record of the
+    pass of the forward).  When `live` is given (average ms of the same launches measured with HIP events INSIDE the timed
+    steps, ops.KernelTimer) `achieved` / `frac` / `launch_ms` are the in-step values and the isolated replay is kept as
+    `isolated_launch_ms`.  `frac` is ALGORITHMIC work / time / dense matrix peak of the dtype.  Returns the record of the
     kernel that is on top of this round's in-step rocprof profile (profiles/r02_in_step_kernels.json) with the others
     under `kernels`."""
     from acr_wsss_amd import _lib as L, ops
@@ -170,12 +172,29 @@ def roofline_probe(args, dev, dtype):
         y = torch.empty(Mtok, Nw, dtype=dt, device=dev)
         dx = torch.empty(Mtok, Kw, dtype=dt, device=dev)
         dww = torch.empty(Nw, Kw, dtype=dt, device=dev)
+        wt32 = w.t().contiguous()                          # what train.refresh_weight_transposes keeps per Linear
         for key, name, call in (
                 ("acr_gemm_f32_nt", "gemm_f32 NT (fc1 forward, %dx%dx%d)" % (Mtok, Nw, Kw), lambda: ops.gemm_f32_raw("nt", x, w, y, bias=bias)),
-                ("acr_gemm_f32_nn", "gemm_f32 NN (fc1 input gradient)", lambda: ops.gemm_f32_raw("nn", dy, w, dx)),
+                ("acr_gemm_f32_dx", "gemm_f32 NT on the cached W^T (fc1 input gradient, %dx%dx%d; same shape as fc2 forward)" % (Mtok, Kw, Nw),
+                 lambda: ops.gemm_f32_raw("nt", dy, wt32, dx)),
                 ("acr_gemm_f32_tn", "gemm_f32 TN (fc1 weight gradient)", lambda: ops.gemm_f32_raw("tn", dy, x, dww))):
             t = time_kernel(call, iters=5)
             kernels[key] = _mfma_rec(name, fl, fl, t, peak)
+    # durations measured inside the timed steps take precedence over the isolated replays above
+    Mt = B * T
+    live_keys = {"acr_attn_fwd": "attn_fwd %dx%dx%d" % (B, H, T), "acr_attn_bwd": "attn_bwd %dx%dx%d" % (B, H, T),
+                 "acr_gemm_f32_nt": "gemm_f32_nt %dx%dx%d" % (Mt, 3072, 768), "acr_gemm_f32_dx": "gemm_f32_nt %dx%dx%d" % (Mt, 768, 3072),
+                 "acr_gemm_f32_tn": "gemm_f32_tn %dx%dx%d" % (3072, 768, Mt), "acr_linear_bf16": "linear_bf16 %dx%dx%d" % (Mt, 3072, 768),
+                 "acr_linear_bf16_dx": "linear_bf16 %dx%dx%d" % (Mt, 768, 3072), "acr_wgrad_bf16": "wgrad_bf16 %dx%dx%d" % (Mt, 3072, 768)}
+    for k, lk in live_keys.items():
+        if live and k in kernels and lk in live:
+            r, t = kernels[k], live[lk] * 1e-3
+            r["isolated_launch_ms"] = r["launch_ms"]
+            r["launch_ms"] = round(t * 1e3, 4)
+            r["achieved"] = round(r["flops_per_launch"] / t / 1e12, 2)
+            r["frac"] = round(r["flops_per_launch"] / t / peak, 4)
+            r["executed_frac"] = round(r["executed_flops_per_launch"] / t / peak, 4)
+            r["timed"] = "HIP events around the launch inside the timed steps (average over the steps)"
     # in-step rocprofv3 durations of this round (scripts/profile_round.sh + scripts/make_in_step.py: kernel trace of this very
     # command) and the HBM traffic of the probe's launches from the two separate PMC passes; the record's head is the
     # kernel group on TOP of the in-step profile, not the one that looks worst
@@ -279,16 +298,25 @@ def run_mode(args, dtype, world, rank, dev):
         loss, _ = step()
         torch.cuda.synchronize()
         log("%s: warmup step %d done" % (dtype, i))
+    # per-kernel durations are taken INSIDE the timed steps: HIP events around the first launch of every hooked kernel shape
+    # in every step, on the launch stream (ops.KernelTimer; ~20 event pairs per step, < 0.1 % of a step)
+    from acr_wsss_amd import ops
+    timer = ops.KernelTimer() if (world == 1 and not args.no_roofline) else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ops.KERNEL_TIMER = timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if timer is not None:
+            timer.next_step()
         loss, _ = step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ops.KERNEL_TIMER = None
+    live = {k: sum(v) / len(v) for k, v in timer.collect().items()} if timer is not None else {}
     log("%s: timed %d steps in %.3f s" % (dtype, args.steps, elapsed))
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -300,6 +328,7 @@ def run_mode(args, dtype, world, rank, dev):
            "loss": round(float(loss.detach()), 5),
            "step_mfma_frac": round(value * FLOP_PER_IMG_448 * (args.size / 448.0) ** 2 / (world * PEAK_MFMA[dtype]), 4),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    rec["_live_ms"] = live                               # popped by main(): feeds the roofline records
     del model, opt, sync, step, img, label, loss
     gc.collect()
     torch.cuda.empty_cache()
@@ -338,8 +367,10 @@ def main():
         return
 
     runs = {m: run_mode(args, m, world, rank, dev) for m in modes}
+    lives = {m: runs[m].pop("_live_ms", {}) for m in modes}
     if rank == 0:
         head = runs[modes[0]]                              # fp32 unless a single dtype was asked for
+        head_live = lives[modes[0]]
         std = (args.size, args.batch, args.classes) == (448, 16, 20)
         out = {
             "metric": "img/s ACR-ViT-hybrid-base %dx%d train step" % (args.size, args.size), "value": head["value"], "unit": "img/s",
@@ -354,12 +385,12 @@ def main():
             "tuned_library_gemms": bool(tuned),
         }
         if world == 1 and not args.no_roofline:
-            out["roofline"] = roofline_probe(args, dev, head["dtype"])
+            out["roofline"] = roofline_probe(args, dev, head["dtype"], head_live)
             log("roofline probe (%s) done" % head["dtype"])
         for m in modes[1:]:
             sub = dict(runs[m])
             if world == 1 and not args.no_roofline:
-                sub["roofline"] = roofline_probe(args, dev, m)
+                sub["roofline"] = roofline_probe(args, dev, m, lives[m])
                 log("roofline probe (%s) done" % m)
             out[m] = sub
         if world == 1 and not args.no_cpu_baseline:

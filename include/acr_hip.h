@@ -219,6 +219,8 @@ typedef struct acr_tr_tensor {
     int32_t tiles_c;    /* ceil(cols / 64) */
 } acr_tr_tensor;
 int acr_transpose_many_bf16(const void* table, const int32_t* blk_tensor, int32_t nblocks, void* stream);
+/* the same for fp32 matrices (rows and cols multiples of 4) */
+int acr_transpose_many_f32(const void* table, const int32_t* blk_tensor, int32_t nblocks, void* stream);
 
 /* ---- LayerNorm of the transformer blocks (models/vision_transformer.py:219-222,299), bf16 (M, C) rows ----
  * C a multiple of 256, <= 1024.  stats: (M*2) fp32 [mean, rstd].  Backward writes dx, dgamma, dbeta in one pass over

@@ -623,3 +623,51 @@ def test_conv1x1_f32(N, cin, cout, H, W):
     for n, a, b in (("y", y, ref), ("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad)):
         err = (a.double() - b).abs().max() / b.abs().max()
         assert err <= 1e-5, (n, float(err))
+
+
+def test_f32_input_gradients_on_cached_transposes_are_bit_identical():
+    """fp32 mode: with a current (in, out) copy of the weight (ops.WeightTransposes, refreshed after every optimizer step by
+    train.refresh_weight_transposes) the Linear / fused-MLP input gradients run as NT GEMMs on the copy instead of NN on W as
+    stored.  Same k-ordered fp32 fmaf chains -> bit-identical gradients; a weight changed behind the cache's back (version
+    mismatch) is never served stale."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    fc1 = torch.nn.Linear(768, 3072).to(dev)
+    fc2 = torch.nn.Linear(3072, 768).to(dev)
+    qkv = torch.nn.Linear(768, 2304).to(dev)
+    head = torch.nn.Linear(768, 20).to(dev)                                  # 20 rows: not cached, stays NN
+    x = torch.randn(3, 197, 768, generator=g).to(dev)
+    dy = torch.randn(3, 197, 768, generator=g).to(dev)
+    dq = torch.randn(3, 197, 2304, generator=g).to(dev)
+
+    def grads():
+        xa = x.clone().requires_grad_(True)
+        ops.mlp_f32(xa, fc1, fc2, None).backward(dy)
+        xb = x.clone().requires_grad_(True)
+        ops.linear_or_hip(xb, qkv).backward(dq)
+        return xa.grad, xb.grad
+
+    base = grads()                                                           # no copies yet: NN on W as stored
+    wt = ops.WeightTransposes([fc1, fc2, qkv, head], dtype=torch.float32)
+    assert len(wt.lins) == 3
+    wt.refresh()
+    assert torch.equal(fc1._acr_wt, fc1.weight.t()) and torch.equal(qkv._acr_wt, qkv.weight.t())
+    assert ops.weight_t(fc2.weight, fc2, make=False) is fc2._acr_wt
+    cached = grads()
+    for a, b in zip(base, cached):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        fc1.weight.mul_(0.5)                                                 # in-place update without a refresh
+    assert ops.weight_t(fc1.weight, fc1, make=False) is None                 # stale copy is not served ...
+    xa = x.clone().requires_grad_(True)
+    ops.mlp_f32(xa, fc1, fc2, None).backward(dy)                             # ... and the gradient follows the new weight
+    ops.F32_WT = False
+    try:
+        xr = x.clone().requires_grad_(True)
+        ops.mlp_f32(xr, fc1, fc2, None).backward(dy)
+    finally:
+        ops.F32_WT = True
+    assert torch.equal(xa.grad, xr.grad) and not torch.equal(xa.grad, base[0])
+    wt.refresh()
+    assert ops.weight_t(fc1.weight, fc1, make=False) is fc1._acr_wt and torch.equal(fc1._acr_wt, fc1.weight.t())
