@@ -518,14 +518,12 @@ __global__ __launch_bounds__(256, 2) void attn_delta_dma_kernel(AttnGeom g, cons
 // ---------------------------------------------------------------------------------------------
 // dQ: workgroup = (b, h, 128 queries); Q and dO rows of the wave's 32 queries in registers; K/V tiles stream
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_dq_dma_kernel(AttnGeom g, const float* __restrict__ q, const float* __restrict__ k,
-                                                             const float* __restrict__ v, const float* __restrict__ d_o,
-                                                             const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                             const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
-                                                             float* __restrict__ dq) {
-    __shared__ __attribute__((aligned(1024))) float smem[4 * DT_FLOATS];
+__device__ __forceinline__ void attn_dq_body(float* smem, int bid, int nblk, const AttnGeom& g, const float* __restrict__ q,
+                                             const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ d_o,
+                                             const float* __restrict__ lse2, const float* __restrict__ delta,
+                                             const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st, float* __restrict__ dq) {
     const int nqt = (g.T + 127) >> 7;
-    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    int id = acr_xcd_remap(bid, nblk);
     const int qt = id % nqt; id /= nqt;
     const int hd = id % g.H;
     const int b = id / g.H;
@@ -596,15 +594,13 @@ __global__ __launch_bounds__(256, 2) void attn_dq_dma_kernel(AttnGeom g, const f
 // dK, dV: workgroup = (b, h, 128 keys); K and V rows of the wave's 32 keys in registers; Q / dO tiles (and the 32 queries'
 // lse2 / delta, one 256-byte DMA) stream
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_dkdv_dma_kernel(AttnGeom g, const float* __restrict__ q, const float* __restrict__ k,
-                                                               const float* __restrict__ v, const float* __restrict__ d_o,
-                                                               const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                               const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
-                                                               float* __restrict__ dk, float* __restrict__ dv) {
-    __shared__ __attribute__((aligned(1024))) float smem[4 * DT_FLOATS];
-    __shared__ __attribute__((aligned(256))) float rc[2 * 64];                 // [slot][lse2 x 32 | delta x 32]
+__device__ __forceinline__ void attn_dkdv_body(float* smem, float* rc, int bid, int nblk, const AttnGeom& g, const float* __restrict__ q,
+                                               const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ d_o,
+                                               const float* __restrict__ lse2, const float* __restrict__ delta,
+                                               const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st, float* __restrict__ dk,
+                                               float* __restrict__ dv) {
     const int nkt = (g.T + 127) >> 7;
-    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    int id = acr_xcd_remap(bid, nblk);
     const int ktile = id % nkt; id /= nkt;
     const int hd = id % g.H;
     const int b = id / g.H;
@@ -689,6 +685,23 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_dma_kernel(AttnGeom g, const
     }
 }
 
+// dK/dV and dQ in ONE launch: the two sweeps are independent and each is a whole number of equally long workgroups on 512
+// resident slots (5.25 rounds at B = 32, T = 785) -- launched separately each pays its own partly filled last round.  The first
+// half of the grid does dK/dV, the second dQ; they share the LDS ring (a workgroup is one or the other).
+__global__ __launch_bounds__(256, 2) void attn_bwd_dma_kernel(AttnGeom g, const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, const float* __restrict__ d_o,
+                                                              const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                              const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
+                                                              float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv) {
+    __shared__ __attribute__((aligned(1024))) float smem[4 * DT_FLOATS];
+    __shared__ __attribute__((aligned(256))) float rc[2 * 64];                 // dK/dV: [slot][lse2 x 32 | delta x 32]
+    const int half = gridDim.x >> 1;
+    if ((int)blockIdx.x < half)
+        attn_dkdv_body(smem, rc, blockIdx.x, half, g, q, k, v, d_o, lse2, delta, gm, gm_sb, gm_st, dk, dv);
+    else
+        attn_dq_body(smem, blockIdx.x - half, half, g, q, k, v, d_o, lse2, delta, gm, gm_sb, gm_st, dq);
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers (called from attn_f32.hip for fp32 tensors)
 // ---------------------------------------------------------------------------------------------
@@ -707,6 +720,6 @@ void acr_attn_bwd_f32_dma(const AttnGeom& g, const float* q, const float* k, con
     const int nt = (g.T + 127) / 128;
     const dim3 grid(g.B * g.H * nt);
     hipLaunchKernelGGL(attn_delta_dma_kernel, grid, dim3(256), 0, st, g, q, k, o, d_o, lse2, gm, gm_sb, gm_st, delta);
-    hipLaunchKernelGGL(attn_dkdv_dma_kernel, grid, dim3(256), 0, st, g, q, k, v, d_o, lse2, (const float*)delta, gm, gm_sb, gm_st, dk, dv);
-    hipLaunchKernelGGL(attn_dq_dma_kernel, grid, dim3(256), 0, st, g, q, k, v, d_o, lse2, (const float*)delta, gm, gm_sb, gm_st, dq);
+    hipLaunchKernelGGL(attn_bwd_dma_kernel, dim3(2 * grid.x), dim3(256), 0, st, g, q, k, v, d_o, lse2, (const float*)delta, gm, gm_sb, gm_st,
+                       dq, dk, dv);
 }

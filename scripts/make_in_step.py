@@ -12,7 +12,7 @@ GROUPS = {
             # forward Linears AND input gradients (NT on the cached W^T since round 2): one symbol family
             "acr_gemm_f32_nt": ["gemm_f32_dma_kernel<true, true,", "gemm_f32_kernel<true, true,"],
             "acr_gemm_f32_nn": ["gemm_f32_dma_kernel<true, false,", "gemm_f32_kernel<true, false,"],
-            "acr_attn_bwd": ["attn_delta_dma_kernel", "attn_dq_dma_kernel", "attn_dkdv_dma_kernel", "attn_delta_kernel<float>",
+            "acr_attn_bwd": ["attn_delta_dma_kernel", "attn_bwd_dma_kernel", "attn_dq_dma_kernel", "attn_dkdv_dma_kernel", "attn_delta_kernel<float>",
                              "attn_dq_kernel<float>", "attn_dkdv_kernel<float>"],
             "acr_attn_fwd": ["attn_fwd_dma_kernel", "attn_pmean_dma_kernel", "attn_fwd_kernel<float>", "attn_tile_qk_kernel<float, 0>"],
             "acr_consistency_fwd": ["cons_fwd", "cons_reduce"]},
