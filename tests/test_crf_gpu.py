@@ -185,3 +185,32 @@ def test_infer_cam_list_writes_crf_outputs(tmp_path):
             assert np.abs(d[c] - ref[c]).max() <= tol, (alpha, c, np.abs(d[c] - ref[c]).max(), tol)
     with pytest.raises(ValueError):
         infer_cam_list(model, [items[0][:4]], out_crf=str(tmp_path / "x"))
+
+
+@pytest.mark.parametrize("hw", [(1, 1), (2, 3), (1, 9), (7, 1)])
+def test_lattice_tiny_images(hw):
+    """degenerate sizes (fewer pixels than the reference's SSE block of 4, single rows / columns) against the oracle"""
+    h, w = hw
+    rng = np.random.default_rng(h * 10 + w)
+    img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    vals = rng.standard_normal((h * w, 2)).astype(np.float32)
+    x = torch.from_numpy(np.ascontiguousarray(vals.T)).to(DEV)
+    for name, feat in (("bil", C.bilateral_features(img, 80, 13)), ("spa", C.spatial_features(h, w, 3))):
+        ref_lat = C.lattice_init(feat)
+        lat = _lattice(img, name)
+        assert lat.n_points == ref_lat["M"]
+        assert np.array_equal(lat.filter(x).cpu().numpy().T, C.lattice_compute(ref_lat, vals))
+
+
+def test_lattice_large_image_capacity():
+    """768 x 1024 (4.7 M pixel-vertex pairs): builds without key overflow, filters deterministically, stays normalisable"""
+    from acr_wsss_amd.crf import PermutohedralLattice
+    h, w = 768, 1024
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    lat = PermutohedralLattice(h, w, 80, rgb=img, srgb=13, device=DEV)
+    assert 0 < lat.n_points <= 6 * (h * w + 1)
+    x = torch.rand(2, h * w, device=DEV)
+    a = lat.filter(x)
+    assert torch.isfinite(a).all() and torch.equal(a, lat.filter(x))
+    assert (lat.filter(torch.ones(1, h * w, device=DEV)) > 0).all()
