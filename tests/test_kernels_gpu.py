@@ -671,3 +671,26 @@ def test_f32_input_gradients_on_cached_transposes_are_bit_identical():
     assert torch.equal(xa.grad, xr.grad) and not torch.equal(xa.grad, base[0])
     wt.refresh()
     assert ops.weight_t(fc1.weight, fc1, make=False) is fc1._acr_wt and torch.equal(fc1._acr_wt, fc1.weight.t())
+
+
+def test_kernel_timer_brackets_first_launch_per_step():
+    """ops.KernelTimer (bench.py's in-step kernel timing): one sample per key and step, on the launch stream, and nothing is
+    recorded while it is off."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    lin = torch.nn.Linear(256, 512).to(dev)
+    x = torch.randn(4, 64, 256, device=dev)
+    assert ops.KERNEL_TIMER is None
+    ops.linear_or_hip(x, lin)
+    t = ops.KernelTimer()
+    ops.KERNEL_TIMER = t
+    try:
+        for _ in range(3):
+            t.next_step()
+            ops.linear_or_hip(x, lin)
+            ops.linear_or_hip(x, lin)                                        # second launch of the same shape in a step: not timed
+    finally:
+        ops.KERNEL_TIMER = None
+    s = t.collect()
+    assert list(s) == ["gemm_f32_nt 256x512x256"] and len(s["gemm_f32_nt 256x512x256"]) == 3
+    assert all(0 < ms < 50 for ms in s["gemm_f32_nt 256x512x256"])
