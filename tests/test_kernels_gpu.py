@@ -694,3 +694,62 @@ def test_kernel_timer_brackets_first_launch_per_step():
     s = t.collect()
     assert list(s) == ["gemm_f32_nt 256x512x256"] and len(s["gemm_f32_nt 256x512x256"]) == 3
     assert all(0 < ms < 50 for ms in s["gemm_f32_nt 256x512x256"])
+
+
+def test_c_abi_launches_capture_into_a_hip_graph():
+    """include/acr_hip.h promises: every entry point only enqueues work on the caller's stream (no allocation, no
+    synchronisation) -> a sequence of them can be captured into a hipGraph and replayed.  Attention forward + backward (fp32,
+    head-mean and G term on) and an fp32 GEMM with epilogue, captured once, replayed on new input values."""
+    from acr_wsss_amd import _lib as L, ops
+    lib = L.load()
+    dev = _dev()
+    B, H, T = 2, 12, 197
+    g = torch.Generator(device="cpu").manual_seed(3)
+    qkv = torch.randn(B, T, 3 * H * 64, generator=g).to(dev)
+    d_o = torch.randn(B, T, H * 64, generator=g).to(dev)
+    gm = (torch.randn(B, T, ops.pad4(T), generator=g).to(dev) * 1e-2)[:, :, :T]
+    o = torch.empty(B, T, H * 64, device=dev)
+    lse2 = torch.empty(B, H, T, device=dev)
+    pm = torch.empty(B, T, T, device=dev)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, T, device=dev)
+    x = torch.randn(B * T, 768, generator=g).to(dev)
+    w = (torch.randn(768, 768, generator=g) * 0.03).to(dev)
+    bias = torch.randn(768, generator=g).to(dev)
+    y = torch.empty(B * T, 768, device=dev)
+    d = ops._desc(B, H, T, torch.float32)
+    qp, kp, vp = ops._qkv_ptrs(qkv, H)
+    dqp, dkp, dvp = ops._qkv_ptrs(dqkv, H)
+
+    def launch():
+        st = L.stream_ptr()
+        L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm), T * T, T, st), "fwd")
+        L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(gm), gm.stride(0), gm.stride(1), dqp, dkp, dvp,
+                                 L.ptr(delta), st), "bwd")
+        L.check(lib.acr_gemm_f32(0, 0, L.ptr(o.view(B * T, 768)), 768, L.ptr(w), 768, L.ptr(bias), L.ptr(x), 768, L.ptr(y), 768, None, None,
+                                 B * T, 768, 768, None, st), "gemm")
+
+    def eager():
+        launch()
+        torch.cuda.synchronize()
+        return o.clone(), pm.clone(), dqkv.clone(), y.clone()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        launch()                                                             # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        launch()
+    for seed in (11, 12):
+        g2 = torch.Generator(device="cpu").manual_seed(seed)
+        qkv.copy_(torch.randn(B, T, 3 * H * 64, generator=g2))
+        d_o.copy_(torch.randn(B, T, H * 64, generator=g2))
+        ref = eager()
+        for t in (o, pm, dqkv, y):
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for got, want in zip((o, pm, dqkv, y), ref):
+            assert torch.equal(got, want)
