@@ -879,7 +879,12 @@ def _wstd_desc(p0s, p1s, p2s, device, p3s=None):
         rec[i] = (w.data_ptr(), p1s[i].data_ptr(), p2s[i].data_ptr() if p2s is not None else 0,
                   p3s[i].data_ptr() if (p3s is not None and p3s[i] is not None) else 0, cout, w.numel() // cout, ch, 0)
         ch += cout
-    return torch.from_numpy(rec.view(np.uint8)).to(device), ch
+    # pinned staging + asynchronous copy: a pageable .to(device) drains the whole stream on the host (twice per step here --
+    # the forward's first and the backward's last launch -- which kept Python from running ahead of the GPU)
+    raw = rec.view(np.uint8)
+    host = torch.empty(raw.size, dtype=torch.uint8, pin_memory=True)
+    host.numpy()[:] = raw
+    return host.to(device, non_blocking=True), ch
 
 
 WSTD_TRANSPOSED = os.environ.get("ACR_WSTD_TRANSPOSED", "1") != "0"      # A/B: transposed 1x1 weights from the weight-std launch
