@@ -8,8 +8,9 @@
 // (<= 13 x 8 bf16 per thread at 1024 threads), so forward is 1 read + 1 write and backward 2 (3 with residual)
 // reads + 1 (2) writes, with exact two-pass statistics in fp32 and no re-read for the normalise / dx passes.
 // ReLU's mask is recomputed in backward from x (and the residual), so y is not kept alive for it.
-// d(gamma), d(beta): per-(sample, channel) partials accumulated with LDS float atomics inside the workgroup
-// (order-dependent in the last bits), summed over samples by the caller in a fixed order.
+// d(gamma), d(beta): per-(sample, channel) partials -- every wave reduces its lanes per channel with a shuffle butterfly
+// (a wave's 64 consecutive vectors span one or two channels) into its own LDS row, the rows are summed in wave order and the
+// caller sums over samples in a fixed order: no atomics, bit-reproducible run to run.
 #include "acr_common.h"
 
 typedef __bf16 bf16_t;
@@ -94,14 +95,16 @@ __global__ __launch_bounds__(NT) void gn_bwd_kernel(const bf16_t* __restrict__ d
                                                     float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
                                                     int C, int HW, int cg) {
     __shared__ float sh[NT / 64];
-    __shared__ float dgs[64], dbs[64];
+    __shared__ float dgw[NT / 64][64], dbw[NT / 64][64];      // [wave][channel of the group]
     const int g = blockIdx.x % GN_GROUPS, n = blockIdx.x / GN_GROUPS;
     const int64_t base = ((int64_t)n * C + (int64_t)g * cg) * HW;
     const int nvec = (cg * HW) >> 3, vpc = HW >> 3;
     const float inv_n = 1.f / (float)(cg * HW);
     const int tid = threadIdx.x;
     const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
-    if (tid < 64) { dgs[tid] = 0.f; dbs[tid] = 0.f; }
+    const int wave = tid >> 6, lane = tid & 63;
+    dgw[wave][lane] = 0.f;
+    dbw[wave][lane] = 0.f;
     bf16x8 xv[GN_MAXV], gv[GN_MAXV];
 #pragma unroll
     for (int i = 0; i < GN_MAXV; ++i) {
@@ -114,13 +117,13 @@ __global__ __launch_bounds__(NT) void gn_bwd_kernel(const bf16_t* __restrict__ d
 #pragma unroll
     for (int i = 0; i < GN_MAXV; ++i) {
         const int v = tid + i * NT;
+        const int cl = v < nvec ? v / vpc : -1;
+        float dgl = 0.f, dbl = 0.f;
         if (v < nvec) {
-            const int cl = v / vpc;
             const float gam = (float)gamma[g * cg + cl];
             const float bet = (float)beta[g * cg + cl];
             bf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
             if (ACT == GN_ACT_ADD_RELU) rv = *reinterpret_cast<const bf16x8*>(res + base + (int64_t)v * 8);
-            float dgl = 0.f, dbl = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xh = ((float)xv[i][e] - mean) * rstd;
@@ -139,8 +142,17 @@ __global__ __launch_bounds__(NT) void gn_bwd_kernel(const bf16_t* __restrict__ d
             if (ACT == GN_ACT_ADD_RELU) *reinterpret_cast<bf16x8*>(dres + base + (int64_t)v * 8) = gv[i];
             s1 = fmaf(dbl, gam, s1);
             s2 = fmaf(dgl, gam, s2);
-            atomicAdd(&dgs[cl], dgl);
-            atomicAdd(&dbs[cl], dbl);
+        }
+        // per-channel sums of this wave's 64 vectors: one butterfly per distinct channel (1-2 of them), fixed order
+        unsigned long long rem = __ballot(cl >= 0);
+        while (rem) {
+            const int c = __shfl(cl, __ffsll((long long)rem) - 1);
+            const bool mine = cl == c;
+            float sa = mine ? dgl : 0.f, sb = mine ? dbl : 0.f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off); sb += __shfl_xor(sb, off); }
+            if (lane == 0) { dgw[wave][c] += sa; dbw[wave][c] += sb; }
+            rem &= ~__ballot(mine);
         }
     }
     const float c1 = gn_block_sum<NT>(s1, sh) * inv_n;
@@ -159,9 +171,12 @@ __global__ __launch_bounds__(NT) void gn_bwd_kernel(const bf16_t* __restrict__ d
             *reinterpret_cast<bf16x8*>(dx + base + (int64_t)v * 8) = o;
         }
     }
-    if (tid < cg) {                                          // gn_block_sum's barriers ordered the LDS atomics
-        dgamma_part[(int64_t)n * C + g * cg + tid] = dgs[tid];
-        dbeta_part[(int64_t)n * C + g * cg + tid] = dbs[tid];
+    if (tid < cg) {                                          // gn_block_sum's barriers ordered the waves' LDS rows
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { a += dgw[w][tid]; b += dbw[w][tid]; }
+        dgamma_part[(int64_t)n * C + g * cg + tid] = a;
+        dbeta_part[(int64_t)n * C + g * cg + tid] = b;
     }
 }
 

@@ -17,6 +17,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _reproducible_library_convolutions():
+    """The hand-written kernels sum nothing with atomics: a training step is bit-reproducible run to run (loss and every
+    gradient, fp32 and bf16; scripts/lab/determinism.py) -- EXCEPT for the stem's 3x3 / 7x7 convolutions, which stay on MIOpen,
+    whose default solver choice includes split-K kernels with atomic accumulation (igemm_*_gkgs), forward included.  On the
+    random recipe weights that last-bit scatter is amplified to ~0.5 % of the bf16 loss, enough to make loose comparisons flip.
+    The GPU tests therefore ask MIOpen for its deterministic solvers; the bench keeps the default (fastest) ones."""
+    old = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    yield
+    torch.backends.cudnn.deterministic = old
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
