@@ -50,13 +50,6 @@ struct GemmF32Args {
 #endif
 };
 
-__device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float dgelu_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;
-    return cdf + x * pdf;
-}
-
 // one K-chunk of one operand, global -> registers (4 float4 per thread), addresses clamped into the matrix so that every
 // load is unconditional and nothing touches the loaded registers before store_chunk (the loads stay in flight across the
 // chunk's MFMAs).  KC: rows = the operand's non-contraction index, k contiguous; KS: rows = k, 128 contiguous elements.
@@ -129,18 +122,19 @@ __device__ __forceinline__ void epilogue_f32(const GemmF32Args& g, f32x16 (&acc)
                 float* cp = g.c + (int64_t)row * g.ldc + col;
                 if (ACT == 0) {
                     *cp = g.aux ? v + x[e] : v;
-                } else if (ACT == 1) {
-                    *cp = v;
-                    g.c2[(int64_t)row * g.ldc + col] = gelu_f(v);
+                } else if (ACT == 1) {                          // one erff serves GELU and GELU'
+                    const float er = erff(v * 0.70710678118654752440f);
+                    g.c2[(int64_t)row * g.ldc + col] = v * 0.5f * (1.0f + er);
+                    *cp = 0.5f * (1.0f + er) + v * (expf(-0.5f * v * v) * 0.39894228040143267794f);
                 } else {
-                    *cp = v * dgelu_f(x[e]);
+                    *cp = v * x[e];
                 }
             }
         }
     }
 }
 
-// ACT: 0 = (+bias)(+resid), 1 = c = h, c2 = GELU(h) with h = acc + bias, 2 = c = acc * GELU'(aux), 3 = split slab (no epilogue)
+// ACT: 0 = (+bias)(+resid), 1 = c = GELU'(h), c2 = GELU(h) with h = acc + bias, 2 = c = acc * aux, 3 = split slab (no epilogue)
 template <bool A_KC, bool B_KC, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
     __shared__ __attribute__((aligned(16))) float smem[4 * F_STAGE];      // [buf][A|B]

@@ -563,7 +563,7 @@ class MlpF32Fn(Function):
         Hd, D = w1.shape[0], w2.shape[0]
         h = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
         a = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
-        gemm_f32_raw("nt", x2, w1, h, bias=b1, act=1, c2=a)
+        gemm_f32_raw("nt", x2, w1, h, bias=b1, act=1, c2=a)          # a = GELU(h), and GELU'(h) in place of h (all backward needs)
         r2 = resid.reshape(-1, D) if resid is not None else None
         if r2 is not None and not r2.is_contiguous():
             r2 = r2.contiguous()
@@ -590,7 +590,7 @@ class MlpF32Fn(Function):
         elif need[4]:
             db2 = dy2.sum(0)
         dh = torch.empty_like(h)
-        _dx_f32(dy2, w2, ctx.fc2, dh, aux=h, act=2)                   # (dY W2) * GELU'(h)
+        _dx_f32(dy2, w2, ctx.fc2, dh, aux=h, act=2)                   # (dY W2) * GELU'(h); `h` holds GELU'(h) (see forward)
         if need[1]:
             dw1 = torch.empty_like(w1)
             db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if need[2] else None

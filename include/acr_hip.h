@@ -131,8 +131,9 @@ int acr_linear_dgelu_bf16(const void* a, int64_t lda, const void* w, int64_t ldw
  *                workgroups into fp32 slabs summed in split order (deterministic); colsum (nullable, (M)) receives
  *                sum_k a[k][m] -- the bias gradient -- from the same sweep over dy
  * Epilogues of NT / NN (act): 0: c = acc (+ bias[N]) (+ aux[M,N] = the block's residual);
- *   1: c = h = acc + bias and c2 = GELU(h) (exact erf form; fc1 forward writes both in one pass);
- *   2: c = acc * GELU'(aux) with aux = the saved h (fc2's input gradient taken through the activation).
+ *   1: with h = acc + bias: c2 = GELU(h) (exact erf form) and c = GELU'(h) -- fc1 forward writes the activation and, in
+ *      place of the pre-activation, the derivative its backward needs (one erff serves both; h itself is used nowhere else);
+ *   2: c = acc * aux with aux = the saved GELU'(h) (fc2's input gradient taken through the activation).
  * Pitches in elements, multiples of 4; pointers 16-byte aligned; K %% 4 == 0 (NT/NN), M, N %% 4 == 0 and ldc == N (TN).
  * ws: caller-owned scratch of acr_gemm_f32_ws_floats(mode, M, N, K) floats (0 for NT / NN). */
 typedef enum acr_gemm_mode { ACR_GEMM_NT = 0, ACR_GEMM_NN = 1, ACR_GEMM_TN = 2 } acr_gemm_mode;
