@@ -445,9 +445,10 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_big_kernel(const bf16_t* __r
 #define GW_BM 320
 #define GW_STAGE ((GW_BM + GB_BN) * GB_BK)         // elements per stage = 36 KiB
 
-// EPI 0: y = acc (+bias) (+resid).  EPI 1 (fc1 forward, models/vision_transformer.py:160-161): Y = h = acc + bias and
-// AUX = GELU(h) (exact erf form, computed from the bf16-rounded h like the unfused pair of kernels).  EPI 2 (input
-// gradient of fc2 through the GELU): y = acc * GELU'(AUX) with AUX = the saved h.
+// EPI 0: y = acc (+bias) (+resid).  EPI 1 (fc1 forward, models/vision_transformer.py:160-161): with h = bf16(acc + bias):
+// AUX = GELU(h) (exact erf form, computed from the bf16-rounded h like the unfused pair of kernels) and Y = GELU'(h) -- the
+// derivative fc2's backward needs, stored in place of h (which nothing else reads; Phi and the density are shared).  EPI 2
+// (input gradient of fc2 through the GELU): y = acc * AUX with AUX = the saved GELU'(h).
 // Phi(x) = 0.5 (1 + erf(x / sqrt 2)) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far inside bf16's 2^-9), sharing
 // exp(-x^2/2) with the density term of GELU': one exp, one rcp and five FMAs per element.  With libm's erff + expf the
 // epilogues cost 70-90 us per GEMM -- as much as the separate GELU kernels they replace.
@@ -462,8 +463,6 @@ __device__ __forceinline__ void gw_phi(float x, float& cdf, float& e) {
     const float erf_abs = 1.f - p * t * e;                  // erf(|x| / sqrt 2)
     cdf = 0.5f * (1.f + copysignf(erf_abs, x));
 }
-__device__ __forceinline__ float gw_gelu(float x) { float c, e; gw_phi(x, c, e); return x * c; }
-__device__ __forceinline__ float gw_dgelu(float x) { float c, e; gw_phi(x, c, e); return fmaf(x * e, 0.39894228040143267794f, c); }
 
 template <bool BIAS, bool RESID, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_wide_kernel(const bf16_t* __restrict__ A, int64_t lda,
@@ -616,17 +615,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_wide_kernel(const bf16_t*
                 if (EPI == 2) {
                     const bf16x8 hv = *reinterpret_cast<const bf16x8*>(AUX + (int64_t)row * ldaux + col);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] *= gw_dgelu((float)hv[e]);
+                    for (int e = 0; e < 8; ++e) y[e] *= (float)hv[e];
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)y[e];
-                *reinterpret_cast<bf16x8*>(Y + (int64_t)row * ldy + col) = o;
                 if (EPI == 1) {
                     bf16x8 a8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a8[e] = (bf16_t)gw_gelu((float)o[e]);
+                    for (int e = 0; e < 8; ++e) {
+                        const float hx = (float)o[e];
+                        float cdf, ex;
+                        gw_phi(hx, cdf, ex);
+                        a8[e] = (bf16_t)(hx * cdf);
+                        o[e] = (bf16_t)fmaf(hx * ex, 0.39894228040143267794f, cdf);
+                    }
                     *reinterpret_cast<bf16x8*>(AUX + (int64_t)row * ldaux + col) = a8;
                 }
+                *reinterpret_cast<bf16x8*>(Y + (int64_t)row * ldy + col) = o;
             }
         }
     }

@@ -114,9 +114,11 @@ int acr_linear_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, cons
                     const void* resid, int64_t ldr, void* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
                     void* stream);
 /* The MLP of a block with its GELU folded into the GEMM epilogues (models/vision_transformer.py:158-164):
- * acr_linear_gelu_bf16: h = a w^T + bias (M,N) and act = GELU(h) (exact erf form) in one pass -- fc1 forward;
- * acr_linear_dgelu_bf16: y = (a w^T) * GELU'(h) -- the input gradient of fc2 taken through the activation
- * (a = dY (M,K), w = W2^T (N,K), h = the saved pre-activation (M,N)).  Same operand rules as acr_linear_bf16. */
+ * acr_linear_gelu_bf16: with h = bf16(a w^T + bias) (M,N): act = GELU(h) (exact erf form) and, written to `h`, GELU'(h)
+ * -- fc1 forward keeps the derivative its backward needs in place of the pre-activation (nothing else reads it);
+ * acr_linear_dgelu_bf16: y = (a w^T) * h -- the input gradient of fc2 taken through the activation
+ * (a = dY (M,K), w = W2^T (N,K), h = the GELU'(h) saved by acr_linear_gelu_bf16 (M,N)).  Same operand rules as
+ * acr_linear_bf16. */
 int acr_linear_gelu_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const void* bias, void* h, void* act,
                          int64_t ldy, int32_t M, int32_t N, int32_t K, void* stream);
 int acr_linear_dgelu_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const void* h, int64_t ldh, void* y,
