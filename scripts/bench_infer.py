@@ -29,3 +29,17 @@ for B in (4, 8):
     for _ in range(n): infer_cam_images(m, imgs, labs, sizes)
     torch.cuda.synchronize(); dt = (time.time() - t0) / n
     print("batch %d, scale 1: %.1f ms/batch  %.1f img/s  (peak mem %.1f GB)" % (B, dt * 1e3, B / dt, torch.cuda.max_memory_allocated() / 2**30))
+
+# the optional CRF stage of infer_cam.py:218-225 on the GPU: both alphas for the 2-class image above
+import numpy as np
+from acr_wsss_amd.crf import crf_with_alpha
+orig = np.random.default_rng(0).integers(0, 256, (375, 500, 3)).astype(np.uint8)
+cam, _ = infer_cam_image(m, img, lab, (375, 500))
+for _ in range(2):
+    crf_with_alpha(cam, 1, orig)
+torch.cuda.synchronize(); t0 = time.time(); n = 5
+for _ in range(n):
+    for alpha in (1, 12):
+        crf_with_alpha(cam, alpha, orig)
+torch.cuda.synchronize()
+print("CRF (2 classes + background, alphas 1 and 12, 375x500): %.1f ms/image" % ((time.time() - t0) / n * 1e3))
