@@ -73,6 +73,7 @@ SIGNATURES = {
                                            c_int32, c_void_p]),
     "acr_sgd_chunk_elems": (c_int32, []),
     "acr_sgd_step_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float, c_void_p]),
+    "acr_sgd_step_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float, c_void_p]),
     "acr_linear_gelu_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                        c_int32, c_int32, c_void_p]),
     "acr_linear_dgelu_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,

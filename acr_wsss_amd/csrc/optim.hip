@@ -57,6 +57,46 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(const acr_sgd_tensor* __r
     }
 }
 
+// the same step for an all-fp32 model (the reference's precision): gradient fp32, the parameter is its own master (no working
+// copy).  Replaces torch's 13-launch multi-tensor SGD (0.95 ms per step) by one pass: 4 (g) + 4+4 (buf) + 4+4 (w) bytes.
+__global__ __launch_bounds__(256) void sgd_step_f32_kernel(const acr_sgd_tensor* __restrict__ tab, const int32_t* __restrict__ blk_tensor,
+                                                           const int32_t* __restrict__ blk_chunk, float lr, float mu) {
+    const acr_sgd_tensor t = tab[blk_tensor[blockIdx.x]];
+    if (!t.grad) return;
+    const int64_t c0 = (int64_t)blk_chunk[blockIdx.x] * SGD_CHUNK;
+    const int64_t c1 = min(c0 + SGD_CHUNK, t.n);
+    const float* g = (const float*)t.grad;
+    const bool vec = ((((uintptr_t)g | (uintptr_t)t.master | (uintptr_t)t.mom) & 15) == 0);
+    int64_t i = c0 + threadIdx.x * 4;
+    if (vec) {
+        for (; i + 4 <= c1; i += 256 * 4) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+            f32x4 b = *reinterpret_cast<const f32x4*>(t.mom + i), w = *reinterpret_cast<const f32x4*>(t.master + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                b[e] = mu * b[e] + gv[e];
+                w[e] = fmaf(-lr, b[e], w[e]);
+            }
+            *reinterpret_cast<f32x4*>(t.mom + i) = b;
+            *reinterpret_cast<f32x4*>(t.master + i) = w;
+        }
+    }
+    const int64_t tail = vec ? c0 + ((c1 - c0) & ~(int64_t)3) : c0;
+    for (int64_t j = tail + threadIdx.x; j < c1; j += 256) {
+        const float b = mu * t.mom[j] + g[j];
+        t.mom[j] = b;
+        t.master[j] = fmaf(-lr, b, t.master[j]);
+    }
+}
+
+extern "C" int acr_sgd_step_f32(const void* table, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t nblocks, float lr,
+                                float momentum, void* stream) {
+    ACR_CHECK_ARG(table && blk_tensor && blk_chunk && nblocks > 0, "acr_sgd_step_f32: null pointer / empty launch");
+    hipLaunchKernelGGL(sgd_step_f32_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const acr_sgd_tensor*)table,
+                       blk_tensor, blk_chunk, lr, momentum);
+    return acr_check_launch("acr_sgd_step_f32");
+}
+
 extern "C" int32_t acr_sgd_chunk_elems(void) { return SGD_CHUNK; }
 
 extern "C" int acr_sgd_step_bf16(const void* table, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t nblocks,

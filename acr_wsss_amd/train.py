@@ -4,10 +4,14 @@
   PolyOptimizer  <- tool/torchutils.py:10-31 (including its positional-argument quirk)
   train_step     <- train_acr.py:135-174 (one iteration, minus data loading and logging)
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
 from . import ops
+
+_set_versions = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
 
 
 def acr_loss(cls_list, attn_list, label, p, alpha):
@@ -51,11 +55,74 @@ class PolyOptimizer(torch.optim.SGD):
             lr_mult = (1 - self.global_step / self.max_step) ** self.momentum
             for i in range(len(self.param_groups)):
                 self.param_groups[i]["lr"] = self._initial_lr[i] * lr_mult * self.lr_scale
-        super().step(closure)
+        if closure is None and self._fused_ok():
+            self._fused_step()
+        else:
+            super().step(closure)
         self.global_step += 1
 
+    # ---- all-fp32 CUDA model: momentum + update of every parameter in ONE launch (acr_sgd_step_f32), bit-identical to the
+    # stock multi-tensor path (13 launches, 0.95 ms per step at this model's 86 M parameters) ----
+    fused = os.environ.get("ACR_F32_FUSED_SGD", "1") != "0"
 
-import os
+    def _fused_ok(self):
+        if not self.fused or len(self.param_groups) != 1 or _set_versions is None:
+            return False
+        g = self.param_groups[0]
+        if (g.get("dampening", 0) != 0 or g.get("nesterov", False) or g.get("weight_decay", 0) != 0 or g.get("maximize", False)
+                or g.get("momentum", 0) == 0):
+            return False
+        ps = g["params"]
+        return bool(ps) and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+                                and (p.grad is None or (p.grad.dtype == torch.float32 and p.grad.is_contiguous() and not p.grad.is_sparse))
+                                for p in ps)
+
+    @torch.no_grad()
+    def _fused_step(self):
+        import numpy as np
+        from . import _lib as L
+        lib = L.load()
+        ps = self.param_groups[0]["params"]
+        dev = ps[0].device
+        if getattr(self, "_f_n", None) != len(ps):
+            chunk = lib.acr_sgd_chunk_elems()
+            bt, bc = [], []
+            for i, p in enumerate(ps):
+                nch = (p.numel() + chunk - 1) // chunk
+                bt.append(np.full(nch, i, dtype=np.int32))
+                bc.append(np.arange(nch, dtype=np.int32))
+            self._f_bt = torch.from_numpy(np.concatenate(bt)).to(dev)
+            self._f_bc = torch.from_numpy(np.concatenate(bc)).to(dev)
+            self._f_host = torch.zeros((len(ps), 5), dtype=torch.int64).pin_memory()
+            self._f_tab = torch.zeros((len(ps), 5), dtype=torch.int64, device=dev)
+            self._f_evt = None
+            self._f_n = len(ps)
+        if self._f_evt is not None:
+            self._f_evt.synchronize()                      # the previous step's copy of the pinned table (long done)
+        moms = []
+        for p in ps:                                       # every column from the live tensors: nothing stale survives a
+            st = self.state[p]                             # load_state_dict or a re-allocated gradient
+            buf = st.get("momentum_buffer")
+            if buf is None:
+                buf = st["momentum_buffer"] = torch.zeros_like(p)      # mu * 0 + g == torch's first-step clone(g)
+            moms.append(buf)
+        hn = self._f_host.numpy()
+        hn[:, 0] = [0 if p.grad is None else p.grad.data_ptr() for p in ps]
+        hn[:, 1] = [p.data_ptr() for p in ps]
+        hn[:, 2] = [b.data_ptr() for b in moms]
+        hn[:, 4] = [p.numel() for p in ps]
+        self._f_tab.copy_(self._f_host, non_blocking=True)
+        self._f_evt = torch.cuda.Event()
+        self._f_evt.record()
+        grp = self.param_groups[0]
+        with torch.cuda.device(dev):
+            L.check(lib.acr_sgd_step_f32(L.ptr(self._f_tab), L.ptr(self._f_bt), L.ptr(self._f_bc), self._f_bt.numel(), float(grp["lr"]),
+                                         float(grp["momentum"]), L.stream_ptr()), "acr_sgd_step_f32")
+        # the kernel changed the parameters behind autograd's back: move their version counters on, as the stock in-place
+        # update would have -- caches keyed on them (the weight transposes) must see a stale copy as stale
+        _set_versions(ps, [p._version + 1 for p in ps])
+
+
 TABLE_CHECK = os.environ.get("ACR_SGD_TABLE_CHECK", "1") != "0"      # A/B (timing only): per-step refresh of the pointer table
 
 

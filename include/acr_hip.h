@@ -210,6 +210,9 @@ typedef struct acr_sgd_tensor {
 int32_t acr_sgd_chunk_elems(void);
 int acr_sgd_step_bf16(const void* table, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t nblocks, float lr,
                       float momentum, void* stream);
+/* the same for an all-fp32 model: grad fp32, `master` is the parameter itself, `param` unused (NULL) */
+int acr_sgd_step_f32(const void* table, const int32_t* blk_tensor, const int32_t* blk_chunk, int32_t nblocks, float lr,
+                     float momentum, void* stream);
 
 /* ---- Batched transpose: dst_i (cols, rows) = src_i (rows, cols)^T for a table of bf16 matrices in one launch (the
  * (in, out) copies of the block weights that the input-gradient GEMMs read; refreshed once per optimizer step).
