@@ -85,7 +85,10 @@ def preprocess_batch(images_uint8, records, S, device, dtype=torch.float32):
         if not ok:
             raise L.AcrHipError("acr_preprocess_batch: inconsistent geometry record %s for a %s image" % (rec, a.shape))
     packed = stage.to(device, non_blocking=True)
-    table = torch.from_numpy(records.view(np.uint8).reshape(-1).copy()).to(device, non_blocking=True)
+    raw = records.view(np.uint8).reshape(-1)
+    table_host = torch.empty(raw.size, dtype=torch.uint8, pin_memory=True)    # pinned: a pageable source would make the
+    table_host.numpy()[:] = raw                                                # "asynchronous" copy drain the stream on the host
+    table = table_host.to(device, non_blocking=True)
     out = torch.empty((len(images_uint8), 3, S, S), dtype=dtype, device=device)
     mean = (ctypes.c_float * 3)(*MEAN)
     std = (ctypes.c_float * 3)(*STD)
