@@ -39,6 +39,11 @@ SIGNATURES = {
                                c_void_p]),
     "acr_attn_bwd": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "acr_attn_scores_floats": (c_int64, [_P]),
+    "acr_attn_fwd_scores": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                      c_void_p]),
+    "acr_attn_bwd_scores": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                      c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acr_attn_probs": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acr_attn_dprobs": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acr_consistency_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),

@@ -628,6 +628,52 @@ extern "C" int acr_attn_bwd(const acr_attn_desc* d, const void* q, const void* k
     return attn_bwd_t<__bf16>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, gmean_st, dq, dk, dv, delta_ws, (hipStream_t)stream);
 }
 
+// ---- resident-score generation (fp32 only; attn_f32_sres.hip) ------------------------------------------------------------
+extern "C" int64_t acr_attn_scores_floats(const acr_attn_desc* d) {
+    if (d == nullptr || d->B <= 0 || d->H <= 0 || d->T <= 0) return 0;
+    const int64_t nb = (d->T + 31) / 32;
+    return (int64_t)d->B * d->H * nb * nb * 1024;
+}
+
+extern "C" int acr_attn_fwd_scores(const acr_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse2,
+                                   float* scores, float* pmean, int64_t pmean_sb, int64_t pmean_st, void* stream) {
+    int rc = check_desc(d, "acr_attn_fwd_scores");
+    if (rc) return rc;
+    if (d->dtype != ACR_F32) {
+        acr_set_error("acr_attn_fwd_scores: fp32 tensors only (the bf16 kernels recompute the logits)");
+        return ACR_ERR_UNSUPPORTED;
+    }
+    ACR_CHECK_ARG(q && k && v && o && lse2 && scores, "acr_attn_fwd_scores: null pointer");
+    ACR_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(scores),
+                  "acr_attn_fwd_scores: q/k/v/o/scores must be 16-byte aligned");
+    ACR_CHECK_ARG(!pmean || (pmean_st >= d->T && pmean_sb >= (int64_t)d->T * pmean_st),
+                  "acr_attn_fwd_scores: pmean row pitch < T or batch stride < T*pitch");
+    acr_attn_fwd_f32_sres(geom(d), (const float*)q, (const float*)k, (const float*)v, (float*)o, lse2, scores, pmean, pmean_sb,
+                          pmean_st, (hipStream_t)stream);
+    return acr_check_launch("acr_attn_fwd_scores");
+}
+
+extern "C" int acr_attn_bwd_scores(const acr_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
+                                   const void* d_o, const float* lse2, const float* scores, const float* gmean, int64_t gmean_sb,
+                                   int64_t gmean_st, void* dq, void* dk, void* dv, float* delta_ws, void* stream) {
+    int rc = check_desc(d, "acr_attn_bwd_scores");
+    if (rc) return rc;
+    if (d->dtype != ACR_F32) {
+        acr_set_error("acr_attn_bwd_scores: fp32 tensors only (the bf16 kernels recompute the logits)");
+        return ACR_ERR_UNSUPPORTED;
+    }
+    ACR_CHECK_ARG(q && k && v && o && d_o && lse2 && scores && dq && dk && dv && delta_ws, "acr_attn_bwd_scores: null pointer");
+    ACR_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(d_o) && aligned16(scores),
+                  "acr_attn_bwd_scores: inputs must be 16-byte aligned");
+    ACR_CHECK_ARG(!gmean || (gmean_st >= d->T && gmean_sb >= (int64_t)d->T * gmean_st),
+                  "acr_attn_bwd_scores: gmean row pitch < T or batch stride < T*pitch");
+    ACR_CHECK_ARG(!gmean || ((gmean_st & 3) == 0 && (gmean_sb & 3) == 0 && aligned16(gmean)),
+                  "acr_attn_bwd_scores: gmean must be 16-byte aligned with pitch and batch stride multiples of 4 floats");
+    acr_attn_bwd_f32_sres(geom(d), (const float*)q, (const float*)k, (const float*)v, (const float*)o, (const float*)d_o, lse2,
+                          scores, gmean, gmean_sb, gmean_st, (float*)dq, (float*)dk, (float*)dv, delta_ws, (hipStream_t)stream);
+    return acr_check_launch("acr_attn_bwd_scores");
+}
+
 extern "C" int acr_attn_probs(const acr_attn_desc* d, const void* q, const void* k, const float* lse2, float* probs,
                               void* stream) {
     int rc = check_desc(d, "acr_attn_probs");

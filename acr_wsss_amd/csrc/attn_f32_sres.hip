@@ -1,0 +1,540 @@
+// fp32 (reference precision) attention, third generation: RESIDENT SCORES.
+//
+// Why: on gfx950 the exact-fp32 MFMA runs at the fp32 vector rate (157 TF, 1/16 of bf16) while HBM3E moves 6+ TB/s, so the
+// ridge of the fp32 roofline is ~20 FLOP/byte -- and recomputing one logit S[i][j] = q_i . k_j costs 128 FLOP for 4 bytes
+// (32 FLOP/byte).  The recompute generation (attn_f32_dma.hip) executed 3 products forward (S, PV, S again for the head
+// mean) and 8 backward (S for the row term, S/dP/dQ, S/dP/dV/dK) for 2 + 4 algorithmic ones.  With 288 GB of HBM per GPU the
+// scaled logits of every layer fit many times over (983 MB per layer at B = 32 views, H = 12, T = 785; 11.8 GB per step),
+// so here the forward sweep stores them ONCE, in the MFMA accumulator layout it produces them in, and everything after it
+// streams them back instead of recomputing:
+//     forward   2 products  + 1 write of S          head-mean: one read of S (no MFMA)
+//     backward  5 products  (dP dQ | dP dV dK)       row term : one read of S and G (no MFMA), dQ / dK-dV: one read each
+// Numerics are those of the recompute generation bit for bit where the same expression is evaluated (S is the forward's own
+// k-ordered fp32 fmaf chain, P = exp2(S - lse2)); the head mean now averages exactly the P the forward used.
+//
+// Score layout ("scores", caller-owned, acr_attn_scores_floats(desc) floats): blocks of 32 keys x 32 queries,
+//     block(b, h, qb, kb) at ((((b*H + h)*NB + qb)*NB + kb) * 1024 floats,   NB = ceil(T / 32)
+// inside a block the 32x32 accumulator tile of v_mfma_f32_32x32x2_f32 as the forward holds it: lane (theta = query & 31, hh),
+// register reg <-> key kappa = (reg & 3) + 8 (reg >> 2) + 4 hh;  float offset = (reg >> 2)*256 + lane*4 + (reg & 3), so that one
+// global_store_dwordx4 per register quad writes 1 KB contiguously and the same-orientation readers (head mean, row term, dQ)
+// get their 16 registers back with four 16-byte loads.  The dK/dV sweep needs the transposed orientation (key on the lane):
+// it pulls its block by LDS-DMA with a chunk permutation on the source address, chunk ^ (2*quad + (chunk >> 5)), that makes
+// the transposed ds_read_b32 walk bank-conflict free.  Keys >= T hold -inf (the forward masks before it stores), queries
+// >= T hold finite junk and every reader gives those rows lse2 = +inf, i.e. P = 0.
+#include <type_traits>
+
+#include "acr_common.h"
+#include "attn_f32.h"
+#include "attn_f32_tiles.h"
+
+#define SB_FLOATS 1024
+
+__device__ __forceinline__ int64_t sres_block(const AttnGeom& g, int NB, int b, int hd, int qb, int kb) {
+    return ((((int64_t)b * g.H + hd) * NB + qb) * NB + kb) * SB_FLOATS;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: workgroup = (b, h, 128 queries), wave = 32 queries; K/V tiles of 32 keys stream through the two-slot LDS ring
+// (attn_fwd_dma_kernel's loop) and every 32 x 32 logit tile is written to `sres` before the softmax consumes it
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_sres_kernel(AttnGeom g, const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, float* __restrict__ o,
+                                                               float* __restrict__ lse2, float* __restrict__ sres) {
+    __shared__ __attribute__((aligned(1024))) float smem[4 * DT_FLOATS];       // [slot][K | V]
+    const int nqt = (g.T + 127) >> 7, NB = (g.T + 31) >> 5;
+    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = id % nqt; id /= nqt;
+    const int hd = id % g.H;
+    const int b = id / g.H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = qt * 128 + wave * 32;
+    const bool live = q0 < g.T;                            // wave-uniform: waves past the end only help with the DMA
+    const int64_t base = (int64_t)b * g.sb + (int64_t)hd * g.sh;
+    const float* kb = k + base;
+    const float* vb = v + base;
+    dma_tile32(smem, kb, g.st, 0, g.T, wave, lane);
+    dma_tile32(smem + DT_FLOATS, vb, g.st, 0, g.T, wave, lane);
+    float qreg[32];
+    rows_from_global(qreg, q + base, g.st, q0, g.T, r, h, g.scale * ACR_LOG2E);
+    float m = -INFINITY, l = 0.f;
+    f32x16 o0 = {0}, o1 = {0};
+    const LaneBases lb = lane_bases(r, h);
+    int doff[2];
+    dma_offsets32(doff, g.st, wave, lane);
+    const char* sm = reinterpret_cast<const char*>(smem);
+    float* sblk = sres + sres_block(g, NB, b, hd, min(q0 >> 5, NB - 1), 0) + lane * 4;
+    auto step = [&](int k0, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr int KOFF = SLOT * 2 * DT_FLOATS * 4, VOFF = KOFF + DT_FLOATS * 4;
+        acr_dma_barrier();                                 // slot SLOT has landed; the other slot is free
+        __builtin_amdgcn_s_setprio(2);
+        if (k0 + 64 <= g.T) {                              // next tile fully inside: precomputed lane offsets, uniform base
+            dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb + (int64_t)(k0 + 32) * g.st, doff, wave);
+            dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb + (int64_t)(k0 + 32) * g.st, doff, wave);
+        } else if (k0 + 32 < g.T) {                        // partial last tile: clamped rows
+            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb, g.st, k0 + 32, g.T, wave, lane);
+            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb, g.st, k0 + 32, g.T, wave, lane);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (!live) return;
+        f32x16 s = {0};
+        rowop_i<KOFF>(s, sm, lb, qreg);                    // s[reg] = S2[key = k0 + krow][query = q0 + r]
+        __builtin_amdgcn_s_setprio(2);
+        if (k0 + 32 > g.T) {                               // only the last key tile has keys beyond T (uniform branch)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                if (k0 + acr_krow(reg, h) >= g.T) s[reg] = -INFINITY;
+        }
+        float* sp = sblk + (int64_t)(k0 >> 5) * SB_FLOATS;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 t = {s[4 * gq], s[4 * gq + 1], s[4 * gq + 2], s[4 * gq + 3]};
+            *reinterpret_cast<f32x4*>(sp + gq * 256) = t;
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int reg = 1; reg < 16; ++reg) mx = fmaxf(mx, s[reg]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (__any(mx > m + 8.f)) {                         // deferred rescale (see attn_fwd_dma_kernel)
+            const float mn = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            l *= alpha;
+            o0 *= alpha; o1 *= alpha;
+            m = mn;
+        }
+        float rs = 0.f;
+        f32x16 p;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) { p[reg] = __builtin_amdgcn_exp2f(s[reg] - m); rs += p[reg]; }
+        rs += __shfl_xor(rs, 32);
+        l += rs;
+        __builtin_amdgcn_s_setprio(0);
+        accop_b_i<VOFF, 0>(o0, p, sm, lb);                 // o[reg] = O^T[d = 32*blk + krow][query = r]
+        accop_b_i<VOFF, 1>(o1, p, sm, lb);
+    };
+    for (int k0 = 0; k0 < g.T; k0 += 64) {
+        step(k0, std::integral_constant<int, 0>{});
+        if (k0 + 32 < g.T) step(k0 + 32, std::integral_constant<int, 1>{});
+    }
+    if (live && q0 + r < g.T) {
+        const float inv = 1.f / l;
+        float* ob = o + (int64_t)b * g.osb + (int64_t)(q0 + r) * g.ost + (int64_t)hd * g.osh;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            f32x4 a = {o0[4 * grp] * inv, o0[4 * grp + 1] * inv, o0[4 * grp + 2] * inv, o0[4 * grp + 3] * inv};
+            f32x4 c = {o1[4 * grp] * inv, o1[4 * grp + 1] * inv, o1[4 * grp + 2] * inv, o1[4 * grp + 3] * inv};
+            *reinterpret_cast<f32x4*>(ob + 8 * grp + 4 * h) = a;
+            *reinterpret_cast<f32x4*>(ob + 32 + 8 * grp + 4 * h) = c;
+        }
+        if (h == 0) lse2[((int64_t)b * g.H + hd) * g.T + q0 + r] = m + log2f(l);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// head mean of P (DPT/ACR.py:107-112) from the resident scores: HBM-bound stream, no MFMA.  One wave per (b, qb, kb) block:
+// for every head four 16-byte loads, P = exp2(S - lse2), summed in head order in registers (deterministic), transposed
+// through a private LDS tile so that the (T, T) map is written in 128-byte row segments.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_pmean_sres_kernel(AttnGeom g, int NB, const float* __restrict__ sres,
+                                                              const float* __restrict__ lse2, float* __restrict__ out,
+                                                              int64_t out_sb, int64_t out_st) {
+    __shared__ float tile[4][32 * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int theta = lane & 31, hh = lane >> 5;
+    const int nblk = g.B * NB * NB;
+    int id = blockIdx.x * 4 + wave;
+    const bool act = id < nblk;
+    id = min(id, nblk - 1);
+    const int kb = id % NB;
+    const int t = id / NB;
+    const int qb = t % NB, b = t / NB;
+    const int qrow = qb * 32 + theta;
+    const float* sp = sres + sres_block(g, NB, b, 0, qb, kb) + lane * 4;
+    const int64_t hstride = (int64_t)NB * NB * SB_FLOATS;
+    const float* lp = lse2 + (int64_t)b * g.H * g.T + min(qrow, g.T - 1);
+    f32x16 pm = {0};
+    for (int h0 = 0; h0 < g.H; h0 += 4) {                  // four heads (16 KB per wave) of loads in flight
+        f32x4 sv[4][4];
+        float lv[4];
+#pragma unroll
+        for (int hi = 0; hi < 4; ++hi) {
+            const int hd = min(h0 + hi, g.H - 1);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) sv[hi][gq] = *reinterpret_cast<const f32x4*>(sp + hd * hstride + gq * 256);
+            lv[hi] = lp[(int64_t)hd * g.T];
+        }
+#pragma unroll
+        for (int hi = 0; hi < 4; ++hi) {
+            if (h0 + hi < g.H) {
+                const float l2 = qrow < g.T ? lv[hi] : INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) pm[reg] += __builtin_amdgcn_exp2f(sv[hi][reg >> 2][reg & 3] - l2);
+            }
+        }
+    }
+    const float mul = 1.f / (float)g.H;
+    float* tl = tile[wave];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) tl[theta * 33 + acr_krow(reg, hh)] = pm[reg] * mul;
+    __syncthreads();
+    if (act) {
+        const int key = kb * 32 + theta;
+        float* ob = out + (int64_t)b * out_sb;
+        if (key < g.T) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 2 * i + hh;
+                const int qq = qb * 32 + row;
+                if (qq < g.T) ob[(int64_t)qq * out_st + key] = tl[row * 33 + theta];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// delta[b,h,i] = rowsum(dO*O) + (1/H) sum_j P_h[i,j] G[b,i,j] from the resident scores: HBM/L2-bound stream, no MFMA.  One
+// wave per (b, qb, h) (h fastest: the twelve heads that read the same 32 rows of G run next to each other); lane (theta, hh)
+// sums its 16 keys of every block in register order, the two lane halves are added at the end (deterministic).
+// G rows are read in 16-byte groups (pitch % 4 == 0, checked by the launcher); the partial last key block takes clamped
+// scalar loads (its masked keys have P = 0 exactly).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_sres_kernel(AttnGeom g, int NB, const float* __restrict__ sres,
+                                                              const float* __restrict__ o, const float* __restrict__ d_o,
+                                                              const float* __restrict__ lse2, const float* __restrict__ gm,
+                                                              int64_t gm_sb, int64_t gm_st, float* __restrict__ delta) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int theta = lane & 31, hh = lane >> 5;
+    int id = blockIdx.x * 4 + wave;
+    if (id >= g.B * NB * g.H) return;                      // no barriers below
+    const int hd = id % g.H;
+    const int t = id / g.H;
+    const int qb = t % NB, b = t / NB;
+    const int qrow = qb * 32 + theta;
+    const bool qok = qrow < g.T;
+    const int qc = min(qrow, g.T - 1);
+    float part = 0.f;
+    {
+        const int64_t off = (int64_t)b * g.osb + (int64_t)hd * g.osh + (int64_t)qc * g.ost + 32 * hh;
+        const float* op = o + off;
+        const float* dp = d_o + off;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(op + 4 * i), c = *reinterpret_cast<const f32x4*>(dp + 4 * i);
+            part += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+        }
+    }
+    part += __shfl_xor(part, 32);
+    float rho = 0.f;
+    if (gm != nullptr) {                                    // uniform over the launch
+        const float l2q = qok ? lse2[((int64_t)b * g.H + hd) * g.T + qrow] : INFINITY;
+        const float* sp = sres + sres_block(g, NB, b, hd, qb, 0) + lane * 4;
+        const float* gr = gm + (int64_t)b * gm_sb + (int64_t)qc * gm_st;
+        const int nfull = g.T >> 5;                        // key blocks entirely inside [0, T)
+#pragma unroll 2
+        for (int kb = 0; kb < nfull; ++kb) {
+            f32x4 sv[4], gv[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                sv[gq] = *reinterpret_cast<const f32x4*>(sp + (int64_t)kb * SB_FLOATS + gq * 256);
+                gv[gq] = *reinterpret_cast<const f32x4*>(gr + kb * 32 + 8 * gq + 4 * hh);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                rho = fmaf(__builtin_amdgcn_exp2f(sv[reg >> 2][reg & 3] - l2q), gv[reg >> 2][reg & 3], rho);
+        }
+        if (nfull < NB) {
+            const int k0 = nfull * 32;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(sp + (int64_t)nfull * SB_FLOATS + gq * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gv = gr[min(k0 + 8 * gq + 4 * hh + e, g.T - 1)];
+                    rho = fmaf(__builtin_amdgcn_exp2f(sv[e] - l2q), gv, rho);
+                }
+            }
+        }
+        rho += __shfl_xor(rho, 32);
+    }
+    if (hh == 0 && qok) delta[((int64_t)b * g.H + hd) * g.T + qrow] = part + rho * (1.f / (float)g.H);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dQ: workgroup = (b, h, 128 queries); dO rows of the wave's 32 queries in registers; K/V tiles stream through the LDS ring;
+// the wave's score block and its G rows for the NEXT step are in flight (registers) while this step's MFMAs run.
+//   dP^T = V dO^T (32 MFMAs)   dS^T = exp2(S - lse2) (dP^T + G/H - delta)   dQ += dS K (32 MFMAs)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk, const AttnGeom& g, const float* __restrict__ k,
+                                                  const float* __restrict__ v, const float* __restrict__ d_o,
+                                                  const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                  const float* __restrict__ sres, const float* __restrict__ gm, int64_t gm_sb,
+                                                  int64_t gm_st, float* __restrict__ dq) {
+    const int nqt = (g.T + 127) >> 7, NB = (g.T + 31) >> 5;
+    int id = acr_xcd_remap(bid, nblk);
+    const int qt = id % nqt; id /= nqt;
+    const int hd = id % g.H;
+    const int b = id / g.H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = qt * 128 + wave * 32;
+    const bool live = q0 < g.T;
+    const int64_t base = (int64_t)b * g.sb + (int64_t)hd * g.sh;
+    const int64_t obase = (int64_t)b * g.osb + (int64_t)hd * g.osh;
+    const float* kb = k + base;
+    const float* vb = v + base;
+    dma_tile32(smem, kb, g.st, 0, g.T, wave, lane);
+    dma_tile32(smem + DT_FLOATS, vb, g.st, 0, g.T, wave, lane);
+    float doreg[32];
+    rows_from_global(doreg, d_o + obase, g.ost, q0, g.T, r, h, 1.f);
+    const bool qok = q0 + r < g.T;
+    const float l2q = qok ? lse2[((int64_t)b * g.H + hd) * g.T + q0 + r] : INFINITY;    // queries beyond T: p = exp2(-inf) = 0
+    const float dl = qok ? delta[((int64_t)b * g.H + hd) * g.T + q0 + r] : 0.f;
+    const float invH = 1.f / (float)g.H;
+    const float* grow = gm ? gm + (int64_t)b * gm_sb + (int64_t)min(q0 + r, g.T - 1) * gm_st : nullptr;
+    const float* sblk = sres + sres_block(g, NB, b, hd, min(q0 >> 5, NB - 1), 0) + lane * 4;
+    f32x16 dq0 = {0}, dq1 = {0};
+    const LaneBases lb = lane_bases(r, h);
+    int doff[2];
+    dma_offsets32(doff, g.st, wave, lane);
+    const char* sm = reinterpret_cast<const char*>(smem);
+    f32x4 sbuf[2][4], gbuf[2][4];                          // [ring slot][register quad]
+    auto load_sg = [&](int k0, f32x4 (&s4)[4], f32x4 (&g4)[4]) {
+        const float* sp = sblk + (int64_t)(k0 >> 5) * SB_FLOATS;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) s4[gq] = *reinterpret_cast<const f32x4*>(sp + gq * 256);
+        if (grow == nullptr) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) g4[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if (k0 + 32 <= g.T) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) g4[gq] = *reinterpret_cast<const f32x4*>(grow + k0 + 8 * gq + 4 * h);
+        } else {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g4[gq][e] = grow[min(k0 + 8 * gq + 4 * h + e, g.T - 1)];
+        }
+    };
+    if (live) load_sg(0, sbuf[0], gbuf[0]);
+    auto step = [&](int k0, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr int KOFF = SLOT * 2 * DT_FLOATS * 4, VOFF = KOFF + DT_FLOATS * 4;
+        acr_dma_barrier();
+        __builtin_amdgcn_s_setprio(2);
+        if (k0 + 64 <= g.T) {
+            dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb + (int64_t)(k0 + 32) * g.st, doff, wave);
+            dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb + (int64_t)(k0 + 32) * g.st, doff, wave);
+        } else if (k0 + 32 < g.T) {
+            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb, g.st, k0 + 32, g.T, wave, lane);
+            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb, g.st, k0 + 32, g.T, wave, lane);
+        }
+        if (!live) { __builtin_amdgcn_s_setprio(0); return; }
+        if (k0 + 32 < g.T) load_sg(k0 + 32, sbuf[SLOT ^ 1], gbuf[SLOT ^ 1]);
+        __builtin_amdgcn_s_setprio(0);
+        f32x16 dp = {0};
+        rowop_i<VOFF>(dp, sm, lb, doreg);                  // dP^T[key = krow][query = r]
+        f32x16 ds;
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const float gv = gbuf[SLOT][reg >> 2][reg & 3] * invH;
+            ds[reg] = __builtin_amdgcn_exp2f(sbuf[SLOT][reg >> 2][reg & 3] - l2q) * (dp[reg] + gv - dl);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        accop_a_i<KOFF, 0>(dq0, ds, sm, lb);               // dQ[query = krow][d = 32*blk + r]
+        accop_a_i<KOFF, 1>(dq1, ds, sm, lb);
+    };
+    for (int k0 = 0; k0 < g.T; k0 += 64) {
+        step(k0, std::integral_constant<int, 0>{});
+        if (k0 + 32 < g.T) step(k0 + 32, std::integral_constant<int, 1>{});
+    }
+    if (!live) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int qq = q0 + acr_krow(reg, h);
+        if (qq < g.T) {
+            float* p = dq + base + (int64_t)qq * g.st;
+            p[r] = dq0[reg] * g.scale;
+            p[32 + r] = dq1[reg] * g.scale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dK, dV: workgroup = (b, h, 128 keys); V rows of the wave's 32 keys in registers; Q / dO tiles (and the 32 queries' lse2 /
+// delta, one 256-byte DMA) stream through the shared ring; every wave also streams ITS score blocks (q-block j x its key
+// block) by LDS-DMA into a private two-slot ring and reads them transposed (key on the lane).
+//   dP = dO V^T (32 MFMAs)   P = exp2(S - lse2)   dS = P (dP + G/H - delta)   dV += P^T dO (32)   dK += dS^T Q (32)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, float* rc, int bid, int nblk, const AttnGeom& g,
+                                                    const float* __restrict__ q, const float* __restrict__ v,
+                                                    const float* __restrict__ d_o, const float* __restrict__ lse2,
+                                                    const float* __restrict__ delta, const float* __restrict__ sres,
+                                                    const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
+                                                    float* __restrict__ dk, float* __restrict__ dv) {
+    const int nkt = (g.T + 127) >> 7, NB = (g.T + 31) >> 5;
+    int id = acr_xcd_remap(bid, nblk);
+    const int ktile = id % nkt; id /= nkt;
+    const int hd = id % g.H;
+    const int b = id / g.H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int key0 = ktile * 128 + wave * 32;
+    const bool live = key0 < g.T;
+    const int64_t base = (int64_t)b * g.sb + (int64_t)hd * g.sh;
+    const int64_t obase = (int64_t)b * g.osb + (int64_t)hd * g.osh;
+    const float* qb = q + base;
+    const float* dob = d_o + obase;
+    const float* lrow = lse2 + ((int64_t)b * g.H + hd) * g.T;
+    const float* drow = delta + ((int64_t)b * g.H + hd) * g.T;
+    // score blocks of this wave: (qb = step, kb = key0 / 32); lane c of DMA piece gq fetches global chunk c ^ (2 gq + (c >> 5))
+    const float* scol = sres + sres_block(g, NB, b, hd, 0, min(key0 >> 5, NB - 1));
+    const int64_t sstep = (int64_t)NB * SB_FLOATS;
+    int soff[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) soff[gq] = gq * 256 + 4 * (lane ^ (2 * gq + (lane >> 5)));
+    float* sw = ssm + wave * 2 * SB_FLOATS;
+    auto dma_scores = [&](int qblk, int slot) {
+        const float* src = scol + (int64_t)qblk * sstep;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            __builtin_amdgcn_global_load_lds((glb_vp)(src + soff[gq]), (lds_vp)(sw + slot * SB_FLOATS + gq * 256), 16, 0, 0);
+    };
+    dma_tile32(smem, qb, g.st, 0, g.T, wave, lane);
+    dma_tile32(smem + DT_FLOATS, dob, g.ost, 0, g.T, wave, lane);
+    if (wave == 0) dma_rowconst(rc, lrow, drow, 0, g.T, lane);
+    if (live) dma_scores(0, 0);
+    float vreg[32];
+    rows_from_global(vreg, v + base, g.st, key0, g.T, r, h, 1.f);
+    const int key = key0 + r;
+    const float invH = 1.f / (float)g.H;
+    const float* gb0 = gm ? gm + (int64_t)b * gm_sb : nullptr;          // uniform
+    const int glane = min(key, g.T - 1) + 4 * h * (int)gm_st;            // lane part of a G address (krow = c_reg + 4h)
+    const int gcl = min(key, g.T - 1);
+    f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+    const LaneBases lb = lane_bases(r, h);
+    const char* sm = reinterpret_cast<const char*>(smem);
+    // transposed score reads: lane (kappa = r, h): byte address = tb[reg & 3] + slot*4096 + 128*(reg >> 2)
+    int tb[4];
+    {
+        const int gk = r >> 3, hk = (r >> 2) & 1, ek = r & 3, mm = 2 * gk + hk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tb[j] = ((wave * 2 * SB_FLOATS) + gk * 256 + 128 * hk + ek + 4 * ((j + 4 * h) ^ mm)) * 4;
+    }
+    const char* ssb = reinterpret_cast<const char*>(ssm);
+    auto step = [&](int q0, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr int QOFF = SLOT * 2 * DT_FLOATS * 4, DOOFF = QOFF + DT_FLOATS * 4;
+        acr_dma_barrier();
+        __builtin_amdgcn_s_setprio(2);
+        if (q0 + 32 < g.T) {
+            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS, qb, g.st, q0 + 32, g.T, wave, lane);
+            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, dob, g.ost, q0 + 32, g.T, wave, lane);
+            if (wave == 0) dma_rowconst(rc + (SLOT ^ 1) * 64, lrow, drow, q0 + 32, g.T, lane);
+            if (live) dma_scores((q0 >> 5) + 1, SLOT ^ 1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (!live) return;
+        const float* rcs = rc + SLOT * 64;
+        float gv[16];
+        if (gb0 == nullptr) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = 0.f;
+        } else if (q0 + 32 <= g.T) {                       // uniform row pointer + lane offset (saddr form loads)
+            const float* gq0 = gb0 + (int64_t)q0 * gm_st;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int c_reg = (reg & 3) + 8 * (reg >> 2);
+                gv[reg] = (gq0 + (int64_t)c_reg * gm_st)[glane] * invH;
+            }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = gb0[(int64_t)min(q0 + acr_krow(reg, h), g.T - 1) * gm_st + gcl] * invH;
+        }
+        f32x16 dp = {0};
+        rowop_i<DOOFF>(dp, sm, lb, vreg);                  // dP[query = krow][key = r]
+        f32x16 s;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            s[reg] = *reinterpret_cast<const float*>(ssb + tb[reg & 3] + (SLOT * SB_FLOATS * 4 + 128 * (reg >> 2)));
+        if (q0 + 32 > g.T) {                               // last query block: rows beyond T are junk, P = 0 there
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                if (q0 + acr_krow(reg, h) >= g.T) s[reg] = -INFINITY;
+        }
+        f32x16 p, ds;
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int kr = acr_krow(reg, h);
+            const float pv = __builtin_amdgcn_exp2f(s[reg] - rcs[kr]);
+            p[reg] = pv;
+            ds[reg] = pv * (dp[reg] + gv[reg] - rcs[32 + kr]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        accop_a_i<DOOFF, 0>(dv0, p, sm, lb);               // dV[key = krow][d = 32*blk + r]
+        accop_a_i<DOOFF, 1>(dv1, p, sm, lb);
+        accop_a_i<QOFF, 0>(dk0, ds, sm, lb);
+        accop_a_i<QOFF, 1>(dk1, ds, sm, lb);
+    };
+    for (int q0 = 0; q0 < g.T; q0 += 64) {
+        step(q0, std::integral_constant<int, 0>{});
+        if (q0 + 32 < g.T) step(q0 + 32, std::integral_constant<int, 1>{});
+    }
+    if (!live) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int kk = key0 + acr_krow(reg, h);
+        if (kk < g.T) {
+            float* pk = dk + base + (int64_t)kk * g.st;
+            float* pv = dv + base + (int64_t)kk * g.st;
+            pk[r] = dk0[reg] * g.scale;
+            pk[32 + r] = dk1[reg] * g.scale;
+            pv[r] = dv0[reg];
+            pv[32 + r] = dv1[reg];
+        }
+    }
+}
+
+// dK/dV and dQ in ONE launch (one partly filled last round instead of two): first half of the grid dK/dV, second half dQ.
+__global__ __launch_bounds__(256, 2) void attn_bwd_sres_kernel(AttnGeom g, const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, const float* __restrict__ d_o,
+                                                               const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                               const float* __restrict__ sres, const float* __restrict__ gm,
+                                                               int64_t gm_sb, int64_t gm_st, float* __restrict__ dq,
+                                                               float* __restrict__ dk, float* __restrict__ dv) {
+    __shared__ __attribute__((aligned(1024))) float smem[4 * DT_FLOATS];       // [slot][Q | dO]  resp.  [slot][K | V]
+    __shared__ __attribute__((aligned(1024))) float ssm[4 * 2 * SB_FLOATS];    // dK/dV: [wave][slot] score blocks
+    __shared__ __attribute__((aligned(256))) float rc[2 * 64];                 // dK/dV: [slot][lse2 x 32 | delta x 32]
+    const int half = gridDim.x >> 1;
+    if ((int)blockIdx.x < half)
+        attn_dkdv_sres_body(smem, ssm, rc, blockIdx.x, half, g, q, v, d_o, lse2, delta, sres, gm, gm_sb, gm_st, dk, dv);
+    else
+        attn_dq_sres_body(smem, blockIdx.x - half, half, g, k, v, d_o, lse2, delta, sres, gm, gm_sb, gm_st, dq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (called from attn_f32.hip)
+// ---------------------------------------------------------------------------------------------
+void acr_attn_fwd_f32_sres(const AttnGeom& g, const float* q, const float* k, const float* v, float* o, float* lse2, float* scores,
+                           float* pmean, int64_t pmean_sb, int64_t pmean_st, hipStream_t st) {
+    const int nt = (g.T + 127) / 128, NB = (g.T + 31) / 32;
+    hipLaunchKernelGGL(attn_fwd_sres_kernel, dim3(g.B * g.H * nt), dim3(256), 0, st, g, q, k, v, o, lse2, scores);
+    if (pmean)
+        hipLaunchKernelGGL(attn_pmean_sres_kernel, dim3((g.B * NB * NB + 3) / 4), dim3(256), 0, st, g, NB, (const float*)scores,
+                           (const float*)lse2, pmean, pmean_sb, pmean_st);
+}
+
+void acr_attn_bwd_f32_sres(const AttnGeom& g, const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                           const float* lse2, const float* scores, const float* gm, int64_t gm_sb, int64_t gm_st, float* dq,
+                           float* dk, float* dv, float* delta, hipStream_t st) {
+    const int nt = (g.T + 127) / 128, NB = (g.T + 31) / 32;
+    hipLaunchKernelGGL(attn_delta_sres_kernel, dim3((g.B * NB * g.H + 3) / 4), dim3(256), 0, st, g, NB, scores, o, d_o, lse2, gm,
+                       gm_sb, gm_st, delta);
+    hipLaunchKernelGGL(attn_bwd_sres_kernel, dim3(2 * g.B * g.H * nt), dim3(256), 0, st, g, q, k, v, d_o, lse2, (const float*)delta,
+                       scores, gm, gm_sb, gm_st, dq, dk, dv);
+}

@@ -22,10 +22,23 @@ class _Bucket:
 
 
 class GradSync:
-    def __init__(self, params, process_group=None, bucket_mb=64):
+    """Bucketed gradient all-reduce overlapped with backward.
+
+    Collective sequences are identical on every rank BY CONSTRUCTION, whatever each rank's autograd graph does:
+      * buckets are exchanged in index order only (a bucket whose gradients are complete waits for its predecessors; backward
+        fills them in that order anyway), each exactly once, the stragglers from ``finish()`` in the same order;
+      * which parameters are not waited for next step (no gradient this step) and which buckets need a late re-exchange are
+        agreed collectively: one tiny host-side all-reduce per step (a gloo side group beside RCCL: no device
+        synchronisation), so a parameter that receives a gradient on some ranks only costs overlap, never a hang.
+    ``strict=True`` (or ACR_DP_STRICT=1) turns any disagreement between ranks into an error instead."""
+
+    def __init__(self, params, process_group=None, bucket_mb=64, strict=None):
+        import os
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in params if p.requires_grad]
+        self._params = params
+        self._pidx = {p: i for i, p in enumerate(params)}
         cap = int(bucket_mb * (1 << 20))
         groups, cur, cur_bytes = [], [], 0
         for p in reversed(params):                         # ~ order in which backward produces gradients
@@ -55,13 +68,29 @@ class GradSync:
             b.index = len(self.buckets)
             self.buckets.append(b)
         self._armed = False
-        # Parameters that got no gradient in the previous step (the reference model has 9 such tensors: bkg_token, norm.*,
-        # head.*, scratch.*) are not waited for: otherwise the bucket they share -- the FIRST one backward fills,
-        # the one with the most overlap to gain -- could only be launched from finish(), after backward.
+        self._next = 0                                    # index of the next bucket to exchange (canonical order)
+        # Parameters that got no gradient on ANY rank in the previous step (the reference model has 9 such tensors:
+        # bkg_token, norm.*, head.*, scratch.*) are not waited for: otherwise the bucket they share -- the FIRST
+        # one backward fills, the one with the most overlap to gain -- could only be launched from finish(), after backward.
         self._unused = set()
         self.launch_log = []                              # (bucket index, "backward" | "finish") of the last step
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        self.backend = backend
         self._avg = backend == "nccl"                     # RCCL has a native AVG; gloo does not
+        self.strict = (os.environ.get("ACR_DP_STRICT") == "1") if strict is None else bool(strict)
+        # host-side agreement channel: the data group itself when it is gloo, else a gloo group over the same ranks
+        self._side = None
+        if self.world > 1:
+            self._side = process_group if backend == "gloo" else dist.new_group(
+                ranks=dist.get_process_group_ranks(process_group) if process_group is not None else None, backend="gloo")
+        self.stats = {"steps": 0, "bucket_launches_in_backward": 0, "bucket_launches_in_finish": 0, "late_reexchanges": 0,
+                      "rank_disagreements": 0}
+
+    def describe(self):
+        """What bench.py reports about the exchange (sizes in MB per bucket, launch counters so far)."""
+        return {"buckets": len(self.buckets),
+                "bucket_mb": [round(b.flat.numel() * b.flat.element_size() / 2 ** 20, 1) for b in self.buckets],
+                "unused_parameters": len(self._unused), **self.stats}
 
     def prepare(self):
         """Call after zero_grad and before backward.  Gradients are left to autograd (``.grad = None``: the engine then
@@ -73,10 +102,12 @@ class GradSync:
             for p in b.params:
                 p.grad = None
         self.launch_log = []
+        self._next = 0
         self._armed = True
 
     def _launch(self, b, where="backward"):
         self.launch_log.append((b.index, where))
+        self.stats["bucket_launches_in_" + where] += 1
         live = [(v, p.grad) for p, v in zip(b.params, b.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if live:
             torch._foreach_copy_([v for v, _ in live], [g for _, g in live])
@@ -89,6 +120,11 @@ class GradSync:
         else:
             b.work = False
 
+    def _launch_ready(self):
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
+
     def _hook(self, p):
         if not self._armed:
             return
@@ -99,29 +135,52 @@ class GradSync:
                 b.late = True
             return
         b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        self._launch_ready()
+
+    def _wait(self, b):
+        if b.work:
+            b.work.wait()
+            if not self._avg:
+                b.flat.div_(self.world)
 
     def finish(self):
-        """Call after backward: launch buckets whose parameters got no gradient (the reference's 9 unused
-        tensors), wait for every collective, and turn sums into means."""
+        """Call after backward: exchange the buckets backward could not complete (in index order), agree with the other
+        ranks on late buckets and on the parameters nobody produced a gradient for, re-exchange the late buckets, wait for
+        every collective and turn sums into means."""
+        while self._next < len(self.buckets):
+            self._launch(self.buckets[self._next], "finish")
+            self._next += 1
+        nb, npar = len(self.buckets), len(self._params)
+        late = [b.late for b in self.buckets]
+        nograd = [p.grad is None for p in self._params]
+        if self._side is not None:
+            # one small host-side exchange: flags[0:nb] = late (OR over ranks), then per parameter "has a gradient" on ANY rank
+            # (OR) and on EVERY rank (AND, sent negated)
+            flags = torch.tensor([float(x) for x in late] + [float(not x) for x in nograd] + [float(x) for x in nograd],
+                                 dtype=torch.float32)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._side)
+            any_late = [bool(v) for v in flags[:nb].tolist()]
+            any_grad = [bool(v) for v in flags[nb:nb + npar].tolist()]
+            any_nograd = [bool(v) for v in flags[nb + npar:].tolist()]
+            disagree = sum(1 for a, n in zip(any_grad, any_nograd) if a and n) + sum(1 for a, l in zip(any_late, late) if a != l)
+            if disagree:
+                self.stats["rank_disagreements"] += 1
+                if self.strict:
+                    raise RuntimeError("GradSync: ranks disagree on gradient presence for %d parameter(s)/bucket(s) this step "
+                                       "(data-dependent graph?); the exchange itself stays consistent -- unset ACR_DP_STRICT "
+                                       "to run on" % disagree)
+            late = any_late
+            nograd = [not a for a in any_grad]
         for b in self.buckets:
-            if b.work is None:
-                self._launch(b, "finish")
-        for b in self.buckets:
-            if b.work:
-                b.work.wait()
-                if not self._avg:
-                    b.flat.div_(self.world)
-            if b.late:                                    # a parameter thought unused produced a gradient after the launch:
-                b.work = None                             # every rank holds the same averaged values, so averaging the
-                self._launch(b, "finish")                 # bucket again only adds the late gradient's exchange
-                if b.work:
-                    b.work.wait()
-                    if not self._avg:
-                        b.flat.div_(self.world)
+            self._wait(b)
+            if late[b.index]:                             # a parameter thought unused produced a gradient (on some rank) after
+                b.work = None                             # the launch: every rank holds the same averaged values, so averaging
+                self._launch(b, "finish")                 # the bucket again only adds the late gradient's exchange
+                self.stats["late_reexchanges"] += 1
+                self._wait(b)
         # re-learned every step: a tensor that stops (or starts) receiving gradients costs one late exchange, once
-        self._unused = {p for b in self.buckets for p in b.params if p.grad is None}
+        self._unused = {p for p, n in zip(self._params, nograd) if n}
+        self.stats["steps"] += 1
         self._armed = False
 
 

@@ -10,6 +10,9 @@ from torch.autograd import Function
 from . import _lib as L
 
 HEAD_DIM = 64
+# fp32 attention with a backward keeps its logits resident in HBM (csrc/attn_f32_sres.hip); ACR_ATTN_F32_SCORES=0 selects the
+# recompute generation (csrc/attn_f32_dma.hip) for A/B runs
+ATTN_F32_SCORES = os.environ.get("ACR_ATTN_F32_SCORES", "1") != "0"
 
 
 def pad4(n):
@@ -112,12 +115,25 @@ class AttnCoreFn(Function):
         if stack is not None:
             pm = stack.buf[:, layer]
         qp, kp, vp = _qkv_ptrs(qkv, heads)
+        # fp32 with a backward to come: keep the scaled logits resident (983 MB per layer at 32 views x 12 heads x 785 tokens;
+        # the card has 288 GB) -- the head mean and the backward sweeps stream them back instead of recomputing q.k on the
+        # fp32 MFMA (csrc/attn_f32_sres.hip)
+        scores = None
+        if ATTN_F32_SCORES and qkv.dtype == torch.float32 and ctx.needs_input_grad[0]:
+            scores = torch.empty(lib.acr_attn_scores_floats(d), dtype=torch.float32, device=qkv.device)
         tok = _t0("attn_fwd" if pm is not None else "attn_fwd_nomean", B, heads, T)
-        L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm),
-                                 pm.stride(0) if pm is not None else 0, pm.stride(1) if pm is not None else 0,
-                                 L.stream_ptr()), "acr_attn_fwd")
+        pm_sb, pm_st = (pm.stride(0), pm.stride(1)) if pm is not None else (0, 0)
+        if scores is not None:
+            L.check(lib.acr_attn_fwd_scores(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(scores), L.ptr(pm), pm_sb, pm_st,
+                                            L.stream_ptr()), "acr_attn_fwd_scores")
+        else:
+            L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm), pm_sb, pm_st, L.stream_ptr()),
+                    "acr_attn_fwd")
         _t1(tok)
-        ctx.save_for_backward(qkv, o, lse2)
+        if scores is not None:
+            ctx.save_for_backward(qkv, o, lse2, scores)
+        else:
+            ctx.save_for_backward(qkv, o, lse2)
         ctx.heads = heads
         # the state API (get_attn / get_attn_gradients / getam) needs q, k, lse2 and later dO; in training mode nobody reads
         # it and keeping it would pin qkv + dO of all 12 layers between steps (2.8 GB at B = 32 views in fp32), so it is
@@ -133,7 +149,9 @@ class AttnCoreFn(Function):
 
     @staticmethod
     def backward(ctx, d_o, g_pm):
-        qkv, o, lse2 = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        qkv, o, lse2 = saved[:3]
+        scores = saved[3] if len(saved) > 3 else None
         heads = ctx.heads
         B, T, _ = qkv.shape
         lib = L.load()
@@ -160,8 +178,12 @@ class AttnCoreFn(Function):
         qp, kp, vp = _qkv_ptrs(qkv, heads)
         dqp, dkp, dvp = _qkv_ptrs(dqkv, heads)
         tok = _t0("attn_bwd" if g_pm is not None else "attn_bwd_nomean", B, heads, T)
-        L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(g_pm), gm_sb, gm_st,
-                                 dqp, dkp, dvp, L.ptr(delta), L.stream_ptr()), "acr_attn_bwd")
+        if scores is not None:
+            L.check(lib.acr_attn_bwd_scores(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(scores), L.ptr(g_pm), gm_sb,
+                                            gm_st, dqp, dkp, dvp, L.ptr(delta), L.stream_ptr()), "acr_attn_bwd_scores")
+        else:
+            L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(g_pm), gm_sb, gm_st,
+                                     dqp, dkp, dvp, L.ptr(delta), L.stream_ptr()), "acr_attn_bwd")
         _t1(tok)
         if ctx.owner is not None:
             ctx.owner._saved_do = d_o

@@ -96,6 +96,24 @@ int acr_attn_bwd(const acr_attn_desc* desc, const void* q, const void* k, const 
                  const float* gmean, int64_t gmean_sb, int64_t gmean_st,
                  void* dq, void* dk, void* dv, float* delta_ws, void* stream);
 
+/* ---- the same attention with RESIDENT SCORES (fp32 tensors only; acr_wsss_amd/csrc/attn_f32_sres.hip) ----
+ * The exact-fp32 MFMA runs at the fp32 vector rate (157 TF) while HBM moves 6+ TB/s: recomputing a logit (128 FLOP per 4
+ * bytes) costs more than reading it back.  acr_attn_fwd_scores computes exactly what acr_attn_fwd computes and additionally
+ * stores the scaled base-2 logits s2 of every (b, h) ONCE into `scores` (caller-owned, acr_attn_scores_floats(desc) floats,
+ * 16-byte aligned; opaque blocked layout: 32 x 32 tiles in MFMA accumulator order, keys >= T hold -inf).  The head mean
+ * (pmean, as in acr_attn_fwd) is then a stream over `scores`, and acr_attn_bwd_scores -- same contract as acr_attn_bwd plus
+ * the `scores` of the matching forward call -- runs 5 matrix products instead of 8.  gmean additionally has to be 16-byte
+ * aligned with row pitch and batch stride multiples of 4 floats.  Replaces the same reference lines as acr_attn_fwd /
+ * acr_attn_bwd (models/vision_transformer.py:203-211 and its autograd backward; there P itself, (B,H,T,T), is what stays
+ * resident between forward and backward). */
+int64_t acr_attn_scores_floats(const acr_attn_desc* desc);
+int acr_attn_fwd_scores(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
+                        void* o, float* lse2, float* scores, float* pmean, int64_t pmean_sb, int64_t pmean_st, void* stream);
+int acr_attn_bwd_scores(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
+                        const void* o, const void* d_o, const float* lse2, const float* scores,
+                        const float* gmean, int64_t gmean_sb, int64_t gmean_st,
+                        void* dq, void* dk, void* dv, float* delta_ws, void* stream);
+
 /* Materialise per-head maps for API compatibility with `Attention.get_attn()` /
  * `get_attn_gradients()` (vision_transformer.py:186-196): probs -> P (B,H,T,T) fp32 contiguous,
  * dprobs -> dO V^T (B,H,T,T) fp32 contiguous.  Not used by the fused training / GETAM paths. */

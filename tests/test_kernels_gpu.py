@@ -62,8 +62,12 @@ def test_consistency(B, L, p):
 @pytest.mark.parametrize("B,T,H", [(2, 2, 1), (1, 17, 12), (2, 197, 3), (1, 785, 12), (1, 1025, 2),
                                    (1, 2305, 3), (1, 3137, 1)])          # multi-scale inference: 768^2 and 896^2
 @pytest.mark.parametrize("with_g", [True, False])
-def test_attention_f32(B, T, H, with_g):
+@pytest.mark.parametrize("gen", ["scores", "recompute"])
+def test_attention_f32(B, T, H, with_g, gen, monkeypatch):
+    """Both fp32 generations (resident scores: csrc/attn_f32_sres.hip, the default; recompute: csrc/attn_f32_dma.hip) against
+    fp64 math of models/vision_transformer.py:203-211 + the head mean of DPT/ACR.py:107-112."""
     from acr_wsss_amd import ops
+    monkeypatch.setattr(ops, "ATTN_F32_SCORES", gen == "scores")
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(T * 3 + H)
     qkv = (1.5 * torch.randn(B, T, 3 * H * 64, generator=g)).to(dev).requires_grad_(True)
