@@ -37,11 +37,12 @@ __device__ __forceinline__ int64_t sres_block(const AttnGeom& g, int NB, int b, 
 // forward: workgroup = (b, h, 128 queries), wave = 32 queries; K/V tiles of 32 keys stream through the two-slot LDS ring
 // (attn_fwd_dma_kernel's loop) and every 32 x 32 logit tile is written to `sres` before the softmax consumes it
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_sres_kernel(AttnGeom g, const float* __restrict__ q, const float* __restrict__ k,
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_sres_kernel(AttnGeom g, const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, float* __restrict__ o,
                                                                float* __restrict__ lse2, float* __restrict__ sres) {
     __shared__ __attribute__((aligned(1024))) float smem[4 * DT_FLOATS];       // [slot][K | V]
-    const int nqt = (g.T + 127) >> 7, NB = (g.T + 31) >> 5;
+    const int NB = (g.T + 31) >> 5, nqt = (NB + NW - 1) / NW;
     int id = acr_xcd_remap(blockIdx.x, gridDim.x);
     const int qt = id % nqt; id /= nqt;
     const int hd = id % g.H;
@@ -49,20 +50,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_sres_kernel(AttnGeom g, const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int q0 = qt * 128 + wave * 32;
+    const int q0 = (qt * NW + wave) * 32;
     const bool live = q0 < g.T;                            // wave-uniform: waves past the end only help with the DMA
     const int64_t base = (int64_t)b * g.sb + (int64_t)hd * g.sh;
     const float* kb = k + base;
     const float* vb = v + base;
-    dma_tile32(smem, kb, g.st, 0, g.T, wave, lane);
-    dma_tile32(smem + DT_FLOATS, vb, g.st, 0, g.T, wave, lane);
+    dma_tile32_nw<NW>(smem, kb, g.st, 0, g.T, wave, lane);
+    dma_tile32_nw<NW>(smem + DT_FLOATS, vb, g.st, 0, g.T, wave, lane);
     float qreg[32];
     rows_from_global(qreg, q + base, g.st, q0, g.T, r, h, g.scale * ACR_LOG2E);
     float m = -INFINITY, l = 0.f;
     f32x16 o0 = {0}, o1 = {0};
     const LaneBases lb = lane_bases(r, h);
-    int doff[2];
-    dma_offsets32(doff, g.st, wave, lane);
+    int doff[(8 + NW - 1) / NW];
+    dma_offsets32_nw<NW>(doff, g.st, wave, lane);
     const char* sm = reinterpret_cast<const char*>(smem);
     float* sblk = sres + sres_block(g, NB, b, hd, min(q0 >> 5, NB - 1), 0) + lane * 4;
     auto step = [&](int k0, auto slot_tag) {
@@ -71,11 +72,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_sres_kernel(AttnGeom g, const
         acr_dma_barrier();                                 // slot SLOT has landed; the other slot is free
         __builtin_amdgcn_s_setprio(2);
         if (k0 + 64 <= g.T) {                              // next tile fully inside: precomputed lane offsets, uniform base
-            dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb + (int64_t)(k0 + 32) * g.st, doff, wave);
-            dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb + (int64_t)(k0 + 32) * g.st, doff, wave);
+            dma_tile32_nw_i<NW>(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb + (int64_t)(k0 + 32) * g.st, doff, wave);
+            dma_tile32_nw_i<NW>(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb + (int64_t)(k0 + 32) * g.st, doff, wave);
         } else if (k0 + 32 < g.T) {                        // partial last tile: clamped rows
-            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb, g.st, k0 + 32, g.T, wave, lane);
-            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb, g.st, k0 + 32, g.T, wave, lane);
+            dma_tile32_nw<NW>(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb, g.st, k0 + 32, g.T, wave, lane);
+            dma_tile32_nw<NW>(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb, g.st, k0 + 32, g.T, wave, lane);
         }
         __builtin_amdgcn_s_setprio(0);
         if (!live) return;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_delta_sres_kernel(AttnGeom g, int NB
         const float* sp = sres + sres_block(g, NB, b, hd, qb, 0) + lane * 4;
         const float* gr = gm + (int64_t)b * gm_sb + (int64_t)qc * gm_st;
         const int nfull = g.T >> 5;                        // key blocks entirely inside [0, T)
-#pragma unroll 2
+#pragma unroll 4
         for (int kb = 0; kb < nfull; ++kb) {
             f32x4 sv[4], gv[4];
 #pragma unroll
@@ -469,11 +470,16 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         f32x16 p, ds;
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int kr = acr_krow(reg, h);
-            const float pv = __builtin_amdgcn_exp2f(s[reg] - rcs[kr]);
-            p[reg] = pv;
-            ds[reg] = pv * (dp[reg] + gv[reg] - rcs[32 + kr]);
+        for (int gq = 0; gq < 4; ++gq) {                   // krow(4 gq + e, h) = 8 gq + 4 h + e: four consecutive queries
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(rcs + 8 * gq + 4 * h);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(rcs + 32 + 8 * gq + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int reg = 4 * gq + e;
+                const float pv = __builtin_amdgcn_exp2f(s[reg] - l4[e]);
+                p[reg] = pv;
+                ds[reg] = pv * (dp[reg] + gv[reg] - d4[e]);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         accop_a_i<DOOFF, 0>(dv0, p, sm, lb);               // dV[key = krow][d = 32*blk + r]
@@ -522,8 +528,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_sres_kernel(AttnGeom g, const
 // ---------------------------------------------------------------------------------------------
 void acr_attn_fwd_f32_sres(const AttnGeom& g, const float* q, const float* k, const float* v, float* o, float* lse2, float* scores,
                            float* pmean, int64_t pmean_sb, int64_t pmean_st, hipStream_t st) {
-    const int nt = (g.T + 127) / 128, NB = (g.T + 31) / 32;
-    hipLaunchKernelGGL(attn_fwd_sres_kernel, dim3(g.B * g.H * nt), dim3(256), 0, st, g, q, k, v, o, lse2, scores);
+    const int NB = (g.T + 31) / 32;
+    // waves (32-query blocks) per workgroup: 4.  T = 785 is 25 blocks = 5 x 5 exactly (with 4 every (b, h) carries a seventh
+    // workgroup with one live wave), but measured at B = 32, H = 12: 5-wave workgroups 0.86 ms vs 0.64 ms -- 160 VGPRs allow 12
+    // wave slots per CU, i.e. only two 5-wave workgroups (10 waves on SIMDs as 3,3,2,2) against three 4-wave ones.  Kept
+    // behind ACR_OPT_ATTN_F32_NW = 5 for A/B runs.
+    if (acr_opt(ACR_OPT_ATTN_F32_NW) == 5)
+        hipLaunchKernelGGL(attn_fwd_sres_kernel<5>, dim3(g.B * g.H * ((NB + 4) / 5)), dim3(320), 0, st, g, q, k, v, o, lse2, scores);
+    else
+        hipLaunchKernelGGL(attn_fwd_sres_kernel<4>, dim3(g.B * g.H * ((NB + 3) / 4)), dim3(256), 0, st, g, q, k, v, o, lse2, scores);
     if (pmean)
         hipLaunchKernelGGL(attn_pmean_sres_kernel, dim3((g.B * NB * NB + 3) / 4), dim3(256), 0, st, g, NB, (const float*)scores,
                            (const float*)lse2, pmean, pmean_sb, pmean_st);

@@ -151,3 +151,35 @@ __device__ __forceinline__ void dma_tile32_i(float* lds, const float* __restrict
         __builtin_amdgcn_global_load_lds((glb_vp)(row0ptr + off[i]), (lds_vp)(lds + (wave * 2 + i) * 256), 16, 0, 0);
 }
 
+
+// ---- the same tile DMA dealt over NW waves (workgroups of NW x 32 rows): piece p of the 8 goes to wave p % NW ----
+template <int NW>
+__device__ __forceinline__ void dma_tile32_nw(float* lds, const float* __restrict__ g, int64_t st, int row0, int Tn, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < (8 + NW - 1) / NW; ++i) {
+        const int piece = wave + i * NW;
+        if (piece < 8) {                                     // wave-uniform
+            const int row = piece * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (row & 15);
+            const float* src = g + (int64_t)min(row0 + row, Tn - 1) * st + c * 4;
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds + piece * 256), 16, 0, 0);
+        }
+    }
+}
+template <int NW>
+__device__ __forceinline__ void dma_offsets32_nw(int (&off)[(8 + NW - 1) / NW], int64_t st, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < (8 + NW - 1) / NW; ++i) {
+        const int row = min(wave + i * NW, 7) * 4 + (lane >> 4);
+        off[i] = row * (int)st + (((lane & 15) ^ (row & 15)) << 2);
+    }
+}
+template <int NW>
+__device__ __forceinline__ void dma_tile32_nw_i(float* lds, const float* __restrict__ row0ptr, const int (&off)[(8 + NW - 1) / NW], int wave) {
+#pragma unroll
+    for (int i = 0; i < (8 + NW - 1) / NW; ++i) {
+        const int piece = wave + i * NW;
+        if (piece < 8)
+            __builtin_amdgcn_global_load_lds((glb_vp)(row0ptr + off[i]), (lds_vp)(lds + piece * 256), 16, 0, 0);
+    }
+}

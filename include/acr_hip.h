@@ -74,6 +74,7 @@ typedef enum acr_option {
     ACR_OPT_DQ_VARIANT = 5,     /* acr_attn_bwd (bf16) dQ sweep: 0 = by presence of G, 2 = 2-wave, 4 = 4-wave */
     ACR_OPT_GEMM_F32_REGSTAGE = 6, /* 1: acr_gemm_f32 always takes the register-staged kernel (A/B of the LDS-DMA kernel) */
     ACR_OPT_ATTN_F32_GEN1 = 7,  /* 1: fp32 attention on the first-generation (register-staged, 2-wave) kernels */
+    ACR_OPT_ATTN_F32_NW = 8,    /* acr_attn_fwd_scores: 5 = five 32-query blocks (waves) per forward workgroup instead of four (A/B: slower) */
     ACR_OPT_COUNT_
 } acr_option;
 int     acr_set_option(int32_t option, int32_t value);

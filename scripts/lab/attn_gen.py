@@ -3,7 +3,7 @@ forward (+ head mean) and backward (with the head-mean gradient) time per launch
 max-abs comparison of the two generations' outputs.  usage: attn_gen.py [B] [T]"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from acr_wsss_amd import ops
+from acr_wsss_amd import ops, _lib
 dev = torch.device("cuda:0")
 H = 12
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
@@ -15,8 +15,9 @@ gst = torch.zeros(B, T, ops.pad4(T), device=dev)
 gst[:, :, :T] = torch.randn(B, T, T, device=dev) * 1e-3
 gpm = gst[:, :, :T]
 res = {}
-for gen in ("recompute", "scores"):
-    ops.ATTN_F32_SCORES = gen == "scores"
+for gen in ("recompute", "scores nw4", "scores nw5"):
+    ops.ATTN_F32_SCORES = gen != "recompute"
+    _lib.set_option("attn_f32_nw", 5 if gen.endswith("5") else 4)
     stack = ops.MeanStack(B, 1, T, dev)
     def run():
         qkv.grad = None
@@ -37,9 +38,9 @@ for gen in ("recompute", "scores"):
         torch.cuda.synchronize()
         tf += ev[0].elapsed_time(ev[1]); tb += ev[1].elapsed_time(ev[2])
     prod = 2.0 * T * T * 64 * B * H
-    print("%-9s B %d T %d: fwd+pmean %.3f ms (%.1f TF algorithmic)   bwd %.3f ms (%.1f TF algorithmic)" % (
+    print("%-10s B %d T %d: fwd+pmean %.3f ms (%.1f TF algorithmic)   bwd %.3f ms (%.1f TF algorithmic)" % (
         gen, B, T, tf / reps, 2 * prod / (tf / reps) * 1e-9, tb / reps, 4 * prod / (tb / reps) * 1e-9), flush=True)
-a, b = res["recompute"], res["scores"]
+a, b = res["recompute"], res["scores nw5"]
 for name, x, y in zip(("o", "pmean", "dqkv"), a, b):
     print("%-6s max |recompute - scores| = %.3e  (max |x| %.3e)  finite %s" % (name, float((x - y).abs().max()), float(x.abs().max()),
                                                                              bool(torch.isfinite(y).all())))
