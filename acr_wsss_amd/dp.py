@@ -79,9 +79,10 @@ class GradSync:
         self._avg = backend == "nccl"                     # RCCL has a native AVG; gloo does not
         self.strict = (os.environ.get("ACR_DP_STRICT") == "1") if strict is None else bool(strict)
         # host-side agreement channel: the data group itself when it is gloo, else a gloo group over the same ranks
-        self._side = None
-        if self.world > 1:
-            self._side = process_group if backend == "gloo" else dist.new_group(
+        self._agree = self.world > 1
+        self._side = process_group                        # None = the default group
+        if self._agree and backend != "gloo":
+            self._side = dist.new_group(
                 ranks=dist.get_process_group_ranks(process_group) if process_group is not None else None, backend="gloo")
         self.stats = {"steps": 0, "bucket_launches_in_backward": 0, "bucket_launches_in_finish": 0, "late_reexchanges": 0,
                       "rank_disagreements": 0}
@@ -153,7 +154,7 @@ class GradSync:
         nb, npar = len(self.buckets), len(self._params)
         late = [b.late for b in self.buckets]
         nograd = [p.grad is None for p in self._params]
-        if self._side is not None:
+        if self._agree:
             # one small host-side exchange: flags[0:nb] = late (OR over ranks), then per parameter "has a gradient" on ANY rank
             # (OR) and on EVERY rank (AND, sent negated)
             flags = torch.tensor([float(x) for x in late] + [float(not x) for x in nograd] + [float(x) for x in nograd],
@@ -178,6 +179,11 @@ class GradSync:
                 self._launch(b, "finish")                 # the bucket again only adds the late gradient's exchange
                 self.stats["late_reexchanges"] += 1
                 self._wait(b)
+        if self._agree:                                   # a gradient that exists on another rank only: its average is ours too
+            for b in self.buckets:
+                for p, v in zip(b.params, b.views):
+                    if p.grad is None and not nograd[self._pidx[p]]:
+                        p.grad = v
         # re-learned every step: a tensor that stops (or starts) receiving gradients costs one late exchange, once
         self._unused = {p for p, n in zip(self._params, nograd) if n}
         self.stats["steps"] += 1

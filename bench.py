@@ -6,9 +6,12 @@ autocast(enabled=False)).  The same invocation then runs the bf16 training mode 
 fp32 master weights / accumulate / softmax / loss; parity pinned by tests/test_model_gpu.py::test_bf16_train_step_448)
 and reports it as the sub-record `"bf16": {...}` -- never as `value`.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1: run directly)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+        N = 1: runs in this process.  N > 1 without WORLD_SIZE in the environment: this process touches no GPU, starts
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...`
+        as a CHILD, relays its one JSON line and exits with its return code.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W  (N>1: one rank per GPU, RCCL)
+           --master-port P bench.py --gpus N --steps K --warmup W  (the driver's form: one rank per GPU, RCCL)
 
 A "step" is one iteration of train_acr.py:127-174 on a synthetic batch already resident in HBM: h-flip view,
 ViT-hybrid-base forward over both views, ACR loss, full backward, (RCCL gradient all-reduce,) PolyOptimizer
@@ -19,6 +22,8 @@ import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,7 +38,7 @@ FLOP_PER_IMG_448 = 1.1307e12          # SURVEY 6 [probe]: 2 views, fwd+bwd, hybr
 PEAK_MFMA = {"f32": 157.3e12, "bf16": 2.5e15}   # MI355X_MICROARCH.md: dense matrix peaks
 PRECISION = {"f32": "fp32 end to end (reference precision, exact-fp32 MFMA)",
              "bf16": "bf16 params/activations/grads + bf16 MFMA, fp32 master weights + fp32 accumulate/softmax/loss"}
-IN_STEP = os.path.join(ROOT, "profiles", "r02_in_step_kernels.json")     # rocprofv3 kernel-trace of this bench, per dtype
+IN_STEP = os.path.join(ROOT, "profiles", "r03_in_step_kernels.json")     # rocprofv3 kernel-trace of this bench, per dtype
 
 
 def parse():
@@ -56,6 +61,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--probe-only", action="store_true", help="run only the kernel roofline probe (for rocprofv3 --pmc passes)")
+    ap.add_argument("--no-infer", action="store_true", help="skip the CAM-generation record (BASELINE configs[3])")
+    ap.add_argument("--infer-only", action="store_true", help="run only the CAM-generation record (profiling)")
     return ap.parse_args()
 
 
@@ -120,20 +127,41 @@ def roofline_probe(args, dev, dtype, live=None):
     dqp, dkp, dvp = ops._qkv_ptrs(dqkv, H)
     st = L.stream_ptr()
 
-    def fwd():
-        L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm), T * T, T, st), "fwd")
+    scores_path = dtype == "f32" and ops.ATTN_F32_SCORES   # what ops.AttnCoreFn launches in fp32: logits resident in HBM
+    if scores_path:
+        sres = torch.empty(lib.acr_attn_scores_floats(d), dtype=torch.float32, device=dev)
 
-    def bwd():
-        L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(gm), gm.stride(0), gm.stride(1), dqp, dkp, dvp,
-                                 L.ptr(delta), st), "bwd")
+        def fwd():
+            L.check(lib.acr_attn_fwd_scores(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(sres), L.ptr(pm), T * T, T, st), "fwd")
+
+        def bwd():
+            L.check(lib.acr_attn_bwd_scores(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(sres), L.ptr(gm), gm.stride(0),
+                                            gm.stride(1), dqp, dkp, dvp, L.ptr(delta), st), "bwd")
+    else:
+        def fwd():
+            L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm), T * T, T, st), "fwd")
+
+        def bwd():
+            L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(gm), gm.stride(0), gm.stride(1), dqp, dkp,
+                                     dvp, L.ptr(delta), st), "bwd")
 
     t_fwd = time_kernel(fwd)
     t_bwd = time_kernel(bwd)
     unit = 2.0 * T * T * 64 * B * H                      # one T x T x 64 product over all (b, h)
-    kernels = {
-        "acr_attn_bwd": _mfma_rec("acr_attn_bwd (delta + dq + dkdv)", 4 * unit, 8 * unit, t_bwd, peak),
-        "acr_attn_fwd": _mfma_rec("acr_attn_fwd (+ head-mean)", 2 * unit, 3 * unit, t_fwd, peak),
-    }
+    if scores_path:                                      # executed products: 2 forward, 5 backward (dP dQ | dP dV dK)
+        sbytes = 4.0 * sres.numel()
+        kernels = {
+            "acr_attn_bwd": _mfma_rec("acr_attn_bwd_scores (row term stream + dq + dkdv, logits read from HBM)", 4 * unit, 5 * unit, t_bwd,
+                                      peak, {"scores_bytes_read_per_launch": 3 * sbytes}),
+            "acr_attn_fwd": _mfma_rec("acr_attn_fwd_scores (+ head-mean stream, logits written once)", 2 * unit, 2 * unit, t_fwd, peak,
+                                      {"scores_bytes_written_per_launch": sbytes, "scores_bytes_read_per_launch": sbytes}),
+        }
+        del sres
+    else:
+        kernels = {
+            "acr_attn_bwd": _mfma_rec("acr_attn_bwd (delta + dq + dkdv)", 4 * unit, 8 * unit, t_bwd, peak),
+            "acr_attn_fwd": _mfma_rec("acr_attn_fwd (+ head-mean)", 2 * unit, 3 * unit, t_fwd, peak),
+        }
     # K3 (HBM-bound): forward reads 2 stacks
     Lyr = 12
     a = torch.rand(B, Lyr, T, T, device=dev)
@@ -258,6 +286,160 @@ def cpu_baseline(args):
                       "+ 3 timed, median %.2f s (min %.2f, max %.2f)" % (args.size, args.size, bsz, med, timed[0], timed[-1])}
 
 
+def infer_record(args, dev, with_cpu):
+    """The CAM half of the path (infer_cam.py:141-215) as BASELINE configs[3] names it: one 384x384 network input with 2
+    positive classes, flipped + plain pass at scales {0.5, 1, 1.5, 2} (T = 145 ... 2305), GETAM `grad` from layer 10 with
+    affinity refinement, CAMs resized to 375x500; fp32 (the precision the argmax seeds are pinned in).  `value` = images/s
+    through acr_wsss_amd.infer_cam.infer_cam_image (host loop included: this path is launch-bound at batch 1);
+    `batch8_scale1` = 8 images per call at scale 1.  Kernel records: the attention pair at the largest scale through the
+    C ABI (MFMA-bound), the GETAM row accumulation and the affinity product (HBM-bound, SURVEY 8d bytes).  CPU baseline:
+    the oracle's infer_image on the same image at scale 1 only (bounded sample)."""
+    from acr_wsss_amd import _lib as L, ops
+    from acr_wsss_amd.DPT.ACR import ACR
+    from acr_wsss_amd.infer_cam import infer_cam_image, infer_cam_images
+    lib = L.load()
+    torch.manual_seed(0)
+    model = ACR(num_classes=20, backbone_name="vitb_hybrid", use_pretrain=False).to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    img = torch.randn(1, 3, 384, 384, generator=g).to(dev)
+    lab = torch.zeros(1, 20)
+    lab[0, 3] = lab[0, 11] = 1
+    scales, out_hw = (0.5, 1.0, 1.5, 2.0), (375, 500)
+
+    def timed(fn, n, warm=1):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    t_ms = timed(lambda: infer_cam_image(model, img, lab, out_hw, scales=scales), 3)
+    log("infer: 4 scales %.1f ms/image" % (t_ms * 1e3))
+    t_s1 = timed(lambda: infer_cam_image(model, img, lab, out_hw), 5)
+    imgs8, labs8 = img.repeat(8, 1, 1, 1), lab.repeat(8, 1)
+    t_b8 = timed(lambda: infer_cam_images(model, imgs8, labs8, [out_hw] * 8), 2)
+    log("infer: scale 1 %.1f ms/image, batch 8 %.1f ms" % (t_s1 * 1e3, t_b8 * 1e3))
+    rec = {"workload": "BASELINE configs[3]: 384x384 base, scales {0.5,1,1.5,2}, 2 classes, flipped + plain pass, GETAM grad "
+                       "start_layer 10 + affinity, CAMs at 375x500 (infer_cam.py:141-215); synthetic image, seeded init",
+           "metric": "img/s CAM generation, 1 GPU", "value": round(1.0 / t_ms, 3), "unit": "img/s", "dtype": "f32",
+           "ms_per_image": round(t_ms * 1e3, 2), "scale1_img_s": round(1.0 / t_s1, 2), "batch8_scale1": round(8.0 / t_b8, 2),
+           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    del model, imgs8
+    gc.collect()
+    torch.cuda.empty_cache()
+    # ---- kernel records at the largest scale: T = (768/16)^2 + 1 = 2305, the flip pair as a batch of 2, 12 heads
+    B, H, T, Lyr = 2, 12, 2305, 12
+    peak = PEAK_MFMA["f32"]
+    gq = torch.Generator(device="cpu").manual_seed(1)
+    qkv = torch.randn(B, T, 3 * H * 64, generator=gq).to(dev)
+    d_o = torch.randn(B, T, H * 64, generator=gq).to(dev)
+    o = torch.empty(B, T, H * 64, device=dev)
+    lse2 = torch.empty(B, H, T, device=dev)
+    pm = torch.empty(B, T, T, device=dev)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, T, device=dev)
+    d = ops._desc(B, H, T, torch.float32)
+    qp, kp, vp = ops._qkv_ptrs(qkv, H)
+    dqp, dkp, dvp = ops._qkv_ptrs(dqkv, H)
+    st = L.stream_ptr()
+    sres = torch.empty(lib.acr_attn_scores_floats(d), device=dev)
+    unit = 2.0 * T * T * 64 * B * H
+    t = time_kernel(lambda: L.check(lib.acr_attn_fwd_scores(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(sres), L.ptr(pm), T * T, T, st), "fwd"))
+    kernels = {"acr_attn_fwd": _mfma_rec("acr_attn_fwd_scores (+ head-mean stream), B=2 H=12 T=2305", 2 * unit, 2 * unit, t, peak)}
+    t = time_kernel(lambda: L.check(lib.acr_attn_bwd_scores(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(sres), None, 0, 0, dqp, dkp,
+                                                            dvp, L.ptr(delta), st), "bwd"))
+    kernels["acr_attn_bwd"] = _mfma_rec("acr_attn_bwd_scores (no head-mean gradient: the class logit's backward), B=2 H=12 T=2305",
+                                        4 * unit, 5 * unit, t, peak)
+    cam_row = torch.zeros(T - 1, device=dev)
+    t = time_kernel(lambda: ops.getam_row_accum(qkv, d_o, lse2, H, 0, "grad", cam_row))
+    row_bytes = 4.0 * (3 * H * 64 * T + H * 64 + H * T + (T - 1))     # k, v of one sample once, q/dO row 0, lse2 row, the output row
+    kernels["acr_getam_row_accum"] = {"bound": "hbm", "kernel": "getam_row (row 0 of relu(dP) head mean, one layer, T=2305)",
+                                      "achieved": round(row_bytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                      "frac": round(row_bytes / t / 8e12, 5), "launch_ms": round(t * 1e3, 4), "bytes_per_launch": row_bytes,
+                                      "note": "latency-bound: 7 MB per launch"}
+    attn = torch.rand(Lyr, T, T, device=dev)
+    cams = torch.rand(2, T - 1, device=dev)
+    t = time_kernel(lambda: ops.aff_refine(attn, cams))
+    aff_bytes = 4.0 * Lyr * (T - 1) * (T - 1)
+    kernels["acr_aff_refine"] = {"bound": "hbm", "kernel": "aff_refine (sum over 12 layers of the head-mean map, times 2 class rows, T=2305)",
+                                 "achieved": round(aff_bytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round(aff_bytes / t / 8e12, 4), "launch_ms": round(t * 1e3, 4), "bytes_per_launch": aff_bytes}
+    head = dict(kernels.pop("acr_attn_bwd"))
+    head["traffic"] = None
+    head["kernels"] = kernels
+    rec["roofline"] = head
+    del sres, qkv, d_o, o, pm, dqkv, attn
+    torch.cuda.empty_cache()
+    if with_cpu:
+        from oracle import acr_oracle as O
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        from recipe import recipe_state_dict
+        with open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")) as f:
+            layout = json.load(f)
+        sd = recipe_state_dict(layout, 0)
+        t0 = time.time()
+        O.infer_image(sd, O.HYBRID_BASE, img.cpu(), lab, out_hw, start_layer=10, func="grad", aff=True, scales=(1,))
+        tc = time.time() - t0
+        log("infer cpu_baseline: oracle infer_image at scale 1: %.1f s" % tc)
+        rec["cpu_baseline"] = {"value": round(1.0 / tc, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "oracle infer_image, the same 384x384 image, scale 1 ONLY (flipped + plain pass, 2 classes x 2 full "
+                                         "backwards): %.1f s; compare with scale1_img_s, not with value" % tc}
+    return rec
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start the N ranks as a child torch.distributed.run job.  Decided
+    before this process has made any GPU call (it never does); the child's stderr passes through, its one JSON line is
+    relayed on stdout, and its return code becomes ours."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("[bench] self-launch: %s" % " ".join(cmd), file=sys.stderr, flush=True)
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+    for ln in child.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return child.returncode if (child.returncode != 0 or lines) else 1
+
+
+def dist_record(args, world, rank, local, dev, sync_info):
+    """What the process group looked like from inside (rank 0 reports): backend, world size, every rank's device, the RCCL
+    version and GradSync's bucket / launch counters -- so that an N > 1 line shows what actually ran."""
+    mine = {"rank": rank, "local_rank": local, "device": "cuda:%d" % dev.index, "name": torch.cuda.get_device_name(dev),
+            "pid": os.getpid()}
+    try:
+        mine["uuid"] = str(torch.cuda.get_device_properties(dev).uuid)
+    except Exception:
+        pass
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    rec = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_devices": allr,
+           "distinct_devices": len({r.get("uuid", r["device"]) for r in allr}), "launched_by": os.environ.get("TORCHELASTIC_RUN_ID", "env")}
+    try:
+        rec["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        rec["nccl_version"] = None
+    if sync_info:
+        rec.update(sync_info)
+    return rec
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
@@ -329,6 +511,15 @@ def run_mode(args, dtype, world, rank, dev):
            "step_mfma_frac": round(value * FLOP_PER_IMG_448 * (args.size / 448.0) ** 2 / (world * PEAK_MFMA[dtype]), 4),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     rec["_live_ms"] = live                               # popped by main(): feeds the roofline records
+    if sync is not None:
+        info = sync.describe()
+        per_step = max(1, info["steps"])
+        rec["_sync"] = {"buckets": info["buckets"], "bucket_mb": info["bucket_mb"], "unused_parameters": info["unused_parameters"],
+                        "bucket_launches_in_backward": info["bucket_launches_in_backward"],
+                        "bucket_launches_in_finish": info["bucket_launches_in_finish"],
+                        "bucket_launches_in_backward_per_step": round(info["bucket_launches_in_backward"] / per_step, 2),
+                        "late_reexchanges": info["late_reexchanges"], "rank_disagreements": info["rank_disagreements"],
+                        "steps_counted": info["steps"]}
     del model, opt, sync, step, img, label, loss
     gc.collect()
     torch.cuda.empty_cache()
@@ -337,6 +528,8 @@ def run_mode(args, dtype, world, rank, dev):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # the driver's `python bench.py --gpus N`: no GPU call has happened yet
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -365,9 +558,14 @@ def main():
     if args.probe_only:
         print(json.dumps({m: roofline_probe(args, dev, m) for m in modes}), flush=True)
         return
+    if args.infer_only:
+        print(json.dumps({"infer": infer_record(args, dev, not args.no_cpu_baseline)}), flush=True)
+        return
 
     runs = {m: run_mode(args, m, world, rank, dev) for m in modes}
     lives = {m: runs[m].pop("_live_ms", {}) for m in modes}
+    syncs = {m: runs[m].pop("_sync", None) for m in modes}
+    dist_info = dist_record(args, world, rank, local, dev, syncs[modes[0]]) if world > 1 else None
     if rank == 0:
         head = runs[modes[0]]                              # fp32 unless a single dtype was asked for
         head_live = lives[modes[0]]
@@ -393,6 +591,10 @@ def main():
                 sub["roofline"] = roofline_probe(args, dev, m, lives[m])
                 log("roofline probe (%s) done" % m)
             out[m] = sub
+        if dist_info is not None:
+            out["dist"] = dist_info
+        if world == 1 and not args.no_infer:
+            out["infer"] = infer_record(args, dev, not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -82,22 +82,35 @@ def test_two_rank_train_step_matches_single_process():
 
 
 def test_bench_two_ranks_gloo_rehearsal(tmp_path):
-    """bench.py's N > 1 path executed end to end: 2 ranks launched exactly as the driver does (torch.distributed.run,
-    one process per rank) but sharing cuda:0 with gloo collectives (`--backend gloo`: RCCL needs one GPU per rank and the
-    test box has one).  Checks the contract fields of the ONE JSON line: whole-job img/s over both ranks, weak scaling,
-    fp32 headline with the bf16 sub-record, GradSync with its first bucket overlapping backward."""
+    """bench.py's N > 1 path executed end to end THROUGH ITS SELF-LAUNCH: `python bench.py --gpus 2` with no WORLD_SIZE in the
+    environment (the driver's command shape) must start the two ranks itself (child torch.distributed.run, one process per
+    rank), relay ONE JSON line and return the child's code.  The ranks share cuda:0 with gloo collectives (`--backend gloo`:
+    RCCL needs one GPU per rank and the test box has one).  Checks the contract fields: whole-job img/s over both ranks,
+    weak scaling, fp32 headline with the bf16 sub-record, and the `dist` record (what the process group looked like,
+    GradSync's buckets going out inside backward)."""
     import json
     import subprocess
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
            "--batch", "2", "--size", "224", "--backend", "gloo", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
+    assert "self-launch" in out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["dtype"] == "f32" and rec["config"]["global_batch"] == 4
     assert rec["config"]["parallelism"] == "dp2" and rec["unit"] == "img/s" and rec["higher_is_better"] is True
     assert abs(rec["value"] - 4 * 1e3 / rec["ms_per_step"]) <= 0.02 * rec["value"]          # whole job: both ranks' images
-    assert rec["bf16"]["dtype"] == "bf16" and rec["bf16"]["value"] > 0 and "roofline" not in rec
+    assert rec["bf16"]["dtype"] == "bf16" and rec["bf16"]["value"] > 0 and "roofline" not in rec and "infer" not in rec
+    d = rec["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and [r["rank"] for r in d["ranks_devices"]] == [0, 1]
+    assert d["buckets"] >= 1 and len(d["bucket_mb"]) == d["buckets"] and d["rank_disagreements"] == 0
+    # step 0 learns the unused tensors (everything from finish()); from step 1 on every bucket goes out inside backward
+    assert d["steps_counted"] == 4 and d["bucket_launches_in_backward"] == 3 * d["buckets"]
+    assert d["bucket_launches_in_finish"] == d["buckets"] and d["late_reexchanges"] == 0
+    # a wrong WORLD_SIZE is still an error, not a silent single-rank run
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         cwd=str(tmp_path))
+    assert bad.returncode != 0
