@@ -236,7 +236,11 @@ class Attention(nn.Module):
 
     ``get_attn()`` / ``get_attn_gradients()`` keep working for code that reaches into the blocks
     (DPT/ACR.py:108-111,182-184): the per-head maps are recomputed on demand from the saved q, k, row
-    log-sum-exp (resp. dO, v) by the HIP kernels instead of being retained after every forward."""
+    log-sum-exp (resp. dO, v, plus G/H when the loss used the head-mean maps) by the HIP kernels instead of being retained
+    after every forward.  One documented deviation: the reference stores P whenever ``x.requires_grad``
+    (vision_transformer.py:207-209), i.e. also in every training step; here a ``train()``-mode forward drops the state
+    (it would pin qkv + dO of all 12 layers between steps) unless ``keep_state_in_training`` is set on the module -- then
+    the API returns the reference's values after a training backward too (tests/test_model_gpu.py::test_attention_state_api_after_training_backward)."""
 
     def __init__(self, dim, num_heads):
         super().__init__()
@@ -247,6 +251,7 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self._saved = None          # (qkv, lse2, heads) of the last forward
         self._saved_do = None       # dO of the last backward
+        self._saved_gpm = None      # dLoss/d(head-mean map) of the last backward (None when the loss did not use the maps)
         self._override = {}
         self.last_pm = None         # (B,T,T) head-mean map of the last forward (slice of the MeanStack)
 
@@ -279,7 +284,12 @@ class Attention(nn.Module):
         if self._saved is None or self._saved_do is None:
             return None
         qkv, _, heads = self._saved
-        return ops.attn_dprobs(qkv.detach(), self._saved_do, heads)
+        g = ops.attn_dprobs(qkv.detach(), self._saved_do, heads)
+        # what the reference's hook on P holds (vision_transformer.py:207-209): the gradient through attn @ v PLUS, after a
+        # training backward, the one through `P.mean(dim=1)` of DPT/ACR.py:109 -- G / H on every head
+        if self._saved_gpm is not None:
+            g += (self._saved_gpm.detach().float() / heads).unsqueeze(1)
+        return g
 
     def save_attn_gradients(self, g):
         self._override["grad"] = g

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_dma_kernel(const bf16_t* __r
     const int nk = K >> 6;
     glds_stage(smem, A, lda, m0, M, 0, wave, lane);
     glds_stage(smem + GL_TILE, B, ldb, n0, N, 0, wave, lane);
-    __syncthreads();
+    acr_dma_barrier();
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_dma_kernel(const bf16_t* __r
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        __syncthreads();                                    // drains the DMA (vmcnt) and frees buffer `cur`
+        acr_dma_barrier();                                    // drains the DMA (vmcnt) and frees buffer `cur`
     }
     // Epilogue through LDS (the operand buffers are free after the last barrier): each wave parks its 64x64 fp32
     // tile in its own 16 KiB, then re-reads it row-major so that 8 lanes store one full 128-byte row segment with
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
     if (st0 < st1) {
         wg_stage(smem, dY, ldy, st0 * 64, M, tn * 128, wave, lane);
         wg_stage(smem + WG_TILE, X, ldx, st0 * 64, M, tk * 128, wave, lane);
-        __syncthreads();
+        acr_dma_barrier();
         int cur = 0;
         for (int stp = st0; stp < st1; ++stp, cur ^= 1) {
             if (stp + 1 < st1) {
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
             }
-            __syncthreads();
+            acr_dma_barrier();
         }
     }
     // acc[ni][kj][reg] = dW[tn*128 + 32(2wi+ni) + krow(reg,hh)][tk*128 + 32(2wj+kj) + r]
@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(256) void conv1x1_nn_kernel(const bf16_t* __restric
     const int nk = K >> 6;
     glds_stage(smem, W, ldw, m0, M, 0, wave, lane);
     c1_stage_b(smem + GL_TILE, xs, HW, 0, p0, max_off, wave, lane);
-    __syncthreads();
+    acr_dma_barrier();
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(256) void conv1x1_nn_kernel(const bf16_t* __restric
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        __syncthreads();
+        acr_dma_barrier();
     }
     // acc[mt][nt][reg] = Y[n][m0 + 64 wm + 32 mt + krow(reg,hh)][p0 + 64 wn + 32 nt + r]; LDS-staged 16-byte stores
     float* stile = reinterpret_cast<float*>(smem) + wave * 4096;
@@ -1535,7 +1535,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const bf16_t* __rest
     };
     if (st0 < st1) {
         stage(smem, st0);
-        __syncthreads();
+        acr_dma_barrier();
         int cur = 0;
         for (int stp = st0; stp < st1; ++stp, cur ^= 1) {
             if (stp + 1 < st1) stage(smem + (cur ^ 1) * 2 * GL_TILE, stp + 1);
@@ -1566,7 +1566,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const bf16_t* __rest
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
             }
-            __syncthreads();
+            acr_dma_barrier();
         }
     }
     float* slab = slabs + (int64_t)split * M * N;

@@ -123,6 +123,14 @@ def seeds_from_cam_dict(cam_dict, threshold, num_cls=21):
     return np.argmax(tensor, axis=0).astype(np.uint8)
 
 
+def shard_indices(n, rank=0, world=1):
+    """Indices of an n-item list that rank `rank` of `world` processes handles: rank, rank + world, ... (the image list is
+    sharded embarrassingly; the reference iterates the whole list on every rank, infer_cam.py:119-123)."""
+    if not 0 <= rank < world:
+        raise ValueError("rank %d outside world %d" % (rank, world))
+    return list(range(rank, n, world))
+
+
 def infer_cam_list(model, items, out_cam=None, rank=0, world=1, batch_size=1, out_crf=None, low_alpha=1, high_alpha=12, **kw):
     """Shard ``items`` -- an indexable of (name, img (1,3,h,w), label (1,C), (W,H)[, orig uint8 (W,H,3)]) -- over ranks and
     write ``<out_cam>/<name>.npy`` in the reference's wire format: a pickled {class: float32 (W,H)} dict
@@ -134,7 +142,7 @@ def infer_cam_list(model, items, out_cam=None, rank=0, world=1, batch_size=1, ou
     dev = next(model.parameters()).device
     model.eval()
     results = {}
-    mine = list(range(rank, len(items), world))
+    mine = shard_indices(len(items), rank, world)
     pos = 0
     while pos < len(mine):
         grp = [mine[pos]]

@@ -143,6 +143,7 @@ class AttnCoreFn(Function):
         if owner is not None:
             owner._saved = (qkv, lse2, heads) if keep else None
             owner._saved_do = None
+            owner._saved_gpm = None
         if pm is None:
             return o, None
         return o, pm
@@ -187,6 +188,7 @@ class AttnCoreFn(Function):
         _t1(tok)
         if ctx.owner is not None:
             ctx.owner._saved_do = d_o
+            ctx.owner._saved_gpm = g_pm       # dLoss/d(mean_h P): reaches every head's P as G/H (get_attn_gradients)
         return dqkv, None, None, None, None
 
 
@@ -315,8 +317,11 @@ class WeightTransposes:
     _f32; in fp32 the GEMM on the transposed copy is 12-17 % faster than on W as stored, scripts/lab/gemm_nn_vs_nt.py).
 
     ``refresh()`` is called by the training step's owner right after the optimizer step; a copy is used only while the
-    weight's autograd version equals the one recorded at refresh (an in-place update by anything else makes the consumer
-    fall back to W as stored / a transpose on the fly), so a stale copy can never be read silently."""
+    weight's autograd version, storage address and device equal those recorded at refresh (an in-place update through the
+    parameter, a re-allocated storage or ``module.to(other_gpu)`` make the consumer fall back to W as stored / a transpose
+    on the fly).  What this CANNOT see: writes through ``.data`` (``p.data.mul_()``, ``p.data.copy_()``, an EMA swap) --
+    they do not move the parameter's version counter -- so code that updates weights that way must call ``refresh()``
+    itself (train.refresh_weight_transposes(model)); INTEGRATION.md says so."""
 
     def __init__(self, modules, dtype=torch.bfloat16):
         import numpy as np
@@ -358,7 +363,7 @@ class WeightTransposes:
         fn = L.load().acr_transpose_many_bf16 if self.dtype == torch.bfloat16 else L.load().acr_transpose_many_f32
         L.check(fn(L.ptr(self.table), L.ptr(self.blk), self.nblocks, L.stream_ptr()), "acr_transpose_many")
         for m, wt in zip(self.lins, self.bufs):
-            m._acr_wt, m._acr_wt_ver = wt, m.weight._version
+            m._acr_wt, m._acr_wt_ver, m._acr_wt_ptr = wt, m.weight._version, m.weight.data_ptr()
 
 
 def weight_t(weight, owner=None, make=True):
@@ -366,7 +371,8 @@ def weight_t(weight, owner=None, make=True):
     (``make`` = False: None instead, for callers that can work on W as stored)."""
     wt = getattr(owner, "_acr_wt", None) if owner is not None else None
     if (wt is not None and owner._acr_wt_ver == weight._version and wt.shape[0] == weight.shape[1] and wt.dtype == weight.dtype
-            and owner.weight.data_ptr() == weight.data_ptr()):
+            and wt.device == weight.device and owner.weight.data_ptr() == weight.data_ptr()
+            and getattr(owner, "_acr_wt_ptr", None) == weight.data_ptr()):
         return wt
     return weight.t().contiguous() if make else None
 

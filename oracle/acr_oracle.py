@@ -24,6 +24,10 @@ import torch.nn.functional as F
 # --------------------------------------------------------------------------------------------
 HYBRID_BASE = dict(embed_dim=768, depth=12, heads=12, hybrid=True, patch=16, start_index=1,
                    stage_depths=(3, 4, 9), stage_chs=(256, 512, 1024), prefix="pretrained.model.")
+# DPT/ACR.py:155-160 'deit_distilled' -> DPT/vit.py deitb16_distil_384: plain 16x16 patch embedding, cls + distillation
+# token (start_index 2, models/vision_transformer.py:466-472)
+DEIT_DISTILLED = dict(embed_dim=768, depth=12, heads=12, hybrid=False, patch=16, start_index=2, distilled=True,
+                      prefix="pretrained.model.")
 VIT_TINY = dict(embed_dim=192, depth=12, heads=3, hybrid=False, patch=16, start_index=1,
                 prefix="pretrained.model.")
 
@@ -134,7 +138,10 @@ def forward_flex(x, sd, cfg):
     else:
         x = F.conv2d(x, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"], stride=cfg["patch"])
     x = x.flatten(2).transpose(1, 2)
-    x = torch.cat((sd[pre + "cls_token"].expand(b, -1, -1), x), dim=1) + pos
+    toks = [sd[pre + "cls_token"].expand(b, -1, -1)]
+    if cfg.get("distilled"):                                 # models/vision_transformer.py:466-472
+        toks.append(sd[pre + "dist_token"].expand(b, -1, -1))
+    x = torch.cat(toks + [x], dim=1) + pos
     maps = []
     for i in range(cfg["depth"]):
         x, P = block(x, sd, "%sblocks.%d." % (pre, i), cfg["heads"])

@@ -42,7 +42,7 @@ def recipe_sd(kind="hybrid", seed=0):
     from recipe import recipe_state_dict
     key = (kind, seed)
     if key not in _SD_CACHE:
-        fn = "state_dict_layout_tiny.json" if kind == "tiny" else "state_dict_layout.json"
+        fn = {"tiny": "state_dict_layout_tiny.json", "distil": "state_dict_layout_distil.json"}.get(kind, "state_dict_layout.json")
         with open(os.path.join(GOLDEN, fn)) as f:
             layout = json.load(f)
         if kind == "coco":                                  # train_acr_coco.py:91: ACR(num_classes=80) -- only the head differs

@@ -303,6 +303,30 @@ def run_infer_case_big(tag, model, size, WH, seed, scales, combos, classes, num_
     print("wrote", path, flush=True)
 
 
+def run_getam_case(tag, model, size, seed, classes, num_classes=20):
+    """The part of infer_cam.py:155-180 that works for EVERY backbone of DPT/ACR.py:155-160: forward_cam, one backward per
+    positive class, ACR.getam for all four funcs.  (For `deit_distilled` the rest of the reference loop cannot run -- the
+    patch-CAM reshape :156 and the affinity product :183-184 assume T = N + 1 -- but getam has a dedicated branch for it,
+    `cams[:, 0, 2:]`, DPT/ACR.py:210-211, which is what this fixture pins.)"""
+    img, _ = make_inputs(1, size, num_classes, seed)
+    model.eval()
+    model.zero_grad()
+    cls_pred, x_patch_cls, attn, patch_cam = model.forward_cam(img)
+    fx = {"img": np_(img), "meta": np.array([size, seed]), "classes": np.array(classes), "cls_pred": np_(cls_pred),
+          "x_patch_cls": np_(x_patch_cls), "attn": np_(attn), "patch_cam": np_(patch_cam)}
+    for c in classes:
+        model.zero_grad()
+        cls_pred[0, c].backward(retain_graph=True)
+        for func in ("grad", "cam_grad", "grad_s", "cam_grad_s"):
+            for start_layer in (0, 10):
+                cam, _, _ = model.getam(0, start_layer=start_layer, func=func)
+                fx["getam:%s_s%d:%d" % (func, start_layer, c)] = np_(cam)
+    fx["weights_checksum"] = np.array(weights_checksum(model.state_dict()))
+    path = os.path.join(HERE, tag + ".npz")
+    np.savez_compressed(path, **fx)
+    print("wrote", path, {k: v.shape for k, v in fx.items() if hasattr(v, "shape") and k.startswith(("attn", "getam:grad_s10"))}, flush=True)
+
+
 def main():
     _install_timm_stub()
     torch.set_num_threads(8)
@@ -310,7 +334,7 @@ def main():
     from DPT.ACR import ACR
 
     which = set(sys.argv[1:]) or {"layout", "hyb64", "hyb96", "tiny224", "infer64", "infer96", "hyb448", "infer384", "ms96", "ms384",
-                                  "coco512"}
+                                  "coco512", "distil96"}
 
     model = ACR(num_classes=20, backbone_name="vitb_hybrid", use_pretrain=False)
     if "layout" in which:
@@ -352,6 +376,15 @@ def main():
         fill_state_dict(coco, seed=0)
         run_train_case("train_coco_512_b1", coco, coco.forward_mirror, 512, 1, 80, 125, 10, gnames, sub=(113, 101))
         del coco
+
+    if "distil96" in which:          # DPT/ACR.py:155-160 'deit_distilled' (cls + dist token: T = N + 2), getam's [:, 2:] branch
+        dist_model = ACR(num_classes=20, backbone_name="deit_distilled", use_pretrain=False)
+        layout = {k: list(v.shape) for k, v in dist_model.state_dict().items()}
+        with open(os.path.join(HERE, "state_dict_layout_distil.json"), "w") as f:
+            json.dump(layout, f, indent=0)
+        fill_state_dict(dist_model, seed=0)
+        run_getam_case("getam_distil_96", dist_model, 96, 13, [3, 11])
+        del dist_model
 
     if "tiny224" in which:
         tiny = build_tiny(20)

@@ -248,12 +248,19 @@ def test_grad_sync_survives_rank_dependent_gradient_presence():
 
 
 def test_infer_list_sharding():
-    """rank r takes items r::world; the union over ranks is the list, no overlaps."""
-    n, world = 11, 4
-    seen = []
-    for r in range(world):
-        seen += list(range(r, n, world))
-    assert sorted(seen) == list(range(n))
+    """infer_cam.shard_indices -- what infer_cam_list(rank, world) iterates: rank r takes items r::world; the union over
+    ranks is the list, no overlaps (the files written per rank are checked on the GPU:
+    test_model_gpu.py::test_infer_cam_list_shards_the_list_over_ranks)."""
+    from acr_wsss_amd.infer_cam import shard_indices
+    for n, world in ((11, 4), (1449, 8), (3, 8), (0, 2)):
+        seen = []
+        for r in range(world):
+            mine = shard_indices(n, r, world)
+            assert mine == list(range(n))[r::world]
+            seen += mine
+        assert sorted(seen) == list(range(n))
+    with pytest.raises(ValueError):
+        shard_indices(5, 2, 2)
 
 
 def test_tuning_helpers_are_inert_without_a_gpu(tmp_path, monkeypatch):

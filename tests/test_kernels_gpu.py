@@ -450,6 +450,17 @@ def test_weight_transposes_cache():
     cache.refresh()
     assert ops.weight_t(lins[0].weight, lins[0]) is lins[0]._acr_wt
     assert torch.equal(lins[0]._acr_wt, lins[0].weight.t().contiguous())
+    # a re-allocated storage (`p.data = ...`, module.to(other device)) is seen through the recorded address ...
+    lins[1].weight.data = lins[1].weight.data.clone() * 3.0
+    wt1 = ops.weight_t(lins[1].weight, lins[1])
+    assert wt1 is not lins[1]._acr_wt and torch.equal(wt1, lins[1].weight.t().contiguous())
+    # ... a write THROUGH .data is not (no version bump, same storage): the documented contract is an explicit refresh
+    lins[2].weight.data.mul_(2.0)
+    assert ops.weight_t(lins[2].weight, lins[2]) is lins[2]._acr_wt and not torch.equal(lins[2]._acr_wt, lins[2].weight.t())
+    cache2 = ops.WeightTransposes(lins)
+    cache2.refresh()
+    for m in lins:
+        assert ops.weight_t(m.weight, m) is m._acr_wt and torch.equal(m._acr_wt, m.weight.t().contiguous())
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 32, 32), (130, 200, 72), (785, 2304, 768), (2 * 785 + 3, 768, 3072), (333, 576, 192),

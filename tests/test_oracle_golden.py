@@ -132,6 +132,27 @@ def test_infer_real_geometry_and_multi_scale(hybrid_sd, name):
         np.testing.assert_allclose(patch_dict[c], fx["patch_cam:%d" % c], rtol=0, atol=1e-5)
 
 
+def test_getam_deit_distilled():
+    """The oracle on a non-hybrid backbone with two leading tokens (DPT/ACR.py:155-160 'deit_distilled') against the
+    reference's own outputs: forward_cam and getam's `[:, 0, 2:]` branch (DPT/ACR.py:210-211)."""
+    fx = load_golden("getam_distil_96")
+    sd = {k: v.clone().requires_grad_(True) for k, v in recipe_sd("distil").items()}
+    img = torch.from_numpy(fx["img"])
+    cls_pred, x_patch_cls, attn, patch_cam, maps = O.forward_cam(img, sd, O.DEIT_DISTILLED)
+    for got, key in ((cls_pred, "cls_pred"), (x_patch_cls, "x_patch_cls"), (attn, "attn"), (patch_cam, "patch_cam")):
+        ref = fx[key]
+        assert np.abs(got.detach().numpy() - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-7, key
+    for c in fx["classes"]:
+        for P in maps:
+            P.grad = None
+        cls_pred[0, int(c)].backward(retain_graph=True)
+        for func in ("grad", "cam_grad", "grad_s", "cam_grad_s"):
+            for start_layer in (0, 10):
+                cam = O.getam([P.detach() for P in maps], [P.grad for P in maps], 0, start_layer, func, distilled=True)
+                ref = fx["getam:%s_s%d:%d" % (func, start_layer, int(c))]
+                assert cam.shape == ref.shape and np.abs(cam.numpy() - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-9
+
+
 def test_iou_counters():
     rng = np.random.default_rng(0)
     gt = rng.integers(0, 21, (40, 50)).astype(np.uint8)
