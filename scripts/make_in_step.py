@@ -1,5 +1,5 @@
-"""Builds profiles/r02_in_step_kernels.json (+ the per-step breakdown text files and kernel-stats copies) from the output of
-scripts/profile_round.sh:  python scripts/make_in_step.py gpurun_out r02
+"""Builds profiles/<tag>_in_step_kernels.json (+ the per-step breakdown text files and kernel-stats copies) from the output of
+scripts/profile_round.sh:  python scripts/make_in_step.py gpurun_out r03
 Per dtype: in-step launches / average duration of every hand-written kernel group bench.py's roofline probe reports, the
 group on top of the step (by in-step time), and HBM traffic per launch of the probe's launches from the two PMC passes
 (FETCH_SIZE x2 on gfx950 -- it tallies 128-byte requests at 64 bytes -- x1024; WRITE_SIZE x1024; MI355X_MICROARCH.md HBM)."""
@@ -12,9 +12,9 @@ GROUPS = {
             # forward Linears AND input gradients (NT on the cached W^T since round 2): one symbol family
             "acr_gemm_f32_nt": ["gemm_f32_dma_kernel<true, true,", "gemm_f32_kernel<true, true,"],
             "acr_gemm_f32_nn": ["gemm_f32_dma_kernel<true, false,", "gemm_f32_kernel<true, false,"],
-            "acr_attn_bwd": ["attn_delta_dma_kernel", "attn_bwd_dma_kernel", "attn_dq_dma_kernel", "attn_dkdv_dma_kernel", "attn_delta_kernel<float>",
+            "acr_attn_bwd": ["attn_delta_sres_kernel", "attn_bwd_sres_kernel", "attn_delta_dma_kernel", "attn_bwd_dma_kernel", "attn_dq_dma_kernel", "attn_dkdv_dma_kernel", "attn_delta_kernel<float>",
                              "attn_dq_kernel<float>", "attn_dkdv_kernel<float>"],
-            "acr_attn_fwd": ["attn_fwd_dma_kernel", "attn_pmean_dma_kernel", "attn_fwd_kernel<float>", "attn_tile_qk_kernel<float, 0>"],
+            "acr_attn_fwd": ["attn_fwd_sres_kernel", "attn_pmean_sres_kernel", "attn_fwd_dma_kernel", "attn_pmean_dma_kernel", "attn_fwd_kernel<float>", "attn_tile_qk_kernel<float, 0>"],
             "acr_consistency_fwd": ["cons_fwd", "cons_reduce"]},
     "bf16": {"acr_wgrad_bf16": ["gemm_tn_bf16", "wgrad_reduce"],
              "acr_linear_bf16": ["gemm_nt_bf16_wide_kernel<true", "gemm_nt_bf16_dma_kernel<true"],
