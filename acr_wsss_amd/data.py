@@ -16,7 +16,9 @@ and returns the same contract as the reference: images (B,3,S,S) + labels (B,C) 
 random.randint / random.randrange) from SEEDABLE generators (the reference's are the unseeded globals, train_acr.py:23).
 There is no CPU path: tensors land on the GPU through the HIP kernel or the call raises.
 """
+import concurrent.futures
 import ctypes
+import os
 import random as _pyrandom
 
 import numpy as np
@@ -122,6 +124,7 @@ class TrainBatcher:
 
     def __call__(self, images_uint8, labels):
         """images_uint8: list of (h,w,3) uint8 RGB arrays; labels: (B,C) tensor.  Returns (img, label) on the device."""
+        self.nprandom.uniform(0.7, 1.3)                     # myTool.py:1161: `scale`, drawn once per chunk and never used
         rec = np.zeros(len(images_uint8), PRE_IMAGE)
         for i, a in enumerate(images_uint8):
             rec[i] = self.draw(int(a.shape[0]), int(a.shape[1]))
@@ -136,3 +139,93 @@ def val_batch(images_uint8, crop_size, device="cuda", dtype=torch.float32):
     for i, a in enumerate(images_uint8):
         rec[i] = (0, int(a.shape[0]), int(a.shape[1]), S, S, 0, 0, 0, 0, 0, S, S, 0)
     return preprocess_batch(images_uint8, rec, S, device, dtype)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's own call contract: names in, tensors out (myTool.py:1158-1199, :1364-1403)
+# ------------------------------------------------------------------------------------------------------------------
+def decode_rgb(path):
+    """One image file -> (h, w, 3) uint8 RGB (what cv2.imread + cvtColor(BGR2RGB) hand to the reference, :1176-1177).  PIL
+    is the decoder this image ships (cv2 is absent); it releases the GIL while it decodes, so a thread pool scales."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"))
+
+
+class ChunkLoader:
+    """`get_data_from_chunk_v2(chunk, args)` / `get_data_from_chunk_val(chunk, args)` for a training process that must not
+    wait for its input: files are read and decoded by a small thread pool, geometry is drawn on the host in the reference's
+    RNG order, and ONE pinned H2D copy + ONE `acr_preprocess_batch` launch build the (B,3,S,S) batch on the GPU.
+
+        loader = ChunkLoader(img_dir, cls_labels, crop_size, device="cuda", seed=None, workers=8)
+        images, ori_images, labels, names = loader.get_data_from_chunk_v2(chunk)        # one chunk, synchronous decode
+        for images, ori_images, labels, names in loader.iterate(chunks, train=True):    # decode of chunk i+1 overlaps step i
+
+    `cls_labels`: the `voc12/cls_labels.npy` dict {name: float32 (C,)} (myTool.py:916-920) or its path.  `ori_images`
+    (de-normalised uint8 crops, :1186-1190, which no caller of the training loop reads) is None unless `with_ori=True`."""
+
+    def __init__(self, img_dir, cls_labels, crop_size, device="cuda", seed=None, workers=8, dtype=torch.float32, ext=".jpg",
+                 with_ori=False):
+        self.img_dir, self.S, self.ext, self.with_ori = img_dir, crop_size, ext, with_ori
+        self.device, self.dtype = torch.device(device), dtype
+        if isinstance(cls_labels, (str, os.PathLike)):
+            cls_labels = np.load(cls_labels, allow_pickle=True).item()
+        self.cls_labels = cls_labels
+        self.batcher = TrainBatcher(crop_size, device, seed, dtype)
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="acr-decode")
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+    def _submit(self, chunk):
+        return [self.pool.submit(decode_rgb, os.path.join(self.img_dir, name + self.ext)) for name in chunk]
+
+    def _labels(self, chunk):
+        return torch.from_numpy(np.stack([np.asarray(self.cls_labels[n], dtype=np.float32) for n in chunk]))
+
+    def _ori(self, images):
+        if not self.with_ori:
+            return None
+        mean = torch.tensor(MEAN, device=images.device).view(1, 3, 1, 1)
+        std = torch.tensor(STD, device=images.device).view(1, 3, 1, 1)
+        return ((images.float() * std + mean) * 255.0).clamp(0, 255).to(torch.uint8).cpu().numpy()     # :1186-1190 (astype truncates)
+
+    def _finish(self, chunk, futures, train):
+        decoded = [f.result() for f in futures]
+        labels = self._labels(chunk)
+        if train:
+            images, labels = self.batcher(decoded, labels)
+        else:
+            self.batcher.nprandom.uniform(0.7, 1.3)         # :1367: the val function draws `scale` too
+            images, labels = val_batch(decoded, self.S, self.device, self.dtype), labels.to(self.device, non_blocking=True)
+        return images, self._ori(images), labels, list(chunk)
+
+    def get_data_from_chunk_v2(self, chunk):
+        """myTool.py:1158-1199 -> (images (B,3,S,S) on the device, ori_images, labels (B,C), name_list)."""
+        return self._finish(chunk, self._submit(chunk), True)
+
+    def get_data_from_chunk_val(self, chunk):
+        """myTool.py:1364-1403: plain resize to S x S + normalise."""
+        return self._finish(chunk, self._submit(chunk), False)
+
+    def iterate(self, chunks, train=True, depth=2):
+        """Yield the batches of `chunks` in order while the pool already decodes the next `depth` chunks (the previous step's
+        GPU work and this thread's Python run meanwhile; the RNG draws stay in chunk order because they happen here)."""
+        chunks = list(chunks)
+        pending = [self._submit(c) for c in chunks[:depth]]
+        for i, chunk in enumerate(chunks):
+            futures = pending.pop(0)
+            if i + depth < len(chunks):
+                pending.append(self._submit(chunks[i + depth]))
+            yield self._finish(chunk, futures, train)
+
+
+def chunker(seq, size):
+    """myTool.py:882-883."""
+    return (seq[pos:pos + size] for pos in range(0, len(seq), size))
+
+
+def read_file(path_to_file):
+    """myTool.py:867-873: one image id per line."""
+    with open(path_to_file) as f:
+        return [line.rstrip("\n") for line in f]

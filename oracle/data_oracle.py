@@ -104,3 +104,22 @@ def val_image(rgb_u8, dim):
     """One image of get_data_from_chunk_val (:1377-1387): plain resize to dim x dim, normalise."""
     img = cv2_resize_linear(rgb_u8.astype(np.float64), dim, dim)
     return normalise(img).astype(np.float32).transpose(2, 0, 1)
+
+
+def get_data_from_chunk_v2(decoded, dim, pyrandom, nprandom):
+    """myTool.py:1158-1199 over already decoded RGB uint8 arrays (the cv2.imread of :1176 is the caller's): the per-chunk
+    `scale` draw of :1161 (never used, but it advances np.random), then per image the draws and the arithmetic above.
+    Returns (images (B,3,dim,dim) float32, geometry list)."""
+    nprandom.uniform(0.7, 1.3)
+    out, geoms = [], []
+    for rgb in decoded:
+        g = draw_train_geometry(rgb.shape[0], rgb.shape[1], dim, pyrandom, nprandom)
+        out.append(train_image(rgb, dim, g))
+        geoms.append(g)
+    return np.stack(out), geoms
+
+
+def get_data_from_chunk_val(decoded, dim, nprandom):
+    """myTool.py:1364-1403: `scale` draw (:1367), then resize to dim x dim + normalise per image."""
+    nprandom.uniform(0.7, 1.3)
+    return np.stack([val_image(rgb, dim) for rgb in decoded])
