@@ -61,6 +61,19 @@ class DPT(BaseModel):
         self.pretrained = nn.Module()
         self.pretrained.model = vit
         self.pretrained.activations = {}
+        if backbone in ("vitl16_384", "deitb16_384", "deitb16_distil_384"):
+            # DPT/blocks.py:29-35,62-82 builds these three without `seg=seg`, so DPT/vit.py:263-341 (default seg=True) attaches
+            # the four read-out heads to `pretrained` although ACR never runs them: their 14 tensors are part of every
+            # checkpoint of these backbones.  Created for state-dict compatibility only (indices 3 / 4 of each Sequential hold
+            # the parameters; 0-2 are the parameter-free read-out / transpose / unflatten steps).
+            D, f = vit.embed_dim, scratch_in
+            tails = ([nn.Conv2d(D, f[0], 1), nn.ConvTranspose2d(f[0], f[0], 4, stride=4)],
+                     [nn.Conv2d(D, f[1], 1), nn.ConvTranspose2d(f[1], f[1], 2, stride=2)],
+                     [nn.Conv2d(D, f[2], 1)],
+                     [nn.Conv2d(D, f[3], 1), nn.Conv2d(f[3], f[3], 3, stride=2, padding=1)])
+            for i, tail in enumerate(tails):
+                setattr(self.pretrained, "act_postprocess%d" % (i + 1),
+                        nn.Sequential(nn.Identity(), nn.Identity(), nn.Identity(), *tail))
         self.scratch = nn.Module()                     # created, never used in the ACR forward (blocks.py:97-147)
         for i, cin in enumerate(scratch_in):
             setattr(self.scratch, "layer%d_rn" % (i + 1), nn.Conv2d(cin, features, 3, 1, 1, bias=False))

@@ -313,3 +313,17 @@ def test_bench_self_launch_builds_the_drivers_command(monkeypatch, capsys):
     assert out.out.strip() == '{"metric": "x", "n_gpus": 4}' and "noise" in out.err
     monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: types.SimpleNamespace(returncode=3, stdout=""))
     assert bench.self_launch(args) == 3
+
+
+@pytest.mark.parametrize("backbone,layout", [("vitb_hybrid", "state_dict_layout.json"), ("deit_distilled", "state_dict_layout_distil.json")])
+def test_state_dict_layout_equals_the_references(backbone, layout):
+    """ACR(...).state_dict() has the reference model's keys and shapes, key for key (layouts dumped from the reference's own
+    ACR by tests/golden/make_golden.py): hybrid-base = 315 tensors; deit_distilled = 176 incl. dist_token / head_dist and the
+    14 read-out tensors DPT/vit.py attaches to the non-hybrid backbones (state-dict compatibility only)."""
+    import json
+    from acr_wsss_amd.DPT.ACR import ACR
+    with open(os.path.join(ROOT, "tests", "golden", layout)) as f:
+        ref = json.load(f)
+    sd = ACR(num_classes=20, backbone_name=backbone, use_pretrain=False).state_dict()
+    assert sorted(sd) == sorted(ref)
+    assert all(list(sd[k].shape) == ref[k] for k in ref)
