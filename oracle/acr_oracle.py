@@ -33,6 +33,41 @@ VIT_TINY = dict(embed_dim=192, depth=12, heads=3, hybrid=False, patch=16, start_
 
 
 # --------------------------------------------------------------------------------------------
+# optional activation rounding: the same algorithm with every activation tensor (and its gradient) stored in bf16 -- the error
+# budget a bf16 training mode has BY CONSTRUCTION, independent of any kernel (tests/test_model_gpu.py compares the HIP bf16
+# mode's deviation from the fp32 oracle with this emulation's).  Off (None) everywhere else: _r is then the identity.
+# --------------------------------------------------------------------------------------------
+_ROUND = None
+
+
+class _RoundBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+class bf16_activations:
+    """with bf16_activations(): ...  -- every tensor the functions below hand from one layer to the next is rounded to bf16
+    (forward value and gradient); products, norm statistics, softmax and the loss stay in fp32."""
+
+    def __enter__(self):
+        global _ROUND
+        _ROUND = _RoundBf16.apply
+
+    def __exit__(self, *a):
+        global _ROUND
+        _ROUND = None
+
+
+def _r(x):
+    return x if _ROUND is None else _ROUND(x)
+
+
+# --------------------------------------------------------------------------------------------
 # ResNetV2 stem (hybrid patch embedding)
 # --------------------------------------------------------------------------------------------
 def _same_pad_amount(n, k, s):
@@ -56,14 +91,14 @@ def std_conv_same(x, w, stride):
     w_hat = (w - mean) / (std + 1e-5)
     k = w.shape[-1]
     if stride == 1 and (k - 1) % 2 == 0:          # static case, padding.py:22-24,44-46
-        return F.conv2d(x, w_hat, None, 1, (k - 1) // 2)
-    return F.conv2d(pad_same(x, k, stride), w_hat, None, stride, 0)
+        return _r(F.conv2d(x, _r(w_hat), None, 1, (k - 1) // 2))
+    return _r(F.conv2d(pad_same(x, k, stride), _r(w_hat), None, stride, 0))
 
 
 def gn(x, sd, name, relu):
     """GroupNorm(32, eps 1e-5) [+ ReLU].  models/layers/norm_act.py:69-85."""
     y = F.group_norm(x, 32, sd[name + ".weight"], sd[name + ".bias"], 1e-5)
-    return F.relu(y) if relu else y
+    return _r(F.relu(y) if relu else y)
 
 
 def bottleneck(x, sd, pre, stride, has_down):
@@ -74,7 +109,7 @@ def bottleneck(x, sd, pre, stride, has_down):
     y = gn(std_conv_same(x, sd[pre + "conv1.weight"], 1), sd, pre + "norm1", True)
     y = gn(std_conv_same(y, sd[pre + "conv2.weight"], stride), sd, pre + "norm2", True)
     y = gn(std_conv_same(y, sd[pre + "conv3.weight"], 1), sd, pre + "norm3", False)
-    return F.relu(y + shortcut)
+    return _r(F.relu(y + shortcut))
 
 
 def resnetv2_features(x, sd, pre, cfg):
@@ -107,23 +142,24 @@ def attention(x, sd, pre, heads):
     B, T, C = x.shape
     d = C // heads
     qkv = F.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"]).reshape(B, T, 3, heads, d).permute(2, 0, 3, 1, 4)
+    qkv = _r(qkv)
     q, k, v = qkv[0], qkv[1], qkv[2]
     P = ((q @ k.transpose(-2, -1)) * (d ** -0.5)).softmax(dim=-1)
     if P.requires_grad:
         P.retain_grad()
-    out = (P @ v).transpose(1, 2).reshape(B, T, C)
-    return F.linear(out, sd[pre + "proj.weight"], sd[pre + "proj.bias"]), P
+    out = _r((_r(P) @ v).transpose(1, 2).reshape(B, T, C))        # (bf16 mode: P enters the second product rounded)
+    return _r(F.linear(out, sd[pre + "proj.weight"], sd[pre + "proj.bias"])), P
 
 
 def block(x, sd, pre, heads):
     """models/vision_transformer.py:230-233; LayerNorm eps 1e-6 (:299); Mlp :158-164 (exact GELU)."""
     C = x.shape[-1]
-    a, P = attention(F.layer_norm(x, (C,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-6), sd, pre + "attn.", heads)
-    x = x + a
-    h = F.layer_norm(x, (C,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-6)
-    h = F.linear(F.gelu(F.linear(h, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])),
-                 sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
-    return x + h, P
+    a, P = attention(_r(F.layer_norm(x, (C,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-6)), sd, pre + "attn.", heads)
+    x = _r(x + a)
+    h = _r(F.layer_norm(x, (C,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-6))
+    h = _r(F.linear(_r(F.gelu(_r(F.linear(h, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])))),
+                    sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"]))
+    return _r(x + h), P
 
 
 def forward_flex(x, sd, cfg):
@@ -134,14 +170,14 @@ def forward_flex(x, sd, cfg):
     pos = resize_pos_embed(sd[pre + "pos_embed"], h // cfg["patch"], w // cfg["patch"], cfg["start_index"])
     if cfg["hybrid"]:
         x = resnetv2_features(x, sd, pre + "patch_embed.backbone.", cfg)
-        x = F.conv2d(x, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"])
+        x = _r(F.conv2d(x, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"]))
     else:
         x = F.conv2d(x, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"], stride=cfg["patch"])
     x = x.flatten(2).transpose(1, 2)
     toks = [sd[pre + "cls_token"].expand(b, -1, -1)]
     if cfg.get("distilled"):                                 # models/vision_transformer.py:466-472
         toks.append(sd[pre + "dist_token"].expand(b, -1, -1))
-    x = torch.cat(toks + [x], dim=1) + pos
+    x = _r(torch.cat(toks + [x], dim=1) + pos)
     maps = []
     for i in range(cfg["depth"]):
         x, P = block(x, sd, "%sblocks.%d." % (pre, i), cfg["heads"])

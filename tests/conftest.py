@@ -66,10 +66,14 @@ def seed_planes(cams, t, shape):
     return np.stack([np.full(shape, t, np.float32)] + [cams[c] for c in sorted(cams)])
 
 
+SEED_TIE_MARGIN = 4e-4      # a CONSTANT: twice the 2e-4 the fp32 CAMs are held to on [0, 1] at real geometry
+
+
 def assert_seeds_exact_or_tie(got_seed, ref_seed, ref_cams, t, cam_err, what=""):
-    """north_star: argmax seeds bit-exact.  A pixel may differ only where the reference's own decision is an fp tie:
-    every plane moved by at most ``cam_err`` (the measured max |CAM - reference CAM|), so the argmax can only change
-    where the reference's top-1 / top-2 margin is <= 2 * cam_err.  Anything else fails; ties are printed."""
+    """north_star: argmax seeds bit-exact.  A pixel may differ only where the reference's own decision is an fp tie: its
+    top-1 / top-2 margin there is at most SEED_TIE_MARGIN -- a fixed number, not one scaled by this run's own error (the
+    measured max |CAM - reference CAM| ``cam_err`` is printed next to it and must itself stay below half the margin for
+    the argument "both planes moved by <= cam_err" to hold).  Anything else fails; ties are printed."""
     if np.array_equal(got_seed, ref_seed):
         return 0
     diff = got_seed != ref_seed
@@ -77,7 +81,8 @@ def assert_seeds_exact_or_tie(got_seed, ref_seed, ref_cams, t, cam_err, what="")
     margin = (planes[-1] - planes[-2])[diff]
     print("seed pixels differing %s t=%.1f: %d of %d, reference margins max %.3e (measured CAM error %.3e)"
           % (what, t, int(diff.sum()), diff.size, float(margin.max()), cam_err))
-    assert float(margin.max()) <= 2.0 * cam_err + 1e-7, (what, t, float(margin.max()), cam_err)
+    assert float(margin.max()) <= SEED_TIE_MARGIN, (what, t, float(margin.max()), cam_err)
+    assert 2.0 * cam_err <= SEED_TIE_MARGIN or float(margin.max()) <= 2.0 * cam_err + 1e-7, (what, t, cam_err)
     return int(diff.sum())
 
 
