@@ -41,6 +41,7 @@ struct GemmF32Args {
     float* cs;                     // TN: per-split column sums of A (bias gradient slabs) or null
     int M, N, K;
     int tiles_m, tiles_n, nsplit, kps;   // kps: contraction elements per split (multiple of F_BK)
+    int tile0, tiles_launch;             // this launch covers tiles tile0 .. tile0 + tiles_launch - 1 (each nsplit times)
     // z-slices: workgroup slice z = split index.  K-split (weight gradient of a Linear): operands shared, k range z*k_zs..;
     // batch (1x1 convolutions per sample): operands / outputs advance by *_zs per slice, k range the whole contraction
     int64_t a_zs, b_zs, c_zs, aux_zs;
@@ -140,9 +141,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
     __shared__ __attribute__((aligned(16))) float smem[4 * F_STAGE];      // [buf][A|B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int ntile = g.tiles_m * g.tiles_n;
+    const int ntile = g.tiles_launch;
     const int t = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
-    const int split = t / ntile, tt = t - split * ntile;
+    const int split = t / ntile, tt = g.tile0 + (t - split * ntile);
     const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
     const int m0 = tm * F_BM, n0 = tn * F_BN;
     const int zs = split / g.ksplit;
@@ -324,9 +325,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int ntile = g.tiles_m * g.tiles_n;
+    const int ntile = g.tiles_launch;
     const int t = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
-    const int split = t / ntile, tt = t - split * ntile;
+    const int split = t / ntile, tt = g.tile0 + (t - split * ntile);
     const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
     const int m0 = tm * F_BM, n0 = tn * F_BN;
     const int zs = split / g.ksplit;
@@ -389,6 +390,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
         g.stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
     }
 #endif
+    if (ACT == 4) {                                         // K-split tail tile: raw accumulators into a compact slab
+        float* slab = g.c + ((int64_t)split * g.tiles_launch + (tt - g.tile0)) * (F_BM * F_BN);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wn * 64 + j * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) slab[(wm * 64 + i * 32 + acr_krow(e, h)) * F_BN + col] = acc[i][j][e];
+            }
+        return;
+    }
     if (ACT == 3) {
         float* slab = g.c + (int64_t)split * g.M * g.ldc;
 #pragma unroll
@@ -441,6 +454,77 @@ __global__ __launch_bounds__(256) void gemm_f32_reduce1_kernel(const float* __re
     out[i] = s;
 }
 
+// Tail tiles of an NT / NN product (see gemm_tail_plan): sum the `nsplit` K-parts of every tail tile in part order
+// (deterministic) and apply the epilogue of epilogue_f32<ACT> -- the same expressions, so a split tile differs from an
+// unsplit one only by the grouping of its fp32 sum.  One thread = 4 consecutive columns of one row.
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_f32_tail_epilogue_kernel(const GemmF32Args g, const float* __restrict__ ws, int ntail,
+                                                                     int nsplit) {
+    const int tix = blockIdx.x >> 4;                        // 16 blocks of 256 threads per 128 x 128 tile
+    const int e4 = ((blockIdx.x & 15) << 8) + threadIdx.x;  // float4 index inside the tile
+    const int row_t = e4 >> 5, col_t = (e4 & 31) << 2;
+    const int tt = g.tile0 + tix;
+    const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
+    const int row = tm * F_BM + row_t, col = tn * F_BN + col_t;
+    if (row >= g.M || col >= g.N) return;                   // host: N % 4 == 0
+    const float* p = ws + (int64_t)tix * (F_BM * F_BN) + row_t * F_BN + col_t;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    for (int k = 1; k < nsplit; ++k) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p + (int64_t)k * ntail * (F_BM * F_BN));
+        v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    if (ACT != 2 && g.bias) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + col);
+        v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+    }
+    float* cp = g.c + (int64_t)row * g.ldc + col;
+    if (ACT == 0) {
+        if (g.aux) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(g.aux + (int64_t)row * g.ldaux + col);
+            v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
+        }
+        *reinterpret_cast<f32x4*>(cp) = v;
+    } else if (ACT == 1) {
+        f32x4 d, a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float er = erff(v[e] * 0.70710678118654752440f);
+            a[e] = v[e] * 0.5f * (1.0f + er);
+            d[e] = 0.5f * (1.0f + er) + v[e] * (expf(-0.5f * v[e] * v[e]) * 0.39894228040143267794f);
+        }
+        *reinterpret_cast<f32x4*>(g.c2 + (int64_t)row * g.ldc + col) = a;
+        *reinterpret_cast<f32x4*>(cp) = d;
+    } else {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(g.aux + (int64_t)row * g.ldaux + col);
+        v[0] *= x[0]; v[1] *= x[1]; v[2] *= x[2]; v[3] *= x[3];
+        *reinterpret_cast<f32x4*>(cp) = v;
+    }
+}
+
+// Tile quantisation of the NT / NN products (measured, scripts/lab/gemm_tail.py): the chip holds 512 workgroups (two per CU)
+// and a launch's time is a step function of its tile count in units of 256 -- 1182 tiles (every 25 120 x 768 output of the
+// step) cost 2.5 rounds for 2.31 rounds of work.  Plan: the leading multiple of 256 tiles runs as usual; the R remaining tiles
+// are split s ways along K (R * s <= 512, all resident at once) into fp32 slabs, and one small kernel sums the parts in order
+// and applies the epilogue.  Only worth it from s = 3 on (two halves at two per CU take what R tiles at one per CU take).
+struct TailPlan { int ntail, nsplit, kps; };
+static TailPlan gemm_tail_plan(int M, int N, int K) {
+    TailPlan p = {0, 1, 0};
+    if (acr_opt(ACR_OPT_GEMM_F32_NOTAIL) != 0 || (K % F_BK) != 0 || (N % 4) != 0) return p;
+    const int tiles = ((M + F_BM - 1) / F_BM) * ((N + F_BN - 1) / F_BN);
+    const int R = tiles % 256;
+    if (tiles < 512 || R == 0) return p;
+    int s = 512 / R;
+    if (s > 8) s = 8;
+    const int maxs = K / (2 * F_BK);                         // at least two chunks per part
+    if (s > maxs) s = maxs;
+    if (s < 3) return p;
+    const int kps = ((K + s - 1) / s + F_BK - 1) / F_BK * F_BK;
+    s = (K + kps - 1) / kps;                                // every part non-empty
+    if (s < 3) return p;
+    p.ntail = R; p.nsplit = s; p.kps = kps;
+    return p;
+}
+
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // the LDS-DMA kernels address operands with 32-bit element offsets inside one operand
@@ -472,7 +556,10 @@ static TnPlan tn_plan(int M, int N, int K) {
 }
 
 extern "C" size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K) {
-    if (mode != ACR_GEMM_TN) return 0;
+    if (mode != ACR_GEMM_TN) {
+        const TailPlan tp = gemm_tail_plan(M, N, K);
+        return (size_t)tp.ntail * tp.nsplit * (F_BM * F_BN);
+    }
     const TnPlan p = tn_plan(M, N, K);
     return (size_t)p.nsplit * ((size_t)M * N + (size_t)M);
 }
@@ -493,7 +580,8 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
 #endif
     g.tiles_m = (M + F_BM - 1) / F_BM; g.tiles_n = (N + F_BN - 1) / F_BN; g.nsplit = 1; g.kps = (K + F_BK - 1) / F_BK * F_BK;
     g.a_zs = g.b_zs = g.c_zs = g.aux_zs = 0; g.k_zs = g.kps; g.ksplit = 1 << 30;
-    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+    g.tile0 = 0; g.tiles_launch = g.tiles_m * g.tiles_n;
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
     if (mode == ACR_GEMM_TN) {
         // c[M,N] = a[K,M]^T b[K,N]: both operands contraction-strided; M, N are the weight's dims, K the token count
         ACR_CHECK_ARG(act == 0 && !bias && !aux, "acr_gemm_f32: TN takes no epilogue");
@@ -523,6 +611,14 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);           \
     } while (0)
     const bool dma = (K % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && off32_ok(M, N, K, lda, ldb, mode);
+    TailPlan tp = gemm_tail_plan(M, N, K);
+    const bool vec_ok = al16(c) && (ldc % 4) == 0 && (!bias || al16(bias)) && (!aux || (al16(aux) && (ldaux % 4) == 0)) &&
+                        (!c2 || al16(c2));
+    if (!dma || !ws || !al16(ws) || !vec_ok) tp.ntail = 0;
+    if (tp.ntail) {                                         // leading whole half-rounds as usual ...
+        g.tiles_launch -= tp.ntail;
+        grid = dim3((unsigned)g.tiles_launch);
+    }
     if (mode == ACR_GEMM_NT) {
         if (act == 0) ACR_F32_LAUNCH(true, true, 0);
         else if (act == 1) ACR_F32_LAUNCH(true, true, 1);
@@ -533,6 +629,20 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         else ACR_F32_LAUNCH(true, false, 2);
     }
 #undef ACR_F32_LAUNCH
+    if (tp.ntail) {                                         // ... then the tail tiles, K-split into slabs, and their epilogue
+        GemmF32Args gt = g;
+        gt.tile0 = g.tiles_launch; gt.tiles_launch = tp.ntail; gt.nsplit = tp.nsplit; gt.kps = tp.kps; gt.k_zs = tp.kps;
+        gt.c = ws;
+        const dim3 tgrid((unsigned)(tp.ntail * tp.nsplit));
+        if (mode == ACR_GEMM_NT) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 4>), tgrid, dim3(256), 0, st, gt);
+        else hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4>), tgrid, dim3(256), 0, st, gt);
+        GemmF32Args ge = g;
+        ge.tile0 = gt.tile0;
+        const dim3 egrid((unsigned)(tp.ntail * 16));
+        if (act == 0) hipLaunchKernelGGL((gemm_f32_tail_epilogue_kernel<0>), egrid, dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
+        else if (act == 1) hipLaunchKernelGGL((gemm_f32_tail_epilogue_kernel<1>), egrid, dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
+        else hipLaunchKernelGGL((gemm_f32_tail_epilogue_kernel<2>), egrid, dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
+    }
     return acr_check_launch("acr_gemm_f32");
 }
 
@@ -548,6 +658,7 @@ static void conv_args(GemmF32Args& g, int M, int N, int K) {
     g.bias = nullptr; g.aux = nullptr; g.ldaux = 0; g.c2 = nullptr; g.cs = nullptr; g.M = M; g.N = N; g.K = K;
     g.tiles_m = (M + F_BM - 1) / F_BM; g.tiles_n = (N + F_BN - 1) / F_BN; g.kps = (K + F_BK - 1) / F_BK * F_BK; g.k_zs = 0;
     g.a_zs = g.b_zs = g.c_zs = g.aux_zs = 0; g.ksplit = 1;
+    g.tile0 = 0; g.tiles_launch = g.tiles_m * g.tiles_n;
 }
 
 extern "C" int acr_conv1x1_f32(const float* w, int32_t w_transposed, const float* x, const float* addend, float* y, int32_t nsamp,

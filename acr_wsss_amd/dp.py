@@ -32,7 +32,7 @@ class GradSync:
         synchronisation), so a parameter that receives a gradient on some ranks only costs overlap, never a hang.
     ``strict=True`` (or ACR_DP_STRICT=1) turns any disagreement between ranks into an error instead."""
 
-    def __init__(self, params, process_group=None, bucket_mb=64, strict=None):
+    def __init__(self, params, process_group=None, bucket_mb=64, strict=None, always_reduce=False):
         import os
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -79,7 +79,10 @@ class GradSync:
         self._avg = backend == "nccl"                     # RCCL has a native AVG; gloo does not
         self.strict = (os.environ.get("ACR_DP_STRICT") == "1") if strict is None else bool(strict)
         # host-side agreement channel: the data group itself when it is gloo, else a gloo group over the same ranks
-        self._agree = self.world > 1
+        # always_reduce: issue the collectives even in a one-rank group (RCCL smoke tests: the all-reduce of one rank is the
+        # identity, but it goes through the same RCCL launch path)
+        self._collective = self.world > 1 or (always_reduce and dist.is_initialized())
+        self._agree = self._collective
         self._side = process_group                        # None = the default group
         if self._agree and backend != "gloo":
             self._side = dist.new_group(
@@ -115,7 +118,7 @@ class GradSync:
         for p, v in zip(b.params, b.views):
             if p.grad is not None:
                 p.grad = v
-        if self.world > 1:
+        if self._collective:
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
         else:

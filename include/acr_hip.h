@@ -75,6 +75,7 @@ typedef enum acr_option {
     ACR_OPT_GEMM_F32_REGSTAGE = 6, /* 1: acr_gemm_f32 always takes the register-staged kernel (A/B of the LDS-DMA kernel) */
     ACR_OPT_ATTN_F32_GEN1 = 7,  /* 1: fp32 attention on the first-generation (register-staged, 2-wave) kernels */
     ACR_OPT_ATTN_F32_NW = 8,    /* acr_attn_fwd_scores: 5 = five 32-query blocks (waves) per forward workgroup instead of four (A/B: slower) */
+    ACR_OPT_GEMM_F32_NOTAIL = 9, /* 1: acr_gemm_f32 NT / NN never K-splits the tiles beyond the last whole half-round (A/B) */
     ACR_OPT_COUNT_
 } acr_option;
 int     acr_set_option(int32_t option, int32_t value);
@@ -156,7 +157,8 @@ int acr_linear_dgelu_bf16(const void* a, int64_t lda, const void* w, int64_t ldw
  *      place of the pre-activation, the derivative its backward needs (one erff serves both; h itself is used nowhere else);
  *   2: c = acc * aux with aux = the saved GELU'(h) (fc2's input gradient taken through the activation).
  * Pitches in elements, multiples of 4; pointers 16-byte aligned; K %% 4 == 0 (NT/NN), M, N %% 4 == 0 and ldc == N (TN).
- * ws: caller-owned scratch of acr_gemm_f32_ws_floats(mode, M, N, K) floats (0 for NT / NN). */
+ * ws: caller-owned scratch of acr_gemm_f32_ws_floats(mode, M, N, K) floats (TN: the split slabs; NT / NN: slabs for the K-split
+ * tail tiles, 0 when the tile count needs none -- ws may then be NULL; without ws the product runs unsplit). */
 typedef enum acr_gemm_mode { ACR_GEMM_NT = 0, ACR_GEMM_NN = 1, ACR_GEMM_TN = 2 } acr_gemm_mode;
 size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K);
 int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,

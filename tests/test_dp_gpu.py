@@ -81,6 +81,56 @@ def test_two_rank_train_step_matches_single_process():
     assert diff.max() <= 2e-3 * ref.abs().max() and diff.mean() <= 1e-5 * ref.abs().max(), (diff.max(), diff.mean())
 
 
+def _rccl_worker(rank, world, port, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from acr_wsss_amd.dp import GradSync, broadcast_parameters
+    from acr_wsss_amd.train import PolyOptimizer, train_step
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    t = torch.arange(8, dtype=torch.float32, device="cuda:0")
+    dist.all_reduce(t, op=dist.ReduceOp.AVG)                # RCCL's native AVG, the op GradSync uses
+    dist.broadcast(t, src=0)
+    dist.barrier()
+    model = _build()
+    broadcast_parameters(model, 0)
+    sync = GradSync(model.parameters(), bucket_mb=4, always_reduce=True)
+    opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=10)
+    img, label = _batch()
+    for _ in range(2):
+        train_step(model, opt, img.cuda(), label.cuda(), 125, grad_sync=sync)
+    torch.cuda.synchronize()
+    out["t"] = t.cpu()
+    out["params"] = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])
+    out["stats"] = dict(sync.stats)
+    out["backend"] = dist.get_backend()
+    out["nccl"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_group_runs_the_exchange():
+    """The box has ONE GPU, so a real multi-rank RCCL run is the driver's; what CAN run here is RCCL itself: a one-rank
+    `nccl` process group (= RCCL on ROCm) initialised by this code, its AVG all-reduce / broadcast / barrier, and GradSync's
+    bucketed exchange overlapping backward through that backend (the all-reduce of one rank is the identity, so the result
+    must equal a plain single-process run)."""
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    assert out["backend"] == "nccl" and torch.equal(out["t"], torch.arange(8, dtype=torch.float32))
+    assert out["stats"]["steps"] == 2 and out["stats"]["bucket_launches_in_backward"] >= 1 and out["stats"]["rank_disagreements"] == 0
+    print("RCCL %s: one-rank group, %s" % (out["nccl"], out["stats"]))
+    from acr_wsss_amd.train import PolyOptimizer, train_step
+    model = _build()
+    opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=10)
+    img, label = _batch()
+    for _ in range(2):
+        train_step(model, opt, img.cuda(), label.cuda(), 125)
+    ref = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])
+    torch.testing.assert_close(out["params"], ref, rtol=0, atol=0)
+
+
 def test_bench_two_ranks_gloo_rehearsal(tmp_path):
     """bench.py's N > 1 path executed end to end THROUGH ITS SELF-LAUNCH: `python bench.py --gpus 2` with no WORLD_SIZE in the
     environment (the driver's command shape) must start the two ranks itself (child torch.distributed.run, one process per
