@@ -128,7 +128,10 @@ def test_rccl_one_rank_group_runs_the_exchange():
     for _ in range(2):
         train_step(model, opt, img.cuda(), label.cuda(), 125)
     ref = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])
-    torch.testing.assert_close(out["params"], ref, rtol=0, atol=0)
+    # same tolerance as the two-rank test: sign() gradients of the L1 terms amplify last-bit differences between two runs
+    # (MIOpen's patch-embedding weight gradient is not run-to-run deterministic outside cudnn.deterministic mode)
+    diff = (out["params"] - ref).abs()
+    assert diff.max() <= 2e-3 * ref.abs().max() and diff.mean() <= 1e-5 * ref.abs().max(), (diff.max(), diff.mean())
 
 
 def test_bench_two_ranks_gloo_rehearsal(tmp_path):
