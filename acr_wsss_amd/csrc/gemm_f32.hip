@@ -51,6 +51,20 @@ struct GemmF32Args {
 #endif
 };
 
+// Tile order of the NT / NN products: bands of 8 tile rows, column-major inside a band, so that the 64 workgroups an XCD
+// holds at a time (it walks one contiguous range of this order, acr_xcd_remap) form an 8 x 8 block of tiles: 8 + 8 operand
+// panels (6.3 MB at K = 768) per 64 tiles instead of one A panel + ALL B panels per tile row (N = 3072: the 9.4 MB weight
+// exceeds one XCD's 4 MB L2 and was re-fetched for every tile row: 1.04 GB fetched for 86 MB of operands).
+#define F_BAND 8
+__device__ __forceinline__ void tile_coords(int tt, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int per_band = F_BAND * tiles_n;
+    const int band = tt / per_band, in_band = tt - band * per_band;
+    const int first = band * F_BAND;
+    const int rows = min(tiles_m - first, F_BAND);
+    tn = in_band / rows;
+    tm = first + (in_band - tn * rows);
+}
+
 // one K-chunk of one operand, global -> registers (4 float4 per thread), addresses clamped into the matrix so that every
 // load is unconditional and nothing touches the loaded registers before store_chunk (the loads stay in flight across the
 // chunk's MFMAs).  KC: rows = the operand's non-contraction index, k contiguous; KS: rows = k, 128 contiguous elements.
@@ -144,7 +158,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
     const int ntile = g.tiles_launch;
     const int t = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
     const int split = t / ntile, tt = g.tile0 + (t - split * ntile);
-    const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
+    int tm, tn;
+    if (ACT == 3) { tm = tt / g.tiles_n; tn = tt - tm * g.tiles_n; }
+    else tile_coords(tt, g.tiles_m, g.tiles_n, tm, tn);
     const int m0 = tm * F_BM, n0 = tn * F_BN;
     const int zs = split / g.ksplit;
     const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);
@@ -328,7 +344,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
     const int ntile = g.tiles_launch;
     const int t = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
     const int split = t / ntile, tt = g.tile0 + (t - split * ntile);
-    const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
+    int tm, tn;
+    if (ACT == 3) { tm = tt / g.tiles_n; tn = tt - tm * g.tiles_n; }
+    else tile_coords(tt, g.tiles_m, g.tiles_n, tm, tn);
     const int m0 = tm * F_BM, n0 = tn * F_BN;
     const int zs = split / g.ksplit;
     const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);      // host: (kend - kbeg) % F_BK == 0
@@ -464,7 +482,8 @@ __global__ __launch_bounds__(256) void gemm_f32_tail_epilogue_kernel(const GemmF
     const int e4 = ((blockIdx.x & 15) << 8) + threadIdx.x;  // float4 index inside the tile
     const int row_t = e4 >> 5, col_t = (e4 & 31) << 2;
     const int tt = g.tile0 + tix;
-    const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
+    int tm, tn;
+    tile_coords(tt, g.tiles_m, g.tiles_n, tm, tn);
     const int row = tm * F_BM + row_t, col = tn * F_BN + col_t;
     if (row >= g.M || col >= g.N) return;                   // host: N % 4 == 0
     const float* p = ws + (int64_t)tix * (F_BM * F_BN) + row_t * F_BN + col_t;
