@@ -419,6 +419,9 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
     const LaneBases lb = lane_bases(r, h);
     const char* sm = reinterpret_cast<const char*>(smem);
+    int qoff[2], dooff[2];                                   // lane parts of the Q / dO tile DMA source addresses (interior tiles)
+    dma_offsets32(qoff, g.st, wave, lane);
+    dma_offsets32(dooff, g.ost, wave, lane);
     // transposed score reads: lane (kappa = r, h): byte address = tb[reg & 3] + slot*4096 + 128*(reg >> 2)
     int tb[4];
     {
@@ -433,8 +436,13 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         acr_dma_barrier();
         __builtin_amdgcn_s_setprio(2);
         if (q0 + 32 < g.T) {
-            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS, qb, g.st, q0 + 32, g.T, wave, lane);
-            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, dob, g.ost, q0 + 32, g.T, wave, lane);
+            if (q0 + 64 <= g.T) {                          // next tile fully inside: precomputed lane offsets, uniform base
+                dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, qb + (int64_t)(q0 + 32) * g.st, qoff, wave);
+                dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, dob + (int64_t)(q0 + 32) * g.ost, dooff, wave);
+            } else {
+                dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS, qb, g.st, q0 + 32, g.T, wave, lane);
+                dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, dob, g.ost, q0 + 32, g.T, wave, lane);
+            }
             if (wave == 0) dma_rowconst(rc + (SLOT ^ 1) * 64, lrow, drow, q0 + 32, g.T, lane);
             if (live) dma_scores((q0 >> 5) + 1, SLOT ^ 1);
         }
