@@ -183,3 +183,23 @@ __device__ __forceinline__ void dma_tile32_nw_i(float* lds, const float* __restr
             __builtin_amdgcn_global_load_lds((glb_vp)(row0ptr + off[i]), (lds_vp)(lds + piece * 256), 16, 0, 0);
     }
 }
+
+// ONE wave DMAs a whole 32-row tile (8 pieces) into its private LDS image (split-tail workgroups: every wave has its own stream)
+__device__ __forceinline__ void dma_tile32_one(float* lds, const float* __restrict__ g, int64_t st, int row0, int Tn, int lane) {
+#pragma unroll
+    for (int piece = 0; piece < 8; ++piece) {
+        const int row = piece * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ (row & 15);
+        const float* src = g + (int64_t)min(row0 + row, Tn - 1) * st + c * 4;
+        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds + piece * 256), 16, 0, 0);
+    }
+}
+// lane bases shifted by a (wave-dependent) byte offset: the *_i walks can then take TILE_OFF = 0 on a private tile
+__device__ __forceinline__ LaneBases lane_bases_at(int r, int h, int byte_off) {
+    LaneBases lb = lane_bases(r, h);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lb.rowb[i] += byte_off;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lb.colb[c] += byte_off;
+    return lb;
+}
