@@ -380,6 +380,11 @@ def infer_record(args, dev, with_cpu):
         with open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")) as f:
             layout = json.load(f)
         sd = recipe_state_dict(layout, 0)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        torch.set_num_threads(max(1, min(16, avail)))          # the GPU box's CPU share is 16 per GPU
         t0 = time.time()
         O.infer_image(sd, O.HYBRID_BASE, img.cpu(), lab, out_hw, start_layer=10, func="grad", aff=True, scales=(1,))
         tc = time.time() - t0
