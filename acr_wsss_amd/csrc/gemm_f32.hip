@@ -42,7 +42,6 @@ struct GemmF32Args {
     int M, N, K;
     int tiles_m, tiles_n, nsplit, kps;   // kps: contraction elements per split (multiple of F_BK)
     int tile0, tiles_launch;             // this launch covers tiles tile0 .. tile0 + tiles_launch - 1 (each nsplit times)
-    int vec_epi;                         // 1: c / c2 / aux / bias are 16-byte aligned with pitches % 4 == 0 (interior tiles: epilogue_f32_vec)
     // z-slices: workgroup slice z = split index.  K-split (weight gradient of a Linear): operands shared, k range z*k_zs..;
     // batch (1x1 convolutions per sample): operands / outputs advance by *_zs per slice, k range the whole contraction
     int64_t a_zs, b_zs, c_zs, aux_zs;
@@ -146,57 +145,6 @@ __device__ __forceinline__ void epilogue_f32(const GemmF32Args& g, f32x16 (&acc)
                     *cp = v * x[e];
                 }
             }
-        }
-    }
-}
-
-// The same epilogue for an interior tile with 16-byte accesses.  In the accumulator layout a lane owns one COLUMN (4-byte
-// stores, 64 per wave, two 128-byte row pieces each): the epilogue of a round of 512 workgroups is store-ISSUE bound (~36 us
-// per round measured as the K-independent part of a launch, a third of a K = 768 product).  Here the wave's 64 x 64 block goes
-// through its quarter of the (now idle) operand LDS once -- 64 ds_write_b32 in accumulator order, 16 ds_read_b128 in row
-// order -- and leaves as 16 global_store_dwordx4 of four 256-byte row pieces each; addend / saved activation come in the
-// same shape.  Same expressions, same results as epilogue_f32.
-template <int ACT>
-__device__ __forceinline__ void epilogue_f32_vec(const GemmF32Args& g, f32x16 (&acc)[2][2], float* __restrict__ lds, int mb, int nb,
-                                                 int lane) {
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) lds[(i * 32 + acr_krow(e, h)) * 64 + j * 32 + r] = acc[i][j][e];
-    // same wave writes and reads: LDS operations of one wave execute in order; the compiler must not move the reads up
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int c4 = (lane & 15) * 4, r0 = lane >> 4;
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (ACT != 2 && g.bias) b4 = *reinterpret_cast<const f32x4*>(g.bias + nb + c4);
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + r0;
-        f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * 64 + c4);
-        const int64_t off = (int64_t)(mb + row) * g.ldc + nb + c4;
-        v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
-        if (ACT == 0) {
-            if (g.aux) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(g.aux + (int64_t)(mb + row) * g.ldaux + nb + c4);
-                v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
-            }
-            *reinterpret_cast<f32x4*>(g.c + off) = v;
-        } else if (ACT == 1) {
-            f32x4 d, a;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float er = erff(v[e] * 0.70710678118654752440f);
-                a[e] = v[e] * 0.5f * (1.0f + er);
-                d[e] = 0.5f * (1.0f + er) + v[e] * (expf(-0.5f * v[e] * v[e]) * 0.39894228040143267794f);
-            }
-            *reinterpret_cast<f32x4*>(g.c2 + off) = a;
-            *reinterpret_cast<f32x4*>(g.c + off) = d;
-        } else {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(g.aux + (int64_t)(mb + row) * g.ldaux + nb + c4);
-            v[0] *= x[0]; v[1] *= x[1]; v[2] *= x[2]; v[3] *= x[3];
-            *reinterpret_cast<f32x4*>(g.c + off) = v;
         }
     }
 }
@@ -329,14 +277,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
     GemmF32Args gz = g;                                     // this slice's output / addend
     gz.c += (int64_t)zs * g.c_zs;
     if (gz.aux) gz.aux += (int64_t)zs * g.aux_zs;
-    if (m0 + F_BM <= g.M && n0 + F_BN <= g.N) {
-        if (ACT <= 2 && g.vec_epi)                          // all fragment reads are behind the loop's last barrier: LDS is free
-            epilogue_f32_vec<(ACT <= 2 ? ACT : 0)>(gz, acc, smem + wave * 4096, m0 + wm * 64, n0 + wn * 64, lane);
-        else
-            epilogue_f32<ACT, false>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
-    } else {
+    if (m0 + F_BM <= g.M && n0 + F_BN <= g.N)
+        epilogue_f32<ACT, false>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+    else
         epilogue_f32<ACT, true>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
-    }
 }
 
 
@@ -500,14 +444,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
     GemmF32Args gz = g;
     gz.c += (int64_t)zs * g.c_zs;
     if (gz.aux) gz.aux += (int64_t)zs * g.aux_zs;
-    if (m0 + F_BM <= g.M && n0 + F_BN <= g.N) {
-        if (ACT <= 2 && g.vec_epi)                          // all fragment reads are behind the loop's last barrier: LDS is free
-            epilogue_f32_vec<(ACT <= 2 ? ACT : 0)>(gz, acc, smem + wave * 4096, m0 + wm * 64, n0 + wn * 64, lane);
-        else
-            epilogue_f32<ACT, false>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
-    } else {
+    if (m0 + F_BM <= g.M && n0 + F_BN <= g.N)
+        epilogue_f32<ACT, false>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+    else
         epilogue_f32<ACT, true>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
-    }
 }
 
 // out[i] = sum_s slab[s][i] in split order (deterministic), float4 per thread; n4 = elements / 4
@@ -660,8 +600,6 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
     g.tiles_m = (M + F_BM - 1) / F_BM; g.tiles_n = (N + F_BN - 1) / F_BN; g.nsplit = 1; g.kps = (K + F_BK - 1) / F_BK * F_BK;
     g.a_zs = g.b_zs = g.c_zs = g.aux_zs = 0; g.k_zs = g.kps; g.ksplit = 1 << 30;
     g.tile0 = 0; g.tiles_launch = g.tiles_m * g.tiles_n;
-    g.vec_epi = (acr_opt(ACR_OPT_GEMM_F32_SCALAR_EPI) == 0 && al16(c) && (ldc % 4) == 0 && (!bias || al16(bias)) &&
-                 (!aux || (al16(aux) && (ldaux % 4) == 0)) && (!c2 || al16(c2))) ? 1 : 0;
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
     if (mode == ACR_GEMM_TN) {
         // c[M,N] = a[K,M]^T b[K,N]: both operands contraction-strided; M, N are the weight's dims, K the token count
@@ -740,7 +678,6 @@ static void conv_args(GemmF32Args& g, int M, int N, int K) {
     g.tiles_m = (M + F_BM - 1) / F_BM; g.tiles_n = (N + F_BN - 1) / F_BN; g.kps = (K + F_BK - 1) / F_BK * F_BK; g.k_zs = 0;
     g.a_zs = g.b_zs = g.c_zs = g.aux_zs = 0; g.ksplit = 1;
     g.tile0 = 0; g.tiles_launch = g.tiles_m * g.tiles_n;
-    g.vec_epi = 0;
 }
 
 extern "C" int acr_conv1x1_f32(const float* w, int32_t w_transposed, const float* x, const float* addend, float* y, int32_t nsamp,

@@ -77,7 +77,6 @@ typedef enum acr_option {
     ACR_OPT_ATTN_F32_NW = 8,    /* acr_attn_fwd_scores: 5 = five 32-query blocks (waves) per forward workgroup instead of four (A/B: slower) */
     ACR_OPT_GEMM_F32_NOTAIL = 9, /* 1: acr_gemm_f32 NT / NN never K-splits the tiles beyond the last whole half-round (A/B) */
     ACR_OPT_ATTN_F32_NOSPLITTAIL = 10, /* 1: resident-score attention keeps the leftover 32-row block as an ordinary (1 live wave) workgroup (A/B) */
-    ACR_OPT_GEMM_F32_SCALAR_EPI = 11, /* 1: acr_gemm_f32 NT / NN epilogues store 4 bytes per lane in accumulator order (A/B of the LDS-transposed 16-byte form) */
     ACR_OPT_COUNT_
 } acr_option;
 int     acr_set_option(int32_t option, int32_t value);
