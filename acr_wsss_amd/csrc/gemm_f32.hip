@@ -335,9 +335,20 @@ __device__ __forceinline__ f32x4 dma_frag(const float* __restrict__ s, int base,
     return v;
 }
 
+#ifdef LAB_TL                      // lab builds only (scripts/lab/gemm_timeline.py): wall-clock timeline of every workgroup
+__device__ unsigned long long g_lab_tl[4 * 16384];
+extern "C" int acr_lab_tl_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_tl), (size_t)n * 8);
+}
+#define LAB_TL_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_lab_tl[4 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LAB_TL_STAMP(i) do { } while (0)
+#endif
+
 template <bool A_KC, bool B_KC, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args g) {
     __shared__ __attribute__((aligned(1024))) float smem[4 * F_DTILE];      // [A0 | B0 | A1 | B1]
+    LAB_TL_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
@@ -372,6 +383,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
     dma_chunk(smem, pa + kbeg * ka, offa, wave);
     dma_chunk(smem + F_DTILE, pb + kbeg * kb, offb, wave);
     acr_dma_barrier();
+    LAB_TL_STAMP(1);
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += F_BK, cur ^= 1) {
         if (k0 + F_BK < kend) {
@@ -402,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
         }
         acr_dma_barrier();                                  // the chunk in flight has landed; buffer `cur` is free
     }
+    LAB_TL_STAMP(2);
 #ifdef LAB_STAMP
     if (tid == 0 && g.stamp) {
         g.stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0;
@@ -448,6 +461,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
         epilogue_f32<ACT, false>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
     else
         epilogue_f32<ACT, true>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+#ifdef LAB_TL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LAB_TL_STAMP(3);
+#endif
 }
 
 // out[i] = sum_s slab[s][i] in split order (deterministic), float4 per thread; n4 = elements / 4

@@ -12,6 +12,7 @@ def t(fn, it=10):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / it
 M = 25120
+OPT = sys.argv[1] if len(sys.argv) > 1 else "notail"      # the option switched off (1) / on (0): notail | scalar_epi
 torch.manual_seed(0)
 for name, N, K, act in (("qkv", 2304, 768, 0), ("proj", 768, 768, 0), ("fc1+gelu", 3072, 768, 1), ("fc2", 768, 3072, 0),
                         ("fc1 dx", 768, 3072, 0), ("fc2 dx*gelu'", 3072, 768, 2), ("qkv dx", 768, 2304, 0)):
@@ -19,7 +20,7 @@ for name, N, K, act in (("qkv", 2304, 768, 0), ("proj", 768, 768, 0), ("fc1+gelu
     aux = torch.randn(M, N, device=dev) if act != 1 else None
     outs = {}
     for notail in (1, 0):
-        _lib.set_option("gemm_f32_notail", notail)
+        _lib.set_option("gemm_f32_" + OPT, notail)
         y = torch.empty(M, N, device=dev); y2 = torch.empty(M, N, device=dev) if act == 1 else None
         fn = lambda: ops.gemm_f32_raw("nt", x, w, y, bias=None if act == 2 else b, aux=aux, act=act, c2=y2)
         ms = t(fn)
@@ -28,5 +29,5 @@ for name, N, K, act in (("qkv", 2304, 768, 0), ("proj", 768, 768, 0), ("fc1+gelu
     d = float((outs[0][1] - outs[1][1]).abs().max())
     d2 = float((outs[0][2] - outs[1][2]).abs().max()) if act == 1 else 0.0
     fl = 2.0 * M * N * K
-    print("%-14s N %4d K %4d: %4d tiles (%.2f rounds, tail %3d)  unsplit %.3f ms %.1f TF   tail-split %.3f ms %.1f TF   max|diff| %.2e %.2e (|y| %.1f)" % (
+    print("%-14s N %4d K %4d: %4d tiles (%.2f rounds, tail %3d)  option=1 %.3f ms %.1f TF   option=0 %.3f ms %.1f TF   max|diff| %.2e %.2e (|y| %.1f)" % (
         name, N, K, tiles, tiles / 512, tiles % 256, outs[1][0], fl / outs[1][0] / 1e9, outs[0][0], fl / outs[0][0] / 1e9, d, d2, float(outs[1][1].abs().max())), flush=True)
