@@ -29,6 +29,24 @@
 
 #define SB_FLOATS 1024
 
+#ifdef LAB_TL                      // lab builds only (scripts/lab/attn_bwd_phases.py): per-phase cycle sums of every wave 0
+__device__ unsigned long long g_lab_attn[8 * 16384];
+extern "C" int acr_lab_attn_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_attn), (size_t)n * 8);
+}
+#define LAB_T() __builtin_amdgcn_s_memtime()
+#define LAB_DECL unsigned long long lt_[6] = {0, 0, 0, 0, 0, 0}, lp_ = 0; (void)lp_
+#define LAB_MARK() (lp_ = LAB_T())
+#define LAB_ADD(i) do { const unsigned long long n_ = LAB_T(); lt_[i] += n_ - lp_; lp_ = n_; } while (0)
+#define LAB_OUT(kind, nsteps) do { if (threadIdx.x == 0 && blockIdx.x < 16384) { unsigned long long* d_ = g_lab_attn + 8 * blockIdx.x; \
+        for (int i_ = 0; i_ < 6; ++i_) d_[i_] = lt_[i_]; d_[6] = (nsteps); d_[7] = (kind); } } while (0)
+#else
+#define LAB_DECL
+#define LAB_MARK()
+#define LAB_ADD(i)
+#define LAB_OUT(kind, nsteps)
+#endif
+
 __device__ __forceinline__ int64_t sres_block(const AttnGeom& g, int NB, int b, int hd, int qb, int kb) {
     return ((((int64_t)b * g.H + hd) * NB + qb) * NB + kb) * SB_FLOATS;
 }
@@ -434,10 +452,13 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk
         }
     };
     if (live) load_sg(0, sbuf[0], gbuf[0]);
+    LAB_DECL;
     auto step = [&](int k0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int KOFF = SLOT * 2 * DT_FLOATS * 4, VOFF = KOFF + DT_FLOATS * 4;
+        LAB_MARK();
         acr_dma_barrier();
+        LAB_ADD(0);
         __builtin_amdgcn_s_setprio(2);
         if (k0 + 64 <= g.T) {
             dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb + (int64_t)(k0 + 32) * g.st, doff, wave);
@@ -449,8 +470,13 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk
         if (!live) { __builtin_amdgcn_s_setprio(0); return; }
         if (k0 + 32 < g.T) load_sg(k0 + 32, sbuf[SLOT ^ 1], gbuf[SLOT ^ 1]);
         __builtin_amdgcn_s_setprio(0);
+        LAB_ADD(1);
         f32x16 dp = {0};
         rowop_i<VOFF>(dp, sm, lb, doreg);                  // dP^T[key = krow][query = r]
+#ifdef LAB_TL
+        asm volatile("" :: "v"(dp[15]));
+#endif
+        LAB_ADD(2);
         f32x16 ds;
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
@@ -459,13 +485,19 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk
             ds[reg] = __builtin_amdgcn_exp2f(sbuf[SLOT][reg >> 2][reg & 3] - l2q) * (dp[reg] + gv - dl);
         }
         __builtin_amdgcn_s_setprio(0);
+        LAB_ADD(3);
         accop_a_i<KOFF, 0>(dq0, ds, sm, lb);               // dQ[query = krow][d = 32*blk + r]
         accop_a_i<KOFF, 1>(dq1, ds, sm, lb);
+#ifdef LAB_TL
+        asm volatile("" :: "v"(dq0[15]), "v"(dq1[15]));
+#endif
+        LAB_ADD(4);
     };
     for (int k0 = 0; k0 < g.T; k0 += 64) {
         step(k0, std::integral_constant<int, 0>{});
         if (k0 + 32 < g.T) step(k0 + 32, std::integral_constant<int, 1>{});
     }
+    LAB_OUT(1, (g.T + 31) >> 5);
     if (!live) return;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -544,10 +576,31 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         for (int j = 0; j < 4; ++j) tb[j] = ((wave * 2 * SB_FLOATS) + gk * 256 + 128 * hk + ek + 4 * ((j + 4 * h) ^ mm)) * 4;
     }
     const char* ssb = reinterpret_cast<const char*>(ssm);
+    float gbuf[2][16];                                      // [ring slot][register]: raw G[b][q0 + krow][key]
+    auto load_g = [&](int q0, float (&gv)[16]) {
+        if (gb0 == nullptr) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = 0.f;
+        } else if (q0 + 32 <= g.T) {                       // uniform row pointer + lane offset (saddr form loads)
+            const float* gq0 = gb0 + (int64_t)q0 * gm_st;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int c_reg = (reg & 3) + 8 * (reg >> 2);
+                gv[reg] = (gq0 + (int64_t)c_reg * gm_st)[glane];
+            }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = gb0[(int64_t)min(q0 + acr_krow(reg, h), g.T - 1) * gm_st + gcl];
+        }
+    };
+    if (live) load_g(0, gbuf[0]);
+    LAB_DECL;
     auto step = [&](int q0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int QOFF = SLOT * 2 * DT_FLOATS * 4, DOOFF = QOFF + DT_FLOATS * 4;
+        LAB_MARK();
         acr_dma_barrier();
+        LAB_ADD(0);
         __builtin_amdgcn_s_setprio(2);
         if (q0 + 32 < g.T) {
             if (q0 + 64 <= g.T) {                          // next tile fully inside: precomputed lane offsets, uniform base
@@ -563,23 +616,17 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         __builtin_amdgcn_s_setprio(0);
         if (!live) return;
         const float* rcs = rc + SLOT * 64;
-        float gv[16];
-        if (gb0 == nullptr) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) gv[reg] = 0.f;
-        } else if (q0 + 32 <= g.T) {                       // uniform row pointer + lane offset (saddr form loads)
-            const float* gq0 = gb0 + (int64_t)q0 * gm_st;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int c_reg = (reg & 3) + 8 * (reg >> 2);
-                gv[reg] = (gq0 + (int64_t)c_reg * gm_st)[glane] * invH;
-            }
-        } else {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) gv[reg] = gb0[(int64_t)min(q0 + acr_krow(reg, h), g.T - 1) * gm_st + gcl] * invH;
-        }
+        // G of the NEXT query block goes in flight now and is consumed a whole step later: consumed in the step that issues
+        // it, the 16 loads stall the wave for their full latency under the score stream's HBM load -- 10.4k of a 21.6k-cycle
+        // step (scripts/lab/attn_bwd_phases.py, profiles/r03_attn_bwd_phases.txt)
+        if (q0 + 32 < g.T) load_g(q0 + 32, gbuf[SLOT ^ 1]);
+        LAB_ADD(1);
         f32x16 dp = {0};
         rowop_i<DOOFF>(dp, sm, lb, vreg);                  // dP[query = krow][key = r]
+#ifdef LAB_TL
+        asm volatile("" :: "v"(dp[15]));
+#endif
+        LAB_ADD(2);
         f32x16 s;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
@@ -600,19 +647,25 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
                 const int reg = 4 * gq + e;
                 const float pv = __builtin_amdgcn_exp2f(s[reg] - l4[e]);
                 p[reg] = pv;
-                ds[reg] = pv * (dp[reg] + gv[reg] - d4[e]);
+                ds[reg] = pv * (dp[reg] + gbuf[SLOT][reg] * invH - d4[e]);
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        LAB_ADD(3);
         accop_a_i<DOOFF, 0>(dv0, p, sm, lb);               // dV[key = krow][d = 32*blk + r]
         accop_a_i<DOOFF, 1>(dv1, p, sm, lb);
         accop_a_i<QOFF, 0>(dk0, ds, sm, lb);
         accop_a_i<QOFF, 1>(dk1, ds, sm, lb);
+#ifdef LAB_TL
+        asm volatile("" :: "v"(dv0[15]), "v"(dv1[15]), "v"(dk0[15]), "v"(dk1[15]));
+#endif
+        LAB_ADD(4);
     };
     for (int q0 = 0; q0 < g.T; q0 += 64) {
         step(q0, std::integral_constant<int, 0>{});
         if (q0 + 32 < g.T) step(q0 + 32, std::integral_constant<int, 1>{});
     }
+    LAB_OUT(2, (g.T + 31) >> 5);
     if (!live) return;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
