@@ -187,10 +187,14 @@ extern "C" int acr_layernorm_bwd_bf16(const void* dy, const void* x, const void*
     return acr_check_launch("acr_layernorm_bwd_bf16");
 }
 
+static bool ln_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }      // null (optional operand) passes
+
 // ---- fp32 rows (reference precision): the same kernels on float tensors; vision_transformer.py:219-222 in the fp32 step ----
 extern "C" int acr_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* stats, int32_t M,
                                      int32_t C, float eps, void* stream) {
     ACR_CHECK_ARG(x && gamma && beta && y && stats, "acr_layernorm_fwd_f32: null pointer");
+    ACR_CHECK_ARG(ln_al16(x) && ln_al16(gamma) && ln_al16(beta) && ln_al16(y),
+                  "acr_layernorm_fwd_f32: x / gamma / beta / y must be 16-byte aligned (vector loads and stores)");
     int rc = ln_check("acr_layernorm_fwd_f32", M, C);
     if (rc) return rc;
     const dim3 grid(ln_grid(M));
@@ -202,6 +206,8 @@ extern "C" int acr_layernorm_fwd_f32(const float* x, const float* gamma, const f
 extern "C" int acr_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* stats, const float* dskip,
                                      float* dx, float* ws, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream) {
     ACR_CHECK_ARG(dy && x && gamma && stats && dx && ws && dgamma && dbeta, "acr_layernorm_bwd_f32: null pointer");
+    ACR_CHECK_ARG(ln_al16(dy) && ln_al16(x) && ln_al16(gamma) && ln_al16(dskip) && ln_al16(dx),
+                  "acr_layernorm_bwd_f32: dy / x / gamma / dskip / dx must be 16-byte aligned (vector loads and stores)");
     int rc = ln_check("acr_layernorm_bwd_f32", M, C);
     if (rc) return rc;
     const dim3 grid(ln_grid(M));

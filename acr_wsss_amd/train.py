@@ -84,7 +84,8 @@ class PolyOptimizer(torch.optim.SGD):
         lib = L.load()
         ps = self.param_groups[0]["params"]
         dev = ps[0].device
-        if getattr(self, "_f_n", None) != len(ps):
+        sizes = tuple(p.numel() for p in ps)                 # the chunk table depends on every tensor's size, not just their count
+        if getattr(self, "_f_sizes", None) != sizes:
             chunk = lib.acr_sgd_chunk_elems()
             bt, bc = [], []
             for i, p in enumerate(ps):
@@ -96,26 +97,29 @@ class PolyOptimizer(torch.optim.SGD):
             self._f_host = torch.zeros((len(ps), 5), dtype=torch.int64).pin_memory()
             self._f_tab = torch.zeros((len(ps), 5), dtype=torch.int64, device=dev)
             self._f_evt = None
-            self._f_n = len(ps)
+            self._f_sizes = sizes
         if self._f_evt is not None:
             self._f_evt.synchronize()                      # the previous step's copy of the pinned table (long done)
         moms = []
         for p in ps:                                       # every column from the live tensors: nothing stale survives a
-            st = self.state[p]                             # load_state_dict or a re-allocated gradient
+            if p.grad is None:                             # load_state_dict or a re-allocated gradient
+                moms.append(0)                             # torch.optim.SGD skips gradient-less parameters entirely: no state
+                continue                                   # entry for them (the kernel skips a zero gradient pointer)
+            st = self.state[p]
             buf = st.get("momentum_buffer")
             if buf is None:
                 buf = st["momentum_buffer"] = torch.zeros_like(p)      # mu * 0 + g == torch's first-step clone(g)
-            moms.append(buf)
+            moms.append(buf.data_ptr())
         hn = self._f_host.numpy()
         hn[:, 0] = [0 if p.grad is None else p.grad.data_ptr() for p in ps]
         hn[:, 1] = [p.data_ptr() for p in ps]
-        hn[:, 2] = [b.data_ptr() for b in moms]
-        hn[:, 4] = [p.numel() for p in ps]
-        self._f_tab.copy_(self._f_host, non_blocking=True)
-        self._f_evt = torch.cuda.Event()
-        self._f_evt.record()
+        hn[:, 2] = moms
+        hn[:, 4] = sizes
         grp = self.param_groups[0]
         with torch.cuda.device(dev):
+            self._f_tab.copy_(self._f_host, non_blocking=True)
+            self._f_evt = torch.cuda.Event()
+            self._f_evt.record()
             L.check(lib.acr_sgd_step_f32(L.ptr(self._f_tab), L.ptr(self._f_bt), L.ptr(self._f_bc), self._f_bt.numel(), float(grp["lr"]),
                                          float(grp["momentum"]), L.stream_ptr()), "acr_sgd_step_f32")
         # the kernel changed the parameters behind autograd's back: move their version counters on, as the stock in-place

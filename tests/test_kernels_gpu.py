@@ -211,6 +211,28 @@ def test_errors_are_loud():
     lib = _lib.load()
     rc = lib.acr_consistency_fwd(None, None, 0, 1, 1, 5, 2, None, None, None)
     assert rc < 0 and b"null" in lib.acr_last_error()
+    # a direct C-ABI caller handing an offset (4-byte aligned) view to a kernel that moves 16 bytes per lane gets an error,
+    # not a GPU memory fault (the fp32 LayerNorm entry points did not check)
+    M, C = 8, 768
+    buf = torch.randn(M * C + 4, device=dev)
+    x, xo = buf[:M * C], buf[1:M * C + 1]
+    gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    y, stats = torch.empty(M * C, device=dev), torch.empty(2 * M, device=dev)
+    st = _lib.stream_ptr()
+    assert lib.acr_layernorm_fwd_f32(_lib.ptr(x), _lib.ptr(gam), _lib.ptr(bet), _lib.ptr(y), _lib.ptr(stats), M, C, 1e-6, st) == 0
+    rc = lib.acr_layernorm_fwd_f32(_lib.ptr(xo), _lib.ptr(gam), _lib.ptr(bet), _lib.ptr(y), _lib.ptr(stats), M, C, 1e-6, st)
+    assert rc < 0 and b"aligned" in lib.acr_last_error()
+    ws = torch.empty(lib.acr_layernorm_ws_floats(M, C), device=dev)
+    dg, db, dx = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(M * C, device=dev)
+    rc = lib.acr_layernorm_bwd_f32(_lib.ptr(xo), _lib.ptr(x), _lib.ptr(gam), _lib.ptr(stats), None, _lib.ptr(dx), _lib.ptr(ws),
+                                   _lib.ptr(dg), _lib.ptr(db), M, C, st)
+    assert rc < 0 and b"aligned" in lib.acr_last_error()
+    # the resident-score attention is an fp32 entry point: other dtypes are refused, not reinterpreted
+    d = ops._desc(1, 1, 5, torch.bfloat16)
+    q = torch.zeros(5 * 192, device=dev)
+    rc = lib.acr_attn_fwd_scores(d, _lib.ptr(q), _lib.ptr(q), _lib.ptr(q), _lib.ptr(q), _lib.ptr(q), _lib.ptr(q), None, 0, 0, st)
+    assert rc == -3 and b"fp32" in lib.acr_last_error()
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("M,N,K,bias,resid", [(1, 128, 64, True, False), (130, 200, 128, True, True),
