@@ -28,6 +28,9 @@ HYBRID_BASE = dict(embed_dim=768, depth=12, heads=12, hybrid=True, patch=16, sta
 # token (start_index 2, models/vision_transformer.py:466-472)
 DEIT_DISTILLED = dict(embed_dim=768, depth=12, heads=12, hybrid=False, patch=16, start_index=2, distilled=True,
                       prefix="pretrained.model.")
+# the plain-ViT backbones of DPT/ACR.py:155-160: 'vitb' / 'deit' (vitb16_384, deitb16_384: identical encoders) and 'vitl'
+VIT_BASE = dict(embed_dim=768, depth=12, heads=12, hybrid=False, patch=16, start_index=1, prefix="pretrained.model.")
+VIT_LARGE = dict(embed_dim=1024, depth=24, heads=16, hybrid=False, patch=16, start_index=1, prefix="pretrained.model.")
 VIT_TINY = dict(embed_dim=192, depth=12, heads=3, hybrid=False, patch=16, start_index=1,
                 prefix="pretrained.model.")
 

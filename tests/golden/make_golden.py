@@ -334,7 +334,7 @@ def main():
     from DPT.ACR import ACR
 
     which = set(sys.argv[1:]) or {"layout", "hyb64", "hyb96", "tiny224", "infer64", "infer96", "hyb448", "infer384", "ms96", "ms384",
-                                  "coco512", "distil96"}
+                                  "coco512", "distil96", "layouts"}
 
     model = ACR(num_classes=20, backbone_name="vitb_hybrid", use_pretrain=False)
     if "layout" in which:
@@ -385,6 +385,15 @@ def main():
         fill_state_dict(dist_model, seed=0)
         run_getam_case("getam_distil_96", dist_model, 96, 13, [3, 11])
         del dist_model
+
+    if "layouts" in which:           # state-dict layouts (key -> shape) of the other backbones of DPT/ACR.py:155-160: data only
+        for name in ("vitb", "deit", "vitl"):
+            mdl = ACR(num_classes=20, backbone_name=name, use_pretrain=False)
+            layout = {k: list(v.shape) for k, v in mdl.state_dict().items()}
+            with open(os.path.join(HERE, "state_dict_layout_%s.json" % name), "w") as f:
+                json.dump(layout, f, indent=0)
+            print("layout %s: %d tensors, %.1f M params" % (name, len(layout), sum(v.numel() for v in mdl.state_dict().values()) / 1e6))
+            del mdl
 
     if "tiny224" in which:
         tiny = build_tiny(20)

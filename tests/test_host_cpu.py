@@ -315,7 +315,8 @@ def test_bench_self_launch_builds_the_drivers_command(monkeypatch, capsys):
     assert bench.self_launch(args) == 3
 
 
-@pytest.mark.parametrize("backbone,layout", [("vitb_hybrid", "state_dict_layout.json"), ("deit_distilled", "state_dict_layout_distil.json")])
+@pytest.mark.parametrize("backbone,layout", [("vitb_hybrid", "state_dict_layout.json"), ("deit_distilled", "state_dict_layout_distil.json"),
+                                             ("vitb", "state_dict_layout_vitb.json"), ("deit", "state_dict_layout_deit.json")])
 def test_state_dict_layout_equals_the_references(backbone, layout):
     """ACR(...).state_dict() has the reference model's keys and shapes, key for key (layouts dumped from the reference's own
     ACR by tests/golden/make_golden.py): hybrid-base = 315 tensors; deit_distilled = 176 incl. dist_token / head_dist and the
