@@ -118,8 +118,12 @@ class AttnCoreFn(Function):
         # fp32 with a backward to come: keep the scaled logits resident (983 MB per layer at 32 views x 12 heads x 785 tokens;
         # the card has 288 GB) -- the head mean and the backward sweeps stream them back instead of recomputing q.k on the
         # fp32 MFMA (csrc/attn_f32_sres.hip)
+        # (also without a backward when the head mean is asked for -- CAM generation below its start layer: storing the
+        # logits once and streaming them into the head mean beats the recompute generation's second q.k product; the buffer
+        # is then a temporary)
         scores = None
-        if ATTN_F32_SCORES and qkv.dtype == torch.float32 and ctx.needs_input_grad[0]:
+        keep_scores = ctx.needs_input_grad[0]
+        if ATTN_F32_SCORES and qkv.dtype == torch.float32 and (keep_scores or pm is not None):
             scores = torch.empty(lib.acr_attn_scores_floats(d), dtype=torch.float32, device=qkv.device)
         tok = _t0("attn_fwd" if pm is not None else "attn_fwd_nomean", B, heads, T)
         pm_sb, pm_st = (pm.stride(0), pm.stride(1)) if pm is not None else (0, 0)
@@ -130,7 +134,7 @@ class AttnCoreFn(Function):
             L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm), pm_sb, pm_st, L.stream_ptr()),
                     "acr_attn_fwd")
         _t1(tok)
-        if scores is not None:
+        if scores is not None and keep_scores:
             ctx.save_for_backward(qkv, o, lse2, scores)
         else:
             ctx.save_for_backward(qkv, o, lse2)
