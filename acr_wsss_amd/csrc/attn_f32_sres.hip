@@ -28,6 +28,16 @@
 #include "attn_f32_tiles.h"
 
 #define SB_FLOATS 1024
+// Cache policy of the score stream.  Every byte of `scores` is written once and read once per consumer, 983 MB per layer
+// against 4 MB of L2 per XCD and 256 MB of Infinity Cache.  Measured per kernel (scripts/lab/attn_gen.py with lab builds):
+// nontemporal loads take the head-mean stream from 235 to 183 us and the dQ body's loads the backward from 1549 to 1535 us;
+// nontemporal stores the forward from 580 to 567 us; the row-term stream gets 5 % SLOWER with them (its G rows want to stay
+// cached beside the scores) and the dK/dV body's LDS-DMA with the nt policy (aux = 2) is within noise: both keep the default.
+#define SRES_LOAD_NT(p) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p))
+#define SRES_LOAD(p) (*reinterpret_cast<const f32x4*>(p))
+#define SRES_STORE(p, v) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p))
+#define SRES_LOAD_DQ(p) SRES_LOAD_NT(p)
+#define SRES_DMA_AUX 0
 
 #ifdef LAB_TL                      // lab builds only (scripts/lab/attn_bwd_phases.py): per-phase cycle sums of every wave 0
 __device__ unsigned long long g_lab_attn[8 * 16384];
@@ -100,7 +110,7 @@ __device__ __forceinline__ void attn_fwd_tail_body(float* smem, float* mlsh, con
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const f32x4 t = {s[4 * gq], s[4 * gq + 1], s[4 * gq + 2], s[4 * gq + 3]};
-            *reinterpret_cast<f32x4*>(sp + gq * 256) = t;
+            SRES_STORE(sp + gq * 256, t);
         }
         float mx = s[0];
 #pragma unroll
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_sres_kernel
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const f32x4 t = {s[4 * gq], s[4 * gq + 1], s[4 * gq + 2], s[4 * gq + 3]};
-            *reinterpret_cast<f32x4*>(sp + gq * 256) = t;
+            SRES_STORE(sp + gq * 256, t);
         }
         float mx = s[0];
 #pragma unroll
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_pmean_sres_kernel(AttnGeom g, int NB
         for (int hi = 0; hi < 4; ++hi) {
             const int hd = min(h0 + hi, g.H - 1);
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) sv[hi][gq] = *reinterpret_cast<const f32x4*>(sp + hd * hstride + gq * 256);
+            for (int gq = 0; gq < 4; ++gq) sv[hi][gq] = SRES_LOAD_NT(sp + hd * hstride + gq * 256);
             lv[hi] = lp[(int64_t)hd * g.T];
         }
 #pragma unroll
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(256) void attn_delta_sres_kernel(AttnGeom g, int NB
             f32x4 sv[4], gv[4];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                sv[gq] = *reinterpret_cast<const f32x4*>(sp + (int64_t)kb * SB_FLOATS + gq * 256);
+                sv[gq] = SRES_LOAD(sp + (int64_t)kb * SB_FLOATS + gq * 256);
                 gv[gq] = *reinterpret_cast<const f32x4*>(gr + kb * 32 + 8 * gq + 4 * hh);
             }
 #pragma unroll
@@ -437,7 +447,7 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk
     auto load_sg = [&](int k0, f32x4 (&s4)[4], f32x4 (&g4)[4]) {
         const float* sp = sblk + (int64_t)(k0 >> 5) * SB_FLOATS;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) s4[gq] = *reinterpret_cast<const f32x4*>(sp + gq * 256);
+        for (int gq = 0; gq < 4; ++gq) s4[gq] = SRES_LOAD_DQ(sp + gq * 256);
         if (grow == nullptr) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) g4[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -549,7 +559,7 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         const float* src = scol + (int64_t)qblk * sstep;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
-            __builtin_amdgcn_global_load_lds((glb_vp)(src + soff[gq]), (lds_vp)(sw + slot * SB_FLOATS + gq * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(src + soff[gq]), (lds_vp)(sw + slot * SB_FLOATS + gq * 256), 16, 0, SRES_DMA_AUX);
     };
     dma_tile32(smem, qb, g.st, 0, g.T, wave, lane);
     dma_tile32(smem + DT_FLOATS, dob, g.ost, 0, g.T, wave, lane);
@@ -719,7 +729,7 @@ __device__ __forceinline__ void attn_dq_tail_body(float* smem, const AttnGeom& g
         f32x4 s4[4], g4[4];
         const float* sp = sblk + (int64_t)kt * SB_FLOATS;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) s4[gq] = *reinterpret_cast<const f32x4*>(sp + gq * 256);
+        for (int gq = 0; gq < 4; ++gq) s4[gq] = SRES_LOAD_DQ(sp + gq * 256);
         if (grow == nullptr) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) g4[gq] = f32x4{0.f, 0.f, 0.f, 0.f};

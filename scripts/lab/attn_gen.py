@@ -3,7 +3,10 @@ forward (+ head mean) and backward (with the head-mean gradient) time per launch
 max-abs comparison of the two generations' outputs.  usage: attn_gen.py [B] [T]"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from acr_wsss_amd import ops, _lib
+from acr_wsss_amd import _lib
+if os.environ.get("ACR_LAB_LIB"):      # a lab build of the library (scripts/lab/_build/*.so)
+    _lib.LIB_PATH = os.environ["ACR_LAB_LIB"]
+from acr_wsss_amd import ops
 dev = torch.device("cuda:0")
 H = 12
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
