@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libacr_hip.so")
+# ACR_LIB_PATH: a lab build of the same library (scripts/lab/_build/*.so, e.g. EXTRA=-DLAB_TL stamps) for A/B runs
+LIB_PATH = os.environ.get("ACR_LIB_PATH") or os.path.join(_HERE, "libacr_hip.so")
 
 ACR_F32, ACR_BF16, ACR_BF16_F32MATH = 0, 1, 2
 BF16_F32MATH = False      # True: bf16 tensors take the exact-fp32 MFMA kernels (reference for the bf16-MFMA ones)

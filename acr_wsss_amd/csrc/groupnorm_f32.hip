@@ -15,6 +15,12 @@
 #include "acr_common.h"
 
 #define GNF_GROUPS 32
+// Cache policy of the second (last) pass: nontemporal loads and stores.  The activations are 100-400 MB per tensor -- nothing
+// the next kernel could still find in the 4 MB L2 / 256 MB Infinity Cache -- and without the hint the pass evicts the lines
+// its own first pass just pulled in for the neighbouring workgroups.  Measured in the fp32 bench (rocprofv3 sums per step):
+// forward 3.37 -> 2.97 ms, backward 6.67 -> 6.02 ms.
+#define GNF_LD2(p) __builtin_nontemporal_load(&(p))
+#define GNF_ST(p, v) __builtin_nontemporal_store(v, &(p))
 enum { GNF_NONE = 0, GNF_RELU = 1, GNF_ADD_RELU = 2 };
 
 template <int NT>
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(NT) void gnf_fwd_kernel(const float* __restrict__ x
         const int c = g * cg + v / vpc;
         const float ga = gamma[c] * rstd;
         const float be = beta[c] - mean * ga;
-        const f32x4 a = xv[v];
+        const f32x4 a = GNF_LD2(xv[v]);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = fmaf(a[e], ga, be);
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(NT) void gnf_fwd_kernel(const float* __restrict__ x
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
         }
-        yv[v] = o;
+        GNF_ST(yv[v], o);
     }
     if (tid == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
 }
@@ -134,15 +140,15 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
         f32x4* ov = reinterpret_cast<f32x4*>(dx + base + (int64_t)cl * HW);
         f32x4* dv = reinterpret_cast<f32x4*>(dres + (ACT == GNF_ADD_RELU ? base + (int64_t)cl * HW : 0));
         for (int v = tid; v < vpc; v += NT) {
-            const f32x4 a = xv[v];
+            const f32x4 a = GNF_LD2(xv[v]);
             f32x4 r = {0.f, 0.f, 0.f, 0.f};
-            if (ACT == GNF_ADD_RELU) r = rv[v];
-            const f32x4 gy = masked(gv[v], a, r, ga, be);
+            if (ACT == GNF_ADD_RELU) r = GNF_LD2(rv[v]);
+            const f32x4 gy = masked(GNF_LD2(gv[v]), a, r, ga, be);
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rstd * (fmaf(gy[e], gam, -c1) - (a[e] - mean) * rstd * c2);
-            ov[v] = o;
-            if (ACT == GNF_ADD_RELU) dv[v] = gy;
+            GNF_ST(ov[v], o);
+            if (ACT == GNF_ADD_RELU) GNF_ST(dv[v], gy);
         }
     }
 }
