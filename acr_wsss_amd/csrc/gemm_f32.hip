@@ -345,7 +345,41 @@ extern "C" int acr_lab_tl_read(unsigned long long* host, int n) {
 #define LAB_TL_STAMP(i) do { } while (0)
 #endif
 
-template <bool A_KC, bool B_KC, int ACT>
+// ---------------------------------------------------------------------------------------------------------------
+// SPLIT = true: the same tiles, the same DMA ring, the same epilogues -- but every fp32 product is evaluated on the bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA's rate) as SIX exact terms of a three-way split,
+//     a = a0 + a1 + a2,  b = b0 + b1 + b2   (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 3 x 8 = 24 mantissa bits)
+//     a b ~ a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0        (the dropped terms are <= 2^-24 |a b|)
+// every bf16 x bf16 product is exact in fp32 and the sums accumulate in fp32: against float64 the result is as accurate as the
+// exact-fp32 MFMA chain (scripts/lab/split_bf16_accuracy.py: rms error 2.1e-7 vs 5.0e-7 of rms y).  The fragments are split
+// in registers right after their ds_read (8 consecutive k per lane = two 16-byte reads): no extra LDS, no extra HBM traffic.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3_bf16(const f32x4& lo4, const f32x4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? lo4[e] : hi4[e - 4];
+        const __bf16 h0 = (__bf16)x;
+        const float r1 = x - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;
+        p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)r2;
+    }
+}
+// fragment of 32 rows (base + r) for the 16-deep k step `st` of a chunk: the 8 consecutive k = 16 st + 8 h + (0..7) of lane (r, h)
+template <bool KC>
+__device__ __forceinline__ void dma_frag8(const float* __restrict__ s, int base, int st, int r, int h, f32x4& lo4, f32x4& hi4) {
+    if (KC) {
+        const int row = base + r, sw = (row >> 1) & 7;
+        lo4 = *reinterpret_cast<const f32x4*>(s + row * F_BK + (((4 * st + 2 * h) ^ sw) << 2));
+        hi4 = *reinterpret_cast<const f32x4*>(s + row * F_BK + (((4 * st + 2 * h + 1) ^ sw) << 2));
+    } else {
+        const float* p = s + (16 * st + 8 * h) * F_BM + base + r;
+        lo4 = f32x4{p[0], p[F_BM], p[2 * F_BM], p[3 * F_BM]};
+        hi4 = f32x4{p[4 * F_BM], p[5 * F_BM], p[6 * F_BM], p[7 * F_BM]};
+    }
+}
+
+template <bool A_KC, bool B_KC, int ACT, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args g) {
     __shared__ __attribute__((aligned(1024))) float smem[4 * F_DTILE];      // [A0 | B0 | A1 | B1]
     LAB_TL_STAMP(0);
@@ -393,6 +427,36 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
         }
         const float* sa = smem + cur * 2 * F_DTILE;
         const float* sb = sa + F_DTILE;
+        if (SPLIT) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 ap[2][3], bp[2][3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 lo4, hi4;
+                    dma_frag8<A_KC>(sa, wm * 64 + i * 32, st, r, h, lo4, hi4);
+                    split3_bf16(lo4, hi4, ap[i][0], ap[i][1], ap[i][2]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 lo4, hi4;
+                    dma_frag8<B_KC>(sb, wn * 64 + j * 32, st, r, h, lo4, hi4);
+                    split3_bf16(lo4, hi4, bp[j][0], bp[j][1], bp[j][2]);
+                }
+                // small terms first (each accumulator still sees its six terms in a fixed order: deterministic)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][2], bp[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 av[2], bv[2];
@@ -407,6 +471,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+        }
         }
         if (want_cs) {                                      // [k][i] image: 16 of the chunk's 32 k rows per thread
 #pragma unroll
@@ -627,7 +692,9 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         g.nsplit = p.nsplit; g.kps = p.kps; g.k_zs = p.kps;
         g.c = ws; g.ldc = N;
         g.cs = colsum ? ws + (size_t)p.nsplit * M * N : nullptr;
-        if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0)
+        if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && acr_opt(ACR_OPT_GEMM_F32_SPLIT) != 0)
+            hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false, 3, true>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
+        else if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0)
             hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
         else
             hipLaunchKernelGGL((gemm_f32_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
@@ -641,11 +708,13 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
     if (mode == ACR_GEMM_NN) ACR_CHECK_ARG((N % 4) == 0 && N >= 4, "acr_gemm_f32: NN needs N %% 4 == 0 (N=%d)", N);
     ACR_CHECK_ARG(act != 1 || c2, "acr_gemm_f32: act 1 (GELU) needs c2");
     ACR_CHECK_ARG(act != 2 || aux, "acr_gemm_f32: act 2 (GELU') needs the saved pre-activation in aux");
-#define ACR_F32_LAUNCH(AK, BK_, ACTV)                                                                    \
-    do {                                                                                                  \
-        if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);   \
-        else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);           \
+#define ACR_F32_LAUNCH(AK, BK_, ACTV)                                                                              \
+    do {                                                                                                            \
+        if (dma && split) hipLaunchKernelGGL((gemm_f32_dma_kernel<AK, BK_, ACTV, true>), grid, dim3(256), 0, st, g); \
+        else if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);          \
+        else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);                      \
     } while (0)
+    const bool split = acr_opt(ACR_OPT_GEMM_F32_SPLIT) != 0;      // products as six bf16 MFMA terms of a three-way split
     const bool dma = (K % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && off32_ok(M, N, K, lda, ldb, mode);
     TailPlan tp = gemm_tail_plan(M, N, K);
     const bool vec_ok = al16(c) && (ldc % 4) == 0 && (!bias || al16(bias)) && (!aux || (al16(aux) && (ldaux % 4) == 0)) &&
@@ -670,7 +739,9 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         gt.tile0 = g.tiles_launch; gt.tiles_launch = tp.ntail; gt.nsplit = tp.nsplit; gt.kps = tp.kps; gt.k_zs = tp.kps;
         gt.c = ws;
         const dim3 tgrid((unsigned)(tp.ntail * tp.nsplit));
-        if (mode == ACR_GEMM_NT) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 4>), tgrid, dim3(256), 0, st, gt);
+        if (mode == ACR_GEMM_NT && split) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 4, true>), tgrid, dim3(256), 0, st, gt);
+        else if (mode == ACR_GEMM_NT) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 4>), tgrid, dim3(256), 0, st, gt);
+        else if (split) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4, true>), tgrid, dim3(256), 0, st, gt);
         else hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4>), tgrid, dim3(256), 0, st, gt);
         GemmF32Args ge = g;
         ge.tile0 = gt.tile0;

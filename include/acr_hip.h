@@ -77,6 +77,7 @@ typedef enum acr_option {
     ACR_OPT_ATTN_F32_NW = 8,    /* acr_attn_fwd_scores: 5 = five 32-query blocks (waves) per forward workgroup instead of four (A/B: slower) */
     ACR_OPT_GEMM_F32_NOTAIL = 9, /* 1: acr_gemm_f32 NT / NN never K-splits the tiles beyond the last whole half-round (A/B) */
     ACR_OPT_ATTN_F32_NOSPLITTAIL = 10, /* 1: resident-score attention keeps the leftover 32-row block as an ordinary (1 live wave) workgroup (A/B) */
+    ACR_OPT_GEMM_F32_SPLIT = 11, /* 1: acr_gemm_f32 evaluates every fp32 product as six bf16-MFMA terms of a three-way operand split (fp32-accurate, see gemm_f32.hip) */
     ACR_OPT_COUNT_
 } acr_option;
 int     acr_set_option(int32_t option, int32_t value);
