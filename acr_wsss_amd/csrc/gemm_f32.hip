@@ -428,34 +428,47 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
         const float* sa = smem + cur * 2 * F_DTILE;
         const float* sb = sa + F_DTILE;
         if (SPLIT) {
+            // Software pipeline inside the chunk: a wave issues in order, so the ~176 VALU instructions that split step 1's
+            // fragments are interleaved (sched_group_barrier: 1 MFMA, 7 VALU, ...) with the 24 MFMAs of step 0 -- the split of
+            // step 0 and the MFMAs of step 1 are left to overlap with the co-resident workgroup's wave on the same SIMD.
+            bf16x8 ap[2][2][3], bp[2][2][3];                    // [step][block][piece]
+            f32x4 ra[2][2], rb[2][2];
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                bf16x8 ap[2][3], bp[2][3];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    f32x4 lo4, hi4;
-                    dma_frag8<A_KC>(sa, wm * 64 + i * 32, st, r, h, lo4, hi4);
-                    split3_bf16(lo4, hi4, ap[i][0], ap[i][1], ap[i][2]);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x4 lo4, hi4;
-                    dma_frag8<B_KC>(sb, wn * 64 + j * 32, st, r, h, lo4, hi4);
-                    split3_bf16(lo4, hi4, bp[j][0], bp[j][1], bp[j][2]);
-                }
-                // small terms first (each accumulator still sees its six terms in a fixed order: deterministic)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][2], bp[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[j][0], acc[i][j], 0, 0, 0);
-                    }
+            for (int i = 0; i < 2; ++i) {
+                dma_frag8<A_KC>(sa, wm * 64 + i * 32, 0, r, h, ra[i][0], ra[i][1]);
+                split3_bf16(ra[i][0], ra[i][1], ap[0][i][0], ap[0][i][1], ap[0][i][2]);
             }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                dma_frag8<B_KC>(sb, wn * 64 + j * 32, 0, r, h, rb[j][0], rb[j][1]);
+                split3_bf16(rb[j][0], rb[j][1], bp[0][j][0], bp[0][j][1], bp[0][j][2]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma_frag8<A_KC>(sa, wm * 64 + i * 32, 1, r, h, ra[i][0], ra[i][1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma_frag8<B_KC>(sb, wn * 64 + j * 32, 1, r, h, rb[j][0], rb[j][1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) split3_bf16(ra[i][0], ra[i][1], ap[1][i][0], ap[1][i][1], ap[1][i][2]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) split3_bf16(rb[j][0], rb[j][1], bp[1][j][0], bp[1][j][1], bp[1][j][2]);
+            // small terms first (each accumulator sees its six terms in a fixed order: deterministic)
+#define ACR_SPLIT_MFMA6(ST, I, J)                                                                                          \
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][0], bp[ST][J][2], acc[I][J], 0, 0, 0);           \
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][2], bp[ST][J][0], acc[I][J], 0, 0, 0);           \
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][1], bp[ST][J][1], acc[I][J], 0, 0, 0);           \
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][0], bp[ST][J][1], acc[I][J], 0, 0, 0);           \
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][1], bp[ST][J][0], acc[I][J], 0, 0, 0);           \
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][0], bp[ST][J][0], acc[I][J], 0, 0, 0);
+            ACR_SPLIT_MFMA6(0, 0, 0) ACR_SPLIT_MFMA6(0, 0, 1) ACR_SPLIT_MFMA6(0, 1, 0) ACR_SPLIT_MFMA6(0, 1, 1)
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // eight VALU instructions of the next step's split
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ACR_SPLIT_MFMA6(1, 0, 0) ACR_SPLIT_MFMA6(1, 0, 1) ACR_SPLIT_MFMA6(1, 1, 0) ACR_SPLIT_MFMA6(1, 1, 1)
+#undef ACR_SPLIT_MFMA6
         } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
