@@ -22,6 +22,8 @@
 // step (q, s), which is what makes one 16-byte read feed four MFMAs.
 #include <math.h>
 
+#include <type_traits>
+
 #include "acr_common.h"
 
 #define F_BM 128
@@ -345,41 +347,58 @@ extern "C" int acr_lab_tl_read(unsigned long long* host, int n) {
 #define LAB_TL_STAMP(i) do { } while (0)
 #endif
 
-// ---------------------------------------------------------------------------------------------------------------
-// SPLIT = true: the same tiles, the same DMA ring, the same epilogues -- but every fp32 product is evaluated on the bf16 MFMA
-// (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA's rate) as SIX exact terms of a three-way split,
-//     a = a0 + a1 + a2,  b = b0 + b1 + b2   (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 3 x 8 = 24 mantissa bits)
-//     a b ~ a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0        (the dropped terms are <= 2^-24 |a b|)
-// every bf16 x bf16 product is exact in fp32 and the sums accumulate in fp32: against float64 the result is as accurate as the
-// exact-fp32 MFMA chain (scripts/lab/split_bf16_accuracy.py: rms error 2.1e-7 vs 5.0e-7 of rms y).  The fragments are split
-// in registers right after their ds_read (8 consecutive k per lane = two 16-byte reads): no extra LDS, no extra HBM traffic.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split3_bf16(const f32x4& lo4, const f32x4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+// everything after the K loop of a DMA-ring kernel: tail slab (ACT 4), split slab + bias-gradient column sums (ACT 3) or the
+// epilogue.  `smem` must be free (all fragment reads behind a barrier).
+template <bool A_KC, int ACT>
+__device__ __forceinline__ void gemm_f32_finish(const GemmF32Args& g, f32x16 (&acc)[2][2], float* smem, int split, int tt, int tn, int m0,
+                                                int n0, int zs, int wm, int wn, int r, int h, int tid, float csum, bool want_cs) {
+    if (ACT == 4) {                                         // K-split tail tile: raw accumulators into a compact slab
+        float* slab = g.c + ((int64_t)split * g.tiles_launch + (tt - g.tile0)) * (F_BM * F_BN);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float x = e < 4 ? lo4[e] : hi4[e - 4];
-        const __bf16 h0 = (__bf16)x;
-        const float r1 = x - (float)h0;
-        const __bf16 h1 = (__bf16)r1;
-        const float r2 = r1 - (float)h1;
-        p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)r2;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wn * 64 + j * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) slab[(wm * 64 + i * 32 + acr_krow(e, h)) * F_BN + col] = acc[i][j][e];
+            }
+        return;
     }
-}
-// fragment of 32 rows (base + r) for the 16-deep k step `st` of a chunk: the 8 consecutive k = 16 st + 8 h + (0..7) of lane (r, h)
-template <bool KC>
-__device__ __forceinline__ void dma_frag8(const float* __restrict__ s, int base, int st, int r, int h, f32x4& lo4, f32x4& hi4) {
-    if (KC) {
-        const int row = base + r, sw = (row >> 1) & 7;
-        lo4 = *reinterpret_cast<const f32x4*>(s + row * F_BK + (((4 * st + 2 * h) ^ sw) << 2));
-        hi4 = *reinterpret_cast<const f32x4*>(s + row * F_BK + (((4 * st + 2 * h + 1) ^ sw) << 2));
-    } else {
-        const float* p = s + (16 * st + 8 * h) * F_BM + base + r;
-        lo4 = f32x4{p[0], p[F_BM], p[2 * F_BM], p[3 * F_BM]};
-        hi4 = f32x4{p[4 * F_BM], p[5 * F_BM], p[6 * F_BM], p[7 * F_BM]};
+    if (ACT == 3) {
+        float* slab = g.c + (int64_t)split * g.M * g.ldc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wm * 64 + i * 32 + acr_krow(e, h);
+                    if (row < g.M && col < g.N) slab[(int64_t)row * g.ldc + col] = acc[i][j][e];
+                }
+            }
+        if (want_cs) {
+            float* red = smem;                              // behind the loop's last barrier
+            red[tid] = csum;
+            __syncthreads();
+            if (tid < 128 && m0 + tid < g.M) g.cs[(int64_t)split * g.M + m0 + tid] = red[tid] + red[tid + 128];
+        }
+        return;
     }
+    GemmF32Args gz = g;
+    gz.c += (int64_t)zs * g.c_zs;
+    if (gz.aux) gz.aux += (int64_t)zs * g.aux_zs;
+    if (m0 + F_BM <= g.M && n0 + F_BN <= g.N)
+        epilogue_f32<ACT, false>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+    else
+        epilogue_f32<ACT, true>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+#ifdef LAB_TL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LAB_TL_STAMP(3);
+#endif
 }
 
-template <bool A_KC, bool B_KC, int ACT, bool SPLIT = false>
+template <bool A_KC, bool B_KC, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args g) {
     __shared__ __attribute__((aligned(1024))) float smem[4 * F_DTILE];      // [A0 | B0 | A1 | B1]
     LAB_TL_STAMP(0);
@@ -427,49 +446,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
         }
         const float* sa = smem + cur * 2 * F_DTILE;
         const float* sb = sa + F_DTILE;
-        if (SPLIT) {
-            // Software pipeline inside the chunk: a wave issues in order, so the ~176 VALU instructions that split step 1's
-            // fragments are interleaved (sched_group_barrier: 1 MFMA, 7 VALU, ...) with the 24 MFMAs of step 0 -- the split of
-            // step 0 and the MFMAs of step 1 are left to overlap with the co-resident workgroup's wave on the same SIMD.
-            bf16x8 ap[2][2][3], bp[2][2][3];                    // [step][block][piece]
-            f32x4 ra[2][2], rb[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                dma_frag8<A_KC>(sa, wm * 64 + i * 32, 0, r, h, ra[i][0], ra[i][1]);
-                split3_bf16(ra[i][0], ra[i][1], ap[0][i][0], ap[0][i][1], ap[0][i][2]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                dma_frag8<B_KC>(sb, wn * 64 + j * 32, 0, r, h, rb[j][0], rb[j][1]);
-                split3_bf16(rb[j][0], rb[j][1], bp[0][j][0], bp[0][j][1], bp[0][j][2]);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) dma_frag8<A_KC>(sa, wm * 64 + i * 32, 1, r, h, ra[i][0], ra[i][1]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) dma_frag8<B_KC>(sb, wn * 64 + j * 32, 1, r, h, rb[j][0], rb[j][1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) split3_bf16(ra[i][0], ra[i][1], ap[1][i][0], ap[1][i][1], ap[1][i][2]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) split3_bf16(rb[j][0], rb[j][1], bp[1][j][0], bp[1][j][1], bp[1][j][2]);
-            // small terms first (each accumulator sees its six terms in a fixed order: deterministic)
-#define ACR_SPLIT_MFMA6(ST, I, J)                                                                                          \
-            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][0], bp[ST][J][2], acc[I][J], 0, 0, 0);           \
-            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][2], bp[ST][J][0], acc[I][J], 0, 0, 0);           \
-            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][1], bp[ST][J][1], acc[I][J], 0, 0, 0);           \
-            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][0], bp[ST][J][1], acc[I][J], 0, 0, 0);           \
-            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][1], bp[ST][J][0], acc[I][J], 0, 0, 0);           \
-            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ST][I][0], bp[ST][J][0], acc[I][J], 0, 0, 0);
-            ACR_SPLIT_MFMA6(0, 0, 0) ACR_SPLIT_MFMA6(0, 0, 1) ACR_SPLIT_MFMA6(0, 1, 0) ACR_SPLIT_MFMA6(0, 1, 1)
-#pragma unroll
-            for (int it = 0; it < 24; ++it) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // eight VALU instructions of the next step's split
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            ACR_SPLIT_MFMA6(1, 0, 0) ACR_SPLIT_MFMA6(1, 0, 1) ACR_SPLIT_MFMA6(1, 1, 0) ACR_SPLIT_MFMA6(1, 1, 1)
-#undef ACR_SPLIT_MFMA6
-        } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 av[2], bv[2];
@@ -485,7 +461,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
         }
-        }
         if (want_cs) {                                      // [k][i] image: 16 of the chunk's 32 k rows per thread
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) csum += sa[(2 * kk + (tid >> 7)) * F_BM + (tid & 127)];
@@ -499,50 +474,171 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
         g.stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
     }
 #endif
-    if (ACT == 4) {                                         // K-split tail tile: raw accumulators into a compact slab
-        float* slab = g.c + ((int64_t)split * g.tiles_launch + (tt - g.tile0)) * (F_BM * F_BN);
+    gemm_f32_finish<A_KC, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, csum, want_cs);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 products on the bf16 MFMA (ACR_OPT_GEMM_F32_SPLIT): the same tiles, operands, epilogues and tail plan as the kernels
+// above, but every fp32 product is evaluated on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA's rate) as SIX exact terms of a
+// three-way operand split,
+//     a = a0 + a1 + a2,  b = b0 + b1 + b2   (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 3 x 8 = 24 mantissa bits)
+//     a b ~ a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0        (the dropped terms are <= 2^-24 |a b|)
+// every bf16 x bf16 product is exact in fp32 and the sums accumulate in fp32: against float64 the result is as accurate as the
+// exact-fp32 MFMA chain (scripts/lab/gemm_split.py: rms error 8.6e-7 vs 9.9e-7 of rms y at K = 3072).  Operands stay fp32 in
+// HBM and in LDS; fragments are split in registers right after their ds_read.
+// Structure: a 32-deep chunk is now ~1.5 us of matrix work for two co-resident workgroups, less than the 3 us a first-touch
+// DMA takes to land -- with the two-slot ring above the loop is latency-bound (3.2 us per chunk measured, x1.3 only).  So:
+// 16-deep stages (one MFMA k-step), a FOUR-slot ring filled three stages ahead with counted vmcnt, and the split of stage t
+// interleaved (sched_group_barrier) with the 24 MFMAs of stage t - 1, whose pieces wait in a second register set.
+// ---------------------------------------------------------------------------------------------------------------
+#define S_BK 16
+#define S_TILE (F_BM * S_BK)         // floats per operand per stage (8 KiB)
+#define S_SLOTS 4
+
+__device__ __forceinline__ void split3_bf16(const f32x4& lo4, const f32x4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = wn * 64 + j * 32 + r;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) slab[(wm * 64 + i * 32 + acr_krow(e, h)) * F_BN + col] = acc[i][j][e];
-            }
-        return;
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? lo4[e] : hi4[e - 4];
+        const __bf16 h0 = (__bf16)x;
+        const float r1 = x - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;
+        p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)r2;
     }
-    if (ACT == 3) {
-        float* slab = g.c + (int64_t)split * g.M * g.ldc;
+}
+// per-lane element offsets of this wave's 2 DMA pieces of one 16-deep stage of one operand (computed once per workgroup).
+// KC: piece = 16 rows x 64 bytes, lane -> (row = l >> 2, 16-byte chunk l & 3), chunk XOR-swizzled by (row >> 2) & 3 on the
+// SOURCE address (mirrored by the fragment reads: every 16-lane group of a ds_read_b128 then hits 16 different bank quads);
+// KS: piece = 2 k rows of 128 floats.
+template <bool KC>
+__device__ __forceinline__ void split_dma_offsets(int (&off)[2], int64_t ld, int i0, int dim, int wave, int lane) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + r;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + wm * 64 + i * 32 + acr_krow(e, h);
-                    if (row < g.M && col < g.N) slab[(int64_t)row * g.ldc + col] = acc[i][j][e];
-                }
-            }
-        if (want_cs) {
-            float* red = smem;                              // behind the loop's last barrier
-            red[tid] = csum;
-            __syncthreads();
-            if (tid < 128 && m0 + tid < g.M) g.cs[(int64_t)split * g.M + m0 + tid] = red[tid] + red[tid + 128];
+    for (int i = 0; i < 2; ++i) {
+        const int piece = wave * 2 + i;
+        if (KC) {
+            const int row = piece * 16 + (lane >> 2);
+            const int lc = (lane & 3) ^ ((row >> 2) & 3);
+            off[i] = min(i0 + row, dim - 1) * (int)ld + lc * 4;
+        } else {
+            const int kr = piece * 2 + (lane >> 5);
+            off[i] = kr * (int)ld + min(i0 + 4 * (lane & 31), dim - 4);
         }
-        return;
     }
-    GemmF32Args gz = g;
-    gz.c += (int64_t)zs * g.c_zs;
-    if (gz.aux) gz.aux += (int64_t)zs * g.aux_zs;
-    if (m0 + F_BM <= g.M && n0 + F_BN <= g.N)
-        epilogue_f32<ACT, false>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
-    else
-        epilogue_f32<ACT, true>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
-#ifdef LAB_TL
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    LAB_TL_STAMP(3);
-#endif
+}
+__device__ __forceinline__ void split_dma_stage(float* s, const float* __restrict__ ub, const int (&off)[2], int wave) {
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((glb_vp)(ub + off[i]), (lds_vp)(s + (wave * 2 + i) * 256), 16, 0, 0);
+}
+// the 8 consecutive contraction indices 8 h + (0..7) of lane (r, h) for 32 rows starting at `base`
+template <bool KC>
+__device__ __forceinline__ void split_frag8(const float* __restrict__ s, int base, int r, int h, f32x4& lo4, f32x4& hi4) {
+    if (KC) {
+        const int row = base + r, sw = (row >> 2) & 3;
+        lo4 = *reinterpret_cast<const f32x4*>(s + row * S_BK + (((2 * h) ^ sw) << 2));
+        hi4 = *reinterpret_cast<const f32x4*>(s + row * S_BK + (((2 * h + 1) ^ sw) << 2));
+    } else {
+        const float* p = s + (8 * h) * F_BM + base + r;
+        lo4 = f32x4{p[0], p[F_BM], p[2 * F_BM], p[3 * F_BM]};
+        hi4 = f32x4{p[4 * F_BM], p[5 * F_BM], p[6 * F_BM], p[7 * F_BM]};
+    }
+}
+
+template <bool A_KC, bool B_KC, int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Args g) {
+    __shared__ __attribute__((aligned(1024))) float smem[S_SLOTS * 2 * S_TILE];      // [slot][A | B], 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int ntile = g.tiles_launch;
+    const int t0 = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
+    const int split = t0 / ntile, tt = g.tile0 + (t0 - split * ntile);
+    int tm, tn;
+    if (ACT == 3) { tm = tt / g.tiles_n; tn = tt - tm * g.tiles_n; }
+    else tile_coords(tt, g.tiles_m, g.tiles_n, tm, tn);
+    const int m0 = tm * F_BM, n0 = tn * F_BN;
+    const int zs = split / g.ksplit;
+    const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);      // host: (kend - kbeg) % 32 == 0
+    const float* __restrict__ pa = g.a + (int64_t)zs * g.a_zs;
+    const float* __restrict__ pb = g.b + (int64_t)zs * g.b_zs;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float csum = 0.f;          // TN bias gradient: column tid & 127 of the A stages, k rows of parity tid >> 7
+    const bool want_cs = ACT == 3 && !A_KC && g.cs && tn == 0;
+    int offa[2], offb[2];
+    split_dma_offsets<A_KC>(offa, g.lda, m0, g.M, wave, lane);
+    split_dma_offsets<B_KC>(offb, g.ldb, n0, g.N, wave, lane);
+    const int64_t ka = A_KC ? 1 : g.lda, kb = B_KC ? 1 : g.ldb;      // operand advance per contraction index
+    const int nst = (kend - kbeg) / S_BK;
+    auto issue = [&](int st) {
+        float* d = smem + (st & (S_SLOTS - 1)) * 2 * S_TILE;
+        split_dma_stage(d, pa + (int64_t)(kbeg + st * S_BK) * ka, offa, wave);
+        split_dma_stage(d + S_TILE, pb + (int64_t)(kbeg + st * S_BK) * kb, offb, wave);
+    };
+#pragma unroll
+    for (int st = 0; st < S_SLOTS - 1; ++st)
+        if (st < nst) issue(st);
+    bf16x8 ap[2][2][3], bp[2][2][3];                        // [register set][block][piece]
+    f32x4 ra[2][2], rb[2][2];
+#define ACR_SPLIT_MFMA6(SET, I, J)                                                                                        \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][2], acc[I][J], 0, 0, 0);               \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][2], bp[SET][J][0], acc[I][J], 0, 0, 0);               \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][1], acc[I][J], 0, 0, 0);               \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][1], acc[I][J], 0, 0, 0);               \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][0], acc[I][J], 0, 0, 0);               \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][0], acc[I][J], 0, 0, 0);
+    // stage st: wait until it has landed (stages st+1, st+2 may stay in flight: 4 DMA instructions each), publish it, refill the
+    // slot stage st-1 was read from, read + split stage st into register set SET while the MFMAs of stage st-1 (set SET^1) run
+    auto step = [&](int st, auto set_tag, auto first_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + S_SLOTS - 1 < nst) issue(st + S_SLOTS - 1);
+        const float* sa = smem + (st & (S_SLOTS - 1)) * 2 * S_TILE;
+        const float* sb = sa + S_TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) split_frag8<A_KC>(sa, wm * 64 + i * 32, r, h, ra[i][0], ra[i][1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) split_frag8<B_KC>(sb, wn * 64 + j * 32, r, h, rb[j][0], rb[j][1]);
+        if (want_cs) {                                      // [k][i] image: 8 of the stage's 16 k rows per thread
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) csum += sa[(2 * kk + (tid >> 7)) * F_BM + (tid & 127)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) split3_bf16(ra[i][0], ra[i][1], ap[SET][i][0], ap[SET][i][1], ap[SET][i][2]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) split3_bf16(rb[j][0], rb[j][1], bp[SET][j][0], bp[SET][j][1], bp[SET][j][2]);
+        if (!FIRST) {
+            ACR_SPLIT_MFMA6(SET ^ 1, 0, 0) ACR_SPLIT_MFMA6(SET ^ 1, 0, 1) ACR_SPLIT_MFMA6(SET ^ 1, 1, 0) ACR_SPLIT_MFMA6(SET ^ 1, 1, 1)
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA of stage st - 1
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // eight VALU instructions of stage st's split
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    step(0, std::integral_constant<int, 0>{}, std::true_type{});
+    for (int st = 1; st < nst; st += 2) {
+        step(st, std::integral_constant<int, 1>{}, std::false_type{});
+        if (st + 1 < nst) step(st + 1, std::integral_constant<int, 0>{}, std::false_type{});
+    }
+    if (nst & 1) { ACR_SPLIT_MFMA6(0, 0, 0) ACR_SPLIT_MFMA6(0, 0, 1) ACR_SPLIT_MFMA6(0, 1, 0) ACR_SPLIT_MFMA6(0, 1, 1) }
+    else { ACR_SPLIT_MFMA6(1, 0, 0) ACR_SPLIT_MFMA6(1, 0, 1) ACR_SPLIT_MFMA6(1, 1, 0) ACR_SPLIT_MFMA6(1, 1, 1) }
+#undef ACR_SPLIT_MFMA6
+    __syncthreads();                                        // every wave is done with the ring: the finish may reuse it
+    gemm_f32_finish<A_KC, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, csum, want_cs);
 }
 
 // out[i] = sum_s slab[s][i] in split order (deterministic), float4 per thread; n4 = elements / 4
@@ -706,7 +802,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         g.c = ws; g.ldc = N;
         g.cs = colsum ? ws + (size_t)p.nsplit * M * N : nullptr;
         if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && acr_opt(ACR_OPT_GEMM_F32_SPLIT) != 0)
-            hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false, 3, true>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
+            hipLaunchKernelGGL((gemm_f32_split_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
         else if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0)
             hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
         else
@@ -723,7 +819,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
     ACR_CHECK_ARG(act != 2 || aux, "acr_gemm_f32: act 2 (GELU') needs the saved pre-activation in aux");
 #define ACR_F32_LAUNCH(AK, BK_, ACTV)                                                                              \
     do {                                                                                                            \
-        if (dma && split) hipLaunchKernelGGL((gemm_f32_dma_kernel<AK, BK_, ACTV, true>), grid, dim3(256), 0, st, g); \
+        if (dma && split) hipLaunchKernelGGL((gemm_f32_split_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);   \
         else if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);          \
         else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);                      \
     } while (0)
@@ -752,9 +848,9 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         gt.tile0 = g.tiles_launch; gt.tiles_launch = tp.ntail; gt.nsplit = tp.nsplit; gt.kps = tp.kps; gt.k_zs = tp.kps;
         gt.c = ws;
         const dim3 tgrid((unsigned)(tp.ntail * tp.nsplit));
-        if (mode == ACR_GEMM_NT && split) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 4, true>), tgrid, dim3(256), 0, st, gt);
+        if (mode == ACR_GEMM_NT && split) hipLaunchKernelGGL((gemm_f32_split_kernel<true, true, 4>), tgrid, dim3(256), 0, st, gt);
         else if (mode == ACR_GEMM_NT) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 4>), tgrid, dim3(256), 0, st, gt);
-        else if (split) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4, true>), tgrid, dim3(256), 0, st, gt);
+        else if (split) hipLaunchKernelGGL((gemm_f32_split_kernel<true, false, 4>), tgrid, dim3(256), 0, st, gt);
         else hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4>), tgrid, dim3(256), 0, st, gt);
         GemmF32Args ge = g;
         ge.tile0 = gt.tile0;
