@@ -496,6 +496,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
 #define S_SLOTS 4
 
 __device__ __forceinline__ void split3_bf16(const f32x4& lo4, const f32x4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#if defined(SPLIT_LAB) && SPLIT_LAB == 1        // lab timing build: no split arithmetic (wrong results), loads + MFMAs only
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 a = __builtin_bit_cast(i32x4, lo4), b = __builtin_bit_cast(i32x4, hi4);
+    p0 = __builtin_bit_cast(bf16x8, a); p1 = __builtin_bit_cast(bf16x8, b); p2 = __builtin_bit_cast(bf16x8, a ^ b);
+    return;
+#endif
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float x = e < 4 ? lo4[e] : hi4[e - 4];
@@ -587,6 +593,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
         if (st < nst) issue(st);
     bf16x8 ap[2][2][3], bp[2][2][3];                        // [register set][block][piece]
     f32x4 ra[2][2], rb[2][2];
+#if defined(SPLIT_LAB) && SPLIT_LAB == 2        // lab timing build: no MFMAs (wrong results), loads + split only
+#define ACR_SPLIT_MFMA6(SET, I, J)                                                                                        \
+    acc[I][J][0] += (float)ap[SET][I][0][0] + (float)bp[SET][J][2][1] + (float)ap[SET][I][2][2] + (float)bp[SET][J][0][3] + (float)ap[SET][I][1][4] + (float)bp[SET][J][1][5];
+#else
 #define ACR_SPLIT_MFMA6(SET, I, J)                                                                                        \
     acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][2], acc[I][J], 0, 0, 0);               \
     acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][2], bp[SET][J][0], acc[I][J], 0, 0, 0);               \
@@ -594,6 +604,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
     acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][1], acc[I][J], 0, 0, 0);               \
     acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][0], acc[I][J], 0, 0, 0);               \
     acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][0], acc[I][J], 0, 0, 0);
+#endif
     // stage st: wait until it has landed (stages st+1, st+2 may stay in flight: 4 DMA instructions each), publish it, refill the
     // slot stage st-1 was read from, read + split stage st into register set SET while the MFMAs of stage st-1 (set SET^1) run
     auto step = [&](int st, auto set_tag, auto first_tag) {
@@ -894,13 +905,16 @@ extern "C" int acr_conv1x1_f32(const float* w, int32_t w_transposed, const float
     g.nsplit = nsamp;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n * nsamp));
     const bool dma = (cin % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0;
+    const bool split = dma && acr_opt(ACR_OPT_GEMM_F32_SPLIT) != 0;
     if (!w_transposed) {                    // w = (cout, cin): rows = output channels, k contiguous
         g.lda = cin;
-        if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 0>), grid, dim3(256), 0, st, g);
+        if (split) hipLaunchKernelGGL((gemm_f32_split_kernel<true, false, 0>), grid, dim3(256), 0, st, g);
+        else if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 0>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((gemm_f32_kernel<true, false, 0>), grid, dim3(256), 0, st, g);
     } else {                                                // w = (cin, cout) as stored by the forward conv: A[i][k] = w[k][i]
         g.lda = cout;
-        if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false, 0>), grid, dim3(256), 0, st, g);
+        if (split) hipLaunchKernelGGL((gemm_f32_split_kernel<false, false, 0>), grid, dim3(256), 0, st, g);
+        else if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false, 0>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((gemm_f32_kernel<false, false, 0>), grid, dim3(256), 0, st, g);
     }
     return acr_check_launch("acr_conv1x1_f32");
@@ -940,7 +954,9 @@ extern "C" int acr_conv1x1_wgrad_f32(const float* dy, const float* x, int32_t ns
     g.k_zs = g.kps;
     g.nsplit = nsamp * ks;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.nsplit));
-    if ((hw % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0)
+    if ((hw % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && acr_opt(ACR_OPT_GEMM_F32_SPLIT) != 0)
+        hipLaunchKernelGGL((gemm_f32_split_kernel<true, true, 3>), grid, dim3(256), 0, st, g);
+    else if ((hw % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0)
         hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 3>), grid, dim3(256), 0, st, g);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<true, true, 3>), grid, dim3(256), 0, st, g);
