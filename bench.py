@@ -35,8 +35,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_IMG_448 = 1.1307e12          # SURVEY 6 [probe]: 2 views, fwd+bwd, hybrid-base @448^2
-PEAK_MFMA = {"f32": 157.3e12, "bf16": 2.5e15}   # MI355X_MICROARCH.md: dense matrix peaks
+PEAK_MFMA = {"f32": 157.3e12, "f32_split": 157.3e12, "bf16": 2.5e15}   # MI355X_MICROARCH.md: dense matrix peaks
 PRECISION = {"f32": "fp32 end to end (reference precision, exact-fp32 MFMA)",
+             "f32_split": "fp32 tensors end to end; every Linear / 1x1-convolution product evaluated on the bf16 MFMA as six exact terms of a "
+                          "three-way operand split (24 mantissa bits), fp32 accumulation -- as accurate against fp64 as the fp32 FMA chain "
+                          "(tests: same tolerances as f32); attention, norms, loss: exact fp32 as in f32",
              "bf16": "bf16 params/activations/grads + bf16 MFMA, fp32 master weights + fp32 accumulate/softmax/loss"}
 IN_STEP = os.path.join(ROOT, "profiles", "r03_in_step_kernels.json")     # rocprofv3 kernel-trace of this bench, per dtype
 
@@ -48,7 +51,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU (BASELINE configs[1]: 16)")
     ap.add_argument("--size", type=int, default=448)
-    ap.add_argument("--dtype", choices=["both", "f32", "bf16"], default=os.environ.get("ACR_BENCH_DTYPE", "both"),
+    ap.add_argument("--dtype", choices=["both", "f32", "f32_split", "bf16"], default=os.environ.get("ACR_BENCH_DTYPE", "both"),
                     help="both (default): the fp32 run is the headline (the reference trains in fp32, train_acr.py:137) and "
                          "the bf16 run rides along as the named sub-record 'bf16'; f32 / bf16: that run only (profiling)")
     ap.add_argument("--classes", type=int, default=20)
@@ -459,6 +462,8 @@ def run_mode(args, dtype, world, rank, dev):
     from acr_wsss_amd.train import MasterWeights, PolyOptimizer, train_step
     from acr_wsss_amd.dp import GradSync, broadcast_parameters
 
+    from acr_wsss_amd import _lib
+    _lib.set_option("gemm_f32_split", 1 if dtype == "f32_split" else int(os.environ.get("ACR_GEMM_F32_SPLIT", "0") == "1"))
     torch.manual_seed(0)
     model = ACR(num_classes=args.classes, backbone_name="vitb_hybrid", use_pretrain=False,
                 channels_last=args.channels_last).to(dev)
@@ -473,7 +478,7 @@ def run_mode(args, dtype, world, rank, dev):
         img = img.to(torch.bfloat16)
     else:
         opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=100000)
-        amp = torch.bfloat16 if dtype == "bf16" else None
+        amp = torch.bfloat16 if dtype == "bf16" else None          # f32_split: fp32 tensors, no autocast
     sync = GradSync(model.parameters()) if (world > 1 or os.environ.get("ACR_FORCE_GRADSYNC") == "1") else None
 
     def step():
@@ -516,6 +521,7 @@ def run_mode(args, dtype, world, rank, dev):
            "step_mfma_frac": round(value * FLOP_PER_IMG_448 * (args.size / 448.0) ** 2 / (world * PEAK_MFMA[dtype]), 4),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     rec["_live_ms"] = live                               # popped by main(): feeds the roofline records
+    _lib.set_option("gemm_f32_split", int(os.environ.get("ACR_GEMM_F32_SPLIT", "0") == "1"))
     if sync is not None:
         info = sync.describe()
         per_step = max(1, info["steps"])
@@ -559,7 +565,7 @@ def main():
     if args.stock_linear:
         from acr_wsss_amd.backbone import Attention
         Attention.hip_linear = False
-    modes = ["f32", "bf16"] if args.dtype == "both" else [args.dtype]
+    modes = ["f32", "f32_split", "bf16"] if args.dtype == "both" else [args.dtype]
     if args.probe_only:
         print(json.dumps({m: roofline_probe(args, dev, m) for m in modes}), flush=True)
         return
@@ -592,9 +598,14 @@ def main():
             log("roofline probe (%s) done" % head["dtype"])
         for m in modes[1:]:
             sub = dict(runs[m])
-            if world == 1 and not args.no_roofline:
+            if world == 1 and not args.no_roofline and m != "f32_split":
                 sub["roofline"] = roofline_probe(args, dev, m, lives[m])
                 log("roofline probe (%s) done" % m)
+            if m == "f32_split":
+                sub["vs_f32"] = round(sub["value"] / head["value"], 3) if head["dtype"] == "f32" else None
+                sub["note"] = ("NOT the headline: the same fp32 step with acr_set_option(ACR_OPT_GEMM_F32_SPLIT, 1); parity tests run in this "
+                               "mode at the fp32 tolerances (tests/test_model_gpu.py::test_split_gemm_mode_matches_the_reference_fixtures, "
+                               "test_kernels_gpu.py::test_gemm_f32_linear[split=1])")
             out[m] = sub
         if dist_info is not None:
             out["dist"] = dist_info

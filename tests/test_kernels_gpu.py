@@ -3,6 +3,8 @@ seeded inputs, incl. ragged sizes (T not a multiple of any tile), the maximum T 
 the edge cases the path has (p = 1 -> T = 2, masked tails, no head-mean gradient)."""
 import math
 
+import os
+
 import pytest
 import torch
 
@@ -487,13 +489,24 @@ def test_weight_transposes_cache():
 
 @pytest.mark.parametrize("M,N,K", [(1, 32, 32), (130, 200, 72), (785, 2304, 768), (2 * 785 + 3, 768, 3072), (333, 576, 192),
                                    (25120, 768, 768), (1025, 3072, 768)])
-def test_gemm_f32_linear(M, N, K):
+@pytest.mark.parametrize("split", [0, 1])
+def test_gemm_f32_linear(M, N, K, split):
     """acr_gemm_f32 (exact-fp32 MFMA, reference precision) through LinearF32Fn: forward NT with bias + residual, input
     gradient NN on the weight as stored, weight + bias gradient in one TN sweep -- against fp64; ragged M (not a multiple
     of 128), N with a partial tile (200, 576), K tails (72 = 2.25 chunks) and a token count that is not a multiple of
-    the 32-deep chunk in the TN contraction (785, 1573, 1025)."""
-    from acr_wsss_amd import ops
+    the 32-deep chunk in the TN contraction (785, 1573, 1025).
+    split = 1: the same products as six bf16-MFMA terms of a three-way operand split (ACR_OPT_GEMM_F32_SPLIT) -- held to the
+    SAME 1e-5 against fp64 as the exact-fp32 MFMA, and bit-reproducible."""
+    from acr_wsss_amd import ops, _lib
     dev = _dev()
+    _lib.set_option("gemm_f32_split", split)
+    try:
+        _gemm_f32_linear_case(ops, dev, M, N, K)
+    finally:
+        _lib.set_option("gemm_f32_split", int(os.environ.get("ACR_GEMM_F32_SPLIT", "0") == "1"))
+
+
+def _gemm_f32_linear_case(ops, dev, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).to(dev).requires_grad_(True)
     w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).requires_grad_(True)
