@@ -88,10 +88,13 @@ class DPT(BaseModel):
             x = x.contiguous(memory_format=torch.channels_last)
         b, _, h, w = x.shape
         T = (h // 16) * (w // 16) + vit.num_tokens
-        stack = ops.MeanStack(b, vit.depth, T, x.device)
+        # GETAM passes with a truncated backward: the gradient-free prefix is one hipGraph replay (backbone.PrefixGraph),
+        # which owns the MeanStack its blocks write into
+        prefix = vit.prefix_graph(x, self.truncate_at) if self.truncate_at else None
+        stack = prefix.stack if prefix is not None else ops.MeanStack(b, vit.depth, T, x.device)
         taps = self.pretrained.activations
         taps.clear()
-        vit.forward_flex(x, stack=stack, taps=taps, truncate_at=self.truncate_at)
+        vit.forward_flex(x, stack=stack, taps=taps, truncate_at=self.truncate_at, prefix=prefix)
         return taps["4"], stack
 
     def _stack_tensor(self, stack):

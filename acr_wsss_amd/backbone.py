@@ -162,6 +162,23 @@ class ResNetV2(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     fused_weight_std = True
+    _frozen = None                # (key, w_hats, transposed) of the last forward with frozen weights
+    frozen_generation = 0         # bumped whenever that cache is rebuilt (PrefixGraph holds pointers into it)
+
+    def _standardised(self, convs, x):
+        """The standardised weights of all convolutions: one launch per forward while training; with frozen weights
+        (CAM generation: requires_grad off) they are kept until a weight changes (tensor version or storage)."""
+        frozen = not any(c.weight.requires_grad for c in convs)
+        if frozen:
+            key = (x.dtype,) + tuple((c.weight.data_ptr(), c.weight._version) for c in convs)
+            if self._frozen is not None and self._frozen[0] == key:
+                return self._frozen[1], self._frozen[2]
+        w_hats = ops.weight_std_all([c.weight for c in convs], convs[0].eps)
+        wts = ops.WeightStdAllFn.last_transposed
+        if frozen:
+            self._frozen = (key, w_hats, wts)
+            self.frozen_generation += 1
+        return w_hats, wts
 
     def forward(self, x, taps=None):
         convs = None
@@ -170,8 +187,8 @@ class ResNetV2(nn.Module):
             # kernels per convolution and direction
             convs = [m for m in self.modules() if isinstance(m, StdConv2dSame)]
             if all(c.weight.dtype == x.dtype for c in convs):
-                w_hats = ops.weight_std_all([c.weight for c in convs], convs[0].eps)
-                for c, w_hat, wt in zip(convs, w_hats, ops.WeightStdAllFn.last_transposed):
+                w_hats, wts = self._standardised(convs, x)
+                for c, w_hat, wt in zip(convs, w_hats, wts):
                     c._w_hat, c._w_hat_t = w_hat, wt
             else:
                 convs = None
@@ -319,6 +336,68 @@ class Block(nn.Module):
     hip_norm = True         # bf16 mode: LayerNorm on acr_layernorm_*_bf16
 
 
+class PrefixGraph:
+    """Stem + token embedding + blocks[:k] for one input geometry, captured once as a hipGraph and replayed per pass.
+
+    CAM generation (infer_cam.py:123-215) only differentiates blocks >= start_layer; everything below is a fixed chain of
+    ~700 small launches per pass that the host cannot issue as fast as the GPU retires them at batch 2.  The graph owns
+    its input, its MeanStack (the head-mean maps of blocks < k land in it on every replay) and the tokens it returns;
+    the attention state the blocks expose (``get_attn`` / ``last_pm``) is re-pointed to this graph's buffers on replay.
+    Weights are read in place, so in-place updates are seen; the frozen standardised conv weights are a cached copy
+    (ResNetV2._standardised) -- ``valid`` compares its generation and the parameter addresses."""
+
+    def __init__(self, vit, x, k):
+        self.k = k
+        self.x = x.detach().clone(memory_format=torch.preserve_format)
+        b, _, h, w = x.shape
+        T = (h // vit.patch_size[1]) * (w // vit.patch_size[0]) + vit.num_tokens
+        self.stack = ops.MeanStack(b, vit.depth, T, x.device)
+        self.taps = {}
+        stem = vit.patch_embed.backbone if isinstance(vit.patch_embed, HybridEmbed) else None
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):                 # MIOpen find / library workspaces / the frozen weight cache happen here, uncaptured
+                t, _ = vit.embed_tokens(self.x, None)
+                vit.run_blocks(t, self.stack, None, 0, k)
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            t, self.res_features = vit.embed_tokens(self.x, self.taps)
+            self.out = vit.run_blocks(t, self.stack, self.taps, 0, k)
+        self._blocks = list(vit.blocks[:k])
+        self.state = [(blk.attn._saved, blk.attn.last_pm) for blk in self._blocks]
+        self.stem_generation = stem.frozen_generation if stem is not None else 0
+        self.addresses = self._addresses(vit)
+
+    @staticmethod
+    def _addresses(vit):
+        return tuple(p.data_ptr() for p in vit.parameters())
+
+    def valid(self, vit):
+        stem = vit.patch_embed.backbone if isinstance(vit.patch_embed, HybridEmbed) else None
+        if self.addresses != self._addresses(vit):
+            return False
+        if stem is not None:
+            # rebuilds the cache when a conv weight changed in place; then the generation moves and the graph is stale
+            convs = [m for m in stem.modules() if isinstance(m, StdConv2dSame)]
+            if all(c.weight.dtype == self.x.dtype for c in convs):
+                stem._standardised(convs, self.x)
+            return stem.frozen_generation == self.stem_generation
+        return True
+
+    def replay(self, x, taps):
+        self.x.copy_(x)
+        self.graph.replay()
+        for blk, (saved, pm) in zip(self._blocks, self.state):
+            blk.attn._saved, blk.attn.last_pm = saved, pm
+            blk.attn._saved_do = blk.attn._saved_gpm = None
+            blk.attn._override = {}
+        if taps is not None:
+            taps.update(self.taps)
+        return self.out, self.res_features
+
+
 class VisionTransformer(nn.Module):
     def __init__(self, embed_dim=768, depth=12, num_heads=12, hybrid=True, patch=16, img_size=384,
                  num_classes=1000, distilled=False, in_chans=3):
@@ -371,10 +450,8 @@ class VisionTransformer(nn.Module):
         grid = grid.permute(0, 2, 3, 1).reshape(1, gs_h * gs_w, -1)
         return torch.cat([tok, grid], dim=1)
 
-    def forward_flex(self, x, stack=None, taps=None, truncate_at=None):
-        """models/vision_transformer.py:449-486.  ``stack`` (ops.MeanStack) receives the head-mean maps,
-        ``taps`` the DPT activations dict; ``truncate_at`` = k detaches the tokens entering block k so a
-        later backward stops there (GETAM only needs gradients of blocks >= start_layer)."""
+    def embed_tokens(self, x, taps=None):
+        """Stem (hybrid) or patch convolution, class/distillation tokens, position embedding: (B,3,h,w) -> ((B,T,D), stem features)."""
         b, c, h, w = x.shape
         pos = self._resize_pos_embed(self.pos_embed, h // self.patch_size[1], w // self.patch_size[0])
         if isinstance(self.patch_embed, HybridEmbed):
@@ -390,17 +467,67 @@ class VisionTransformer(nn.Module):
         toks = [self.cls_token.expand(b, -1, -1)]
         if self.dist_token is not None:
             toks.append(self.dist_token.expand(b, -1, -1))
-        x = torch.cat(toks + [x], dim=1) + pos
-        for i, blk in enumerate(self.blocks):
-            if truncate_at is not None and i == truncate_at:
-                x = x.detach().requires_grad_(True)
-                self.trunc_input = x
-            x = blk(x, stack, i)
+        return torch.cat(toks + [x], dim=1) + pos, res_features
+
+    def run_blocks(self, x, stack, taps, lo, hi):
+        for i in range(lo, hi):
+            x = self.blocks[i](x, stack, i)
             if taps is not None:
                 if i == self.tap3:
                     taps["3"] = x
                 if i == self.tap4:
                     taps["4"] = x
+        return x
+
+    def forward_flex(self, x, stack=None, taps=None, truncate_at=None, prefix=None):
+        """models/vision_transformer.py:449-486.  ``stack`` (ops.MeanStack) receives the head-mean maps,
+        ``taps`` the DPT activations dict; ``truncate_at`` = k detaches the tokens entering block k so a
+        later backward stops there (GETAM only needs gradients of blocks >= start_layer).  ``prefix`` (a PrefixGraph
+        from ``prefix_graph``, whose MeanStack must be the ``stack`` passed here) replays everything below block k as
+        one captured hipGraph instead of launching it kernel by kernel."""
+        k = 0 if truncate_at is None else truncate_at
+        if prefix is not None:
+            assert truncate_at is not None and prefix.k == truncate_at and stack is prefix.stack
+            x, res_features = prefix.replay(x, taps)
+        else:
+            x, res_features = self.embed_tokens(x, taps)
+            x = self.run_blocks(x, stack, taps, 0, k)
+        if truncate_at is not None:
+            x = x.detach().requires_grad_(True)
+            self.trunc_input = x
+        x = self.run_blocks(x, stack, taps, k, len(self.blocks))
         return self.norm(x) if truncate_at is None else None, res_features
+
+    graph_prefix = os.environ.get("ACR_INFER_GRAPH", "1") != "0"      # A/B: hipGraph replay of the gradient-free prefix
+    max_prefix_graphs = 8
+
+    def prefix_graph(self, x, k):
+        """The PrefixGraph for inputs shaped like ``x`` and a backward truncated at block ``k`` -- or None when the prefix
+        cannot be replayed: a parameter or the input wants a gradient, a kernel timer is recording, k == 0, the switch is
+        off, or an earlier capture of this geometry failed."""
+        if (not self.graph_prefix or not k or not x.is_cuda or x.requires_grad or ops.KERNEL_TIMER is not None
+                or torch.is_autocast_enabled() or torch.cuda.is_current_stream_capturing()
+                or any(p.requires_grad for p in self.parameters())):
+            return None
+        key = (tuple(x.shape), x.dtype, x.device, x.is_contiguous(memory_format=torch.channels_last), k, self.training,
+               self.blocks[0].attn.keep_state_in_training)
+        cache = self.__dict__.setdefault("_prefix_graphs", OrderedDict())
+        g = cache.get(key)
+        if g is not None and g is not False and not g.valid(self):
+            del cache[key]                     # the parameters moved (.to / .float / load into new storage): capture again
+            g = None
+        if g is None:
+            try:
+                g = PrefixGraph(self, x, k)
+            except RuntimeError as e:          # an op that cannot be captured on this build: stay on eager launches
+                import warnings
+                warnings.warn("hipGraph capture of the inference prefix failed (%s); running it eagerly" % str(e).splitlines()[0])
+                torch.cuda.synchronize()
+                g = False
+            cache[key] = g
+            while len(cache) > self.max_prefix_graphs:
+                cache.popitem(last=False)
+        cache.move_to_end(key)
+        return g or None
 
     tap3, tap4 = 8, 11

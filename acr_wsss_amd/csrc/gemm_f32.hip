@@ -732,10 +732,13 @@ static TailPlan gemm_tail_plan(int M, int N, int K) {
     TailPlan p = {0, 1, 0};
     if (acr_opt(ACR_OPT_GEMM_F32_NOTAIL) != 0 || (K % F_BK) != 0 || (N % 4) != 0) return p;
     const int tiles = ((M + F_BM - 1) / F_BM) * ((N + F_BN - 1) / F_BN);
-    const int R = tiles % 256;
-    if (tiles < 512 || R == 0) return p;
+    // A product of at most a third of the chip's 512 workgroup slots (CAM generation at batch 2: 18-170 tiles) is all tail:
+    // every tile is K-split, up to 16 ways, so that the launch fills the CUs instead of running 24-96 chunks on a few of them.
+    const bool small = tiles * 3 <= 512;
+    const int R = small ? tiles : tiles % 256;
+    if ((!small && tiles < 512) || R == 0) return p;
     int s = 512 / R;
-    if (s > 8) s = 8;
+    if (s > (small ? 16 : 8)) s = small ? 16 : 8;
     const int maxs = K / (2 * F_BK);                         // at least two chunks per part
     if (s > maxs) s = maxs;
     if (s < 3) return p;
@@ -844,7 +847,8 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         g.tiles_launch -= tp.ntail;
         grid = dim3((unsigned)g.tiles_launch);
     }
-    if (mode == ACR_GEMM_NT) {
+    if (g.tiles_launch == 0) {                              // a small product: every tile goes the K-split way
+    } else if (mode == ACR_GEMM_NT) {
         if (act == 0) ACR_F32_LAUNCH(true, true, 0);
         else if (act == 1) ACR_F32_LAUNCH(true, true, 1);
         else ACR_F32_LAUNCH(true, true, 2);

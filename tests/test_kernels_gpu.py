@@ -488,13 +488,14 @@ def test_weight_transposes_cache():
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 32, 32), (130, 200, 72), (785, 2304, 768), (2 * 785 + 3, 768, 3072), (333, 576, 192),
-                                   (25120, 768, 768), (1025, 3072, 768)])
+                                   (25120, 768, 768), (1025, 3072, 768), (1154, 768, 3072), (290, 768, 768)])
 @pytest.mark.parametrize("split", [0, 1])
 def test_gemm_f32_linear(M, N, K, split):
     """acr_gemm_f32 (exact-fp32 MFMA, reference precision) through LinearF32Fn: forward NT with bias + residual, input
     gradient NN on the weight as stored, weight + bias gradient in one TN sweep -- against fp64; ragged M (not a multiple
     of 128), N with a partial tile (200, 576), K tails (72 = 2.25 chunks) and a token count that is not a multiple of
-    the 32-deep chunk in the TN contraction (785, 1573, 1025).
+    the 32-deep chunk in the TN contraction (785, 1573, 1025); products of a few dozen tiles (CAM generation at batch 2:
+    1154 = 2 x 577 and 290 = 2 x 145 tokens), which run entirely as K-split parts + the tail epilogue.
     split = 1: the same products as six bf16-MFMA terms of a three-way operand split (ACR_OPT_GEMM_F32_SPLIT) -- held to the
     SAME 1e-5 against fp64 as the exact-fp32 MFMA, and bit-reproducible."""
     from acr_wsss_amd import ops, _lib
@@ -535,7 +536,7 @@ def _gemm_f32_linear_case(ops, dev, M, N, K):
     assert torch.equal(dw1, w.grad)
 
 
-@pytest.mark.parametrize("M,D,Hd", [(197 * 2, 192, 768), (785, 768, 3072), (131, 128, 260)])
+@pytest.mark.parametrize("M,D,Hd", [(197 * 2, 192, 768), (785, 768, 3072), (131, 128, 260), (290, 768, 3072)])
 def test_fused_mlp_f32(M, D, Hd):
     """MlpF32Fn (GELU / GELU' inside the fp32 GEMM epilogues) against fp64 fc2(gelu(fc1(x))) + resid and against the
     stock torch fp32 ops it replaces (same exact-erf GELU): output and all six gradients."""
