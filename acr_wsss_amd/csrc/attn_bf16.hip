@@ -29,7 +29,29 @@ struct AttnGeomB {
     int64_t osb, ost, osh;
 };
 
+#ifdef LAB_NOEXP       // lab: what the transcendental costs (wrong results)
+__device__ __forceinline__ float fast_exp2(float x) { return x * 1e-3f; }
+#else
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
+
+#ifdef LAB_TLB                     // lab builds only (scripts/lab/attn_bf16_phases.py): per-phase cycle sums of every wave 0
+__device__ unsigned long long g_lab_attnb[8 * 16384];
+extern "C" int acr_lab_attnb_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_attnb), (size_t)n * 8);
+}
+#define LABB_T() __builtin_amdgcn_s_memtime()
+#define LABB_DECL unsigned long long lt_[6] = {0, 0, 0, 0, 0, 0}, lp_ = 0; (void)lp_
+#define LABB_MARK() (lp_ = LABB_T())
+#define LABB_ADD(i) do { const unsigned long long n_ = LABB_T(); lt_[i] += n_ - lp_; lp_ = n_; } while (0)
+#define LABB_OUT(kind, nsteps) do { if (threadIdx.x == 0 && blockIdx.x < 16384) { unsigned long long* d_ = g_lab_attnb + 8 * blockIdx.x; \
+        for (int i_ = 0; i_ < 6; ++i_) d_[i_] = lt_[i_]; d_[6] = (nsteps); d_[7] = (kind); } } while (0)
+#else
+#define LABB_DECL
+#define LABB_MARK()
+#define LABB_ADD(i)
+#define LABB_OUT(kind, nsteps)
+#endif
 
 // Compiler-level fence: global loads issued before it stay before it, LDS stores after it stay after it.  Without
 // it hipcc sinks every staging load next to its ds_write and drains vmcnt(0) per 16-byte chunk.
@@ -477,10 +499,14 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
     int cur = 0;
     // one step = 64 keys.  EDGE steps (the partial last tile, and the step that prefetches it) carry the clamps and
     // the key masks; all other steps are straight-line code without a single compare/select.
+    LABB_DECL;
     auto step = [&](int k0, auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
+        LABB_MARK();
+#ifndef LAB_NOSTAGE     // lab: what streaming the K/V tiles costs (wrong results)
         tile_gload<128, EDGE>(kr, k + base, g.st, k0 + 64, g.T, tid);
         tile_gload<128, EDGE>(vr, v + base, g.st, k0 + 64, g.T, tid);
+#endif
         f32x4 gq[2][4];
         if (HAS_G) {
 #pragma unroll
@@ -488,10 +514,15 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
 #pragma unroll
                 for (int grp = 0; grp < 4; ++grp) {
                     const int go = k0 + 32 * kb + 8 * grp;
+#ifdef LAB_NOGLOAD     // lab: what fetching G costs (wrong results)
+                    gq[kb][grp] = f32x4{1e-3f, 2e-3f, -1e-3f, 1e-4f} * (float)go;
+#else
                     __builtin_memcpy(&gq[kb][grp], grow + (EDGE ? min(go, gmax) : go), 16);
+#endif
                 }
         }
         ACR_MEMBAR();
+        LABB_ADD(0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const bf16_t* ktc = kt[cur] + kb * 32 * BP;
@@ -499,6 +530,7 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
             f32x16 s = {0}, dp = {0};
             mma_rowop_bf(s, ktc, qreg, lane);               // S^T raw [key = krow][query = r]
             mma_rowop_bf(dp, vtc, doreg, lane);             // dP^T
+            LABB_ADD(1);
             // in place: s becomes dS and dp becomes P.  (Filling fresh f32x16 values element by element makes hipcc
             // initialise each 16-register tuple with 16 v_mov first: 64 of a step's ~250 VALU instructions.)
 #pragma unroll
@@ -519,22 +551,33 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
                 }
                 s[reg] = p * (t - dl);
             }
+            LABB_ADD(2);
             mma_accop_a_bf(dq0, s, ktc, 0, lane);           // dQ[query = krow][d = 32*blk + r]
             mma_accop_a_bf(dq1, s, ktc, 1, lane);
+#ifndef LAB_NOY
             if (HAS_G) {
                 mma_accop_a_bf(y0, dp, ktc, 0, lane);       // Y[query = krow][d]
                 mma_accop_a_bf(y1, dp, ktc, 1, lane);
             }
+#endif
+            LABB_ADD(3);
         }
         ACR_MEMBAR();
+#ifndef LAB_NOSTAGE
         tile_lstore<128>(kt[cur ^ 1], kr, k0 + 64, g.T, tid);
         tile_lstore<128>(vt[cur ^ 1], vr, k0 + 64, g.T, tid);
+#endif
+        LABB_ADD(4);
         __syncthreads();
+        LABB_ADD(5);
+#ifndef LAB_NOSTAGE
         cur ^= 1;
+#endif
     };
     int k0 = 0;
     for (; k0 + 128 <= g.T; k0 += 64) step(k0, std::false_type{});
     for (; k0 < g.T; k0 += 64) step(k0, std::true_type{});
+    LABB_OUT(1, (g.T + 63) >> 6);
     if (HAS_G) {
         rho += __shfl_xor(rho, 32);                         // both halves of a lane pair hold keys of the same query row
         rho *= invH;                                        // lane r (either half): rho_{q0+r} / H
@@ -782,7 +825,11 @@ __global__ __launch_bounds__(128, 2) void attn_dkdv_bf16_kernel(AttnGeomB g, con
                     const float* gu = gm + (int64_t)b * gm_sb + (int64_t)(q0 + 32 * qb) * gst;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg)
+#ifdef LAB_NOGLOAD
+                        gv[reg] = 1e-3f * (float)(reg + q0);
+#else
                         gv[reg] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gu + ((reg & 3) + 8 * (reg >> 2)) * gst) + gloff);
+#endif
                 }
             }
             ACR_MEMBAR();

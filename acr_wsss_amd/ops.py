@@ -102,6 +102,10 @@ class AttnCoreFn(Function):
     @staticmethod
     def forward(ctx, qkv, heads, stack, layer, owner):
         L.require_gpu(qkv)
+        # an output nobody differentiated arrives as None in backward, not as a zero tensor: CAM generation back-propagates
+        # the class logit through `o` only, and a materialised zero head-mean gradient would cost a (B,T,T) fill + re-layout
+        # per layer and send the backward down its with-G path
+        ctx.set_materialize_grads(False)
         if not qkv.is_contiguous():
             qkv = qkv.contiguous()
         B, T, D3 = qkv.shape
