@@ -180,6 +180,14 @@ class ResNetV2(nn.Module):
             self.frozen_generation += 1
         return w_hats, wts
 
+    def refresh_frozen(self, dtype):
+        """Bring the frozen standardised-weight cache up to date on the current stream (no-op while a weight wants a gradient)."""
+        convs = [m for m in self.modules() if isinstance(m, StdConv2dSame)]
+        w = convs[0].weight
+        if self.fused_weight_std and w.is_cuda and w.dtype == dtype and all(c.weight.dtype == dtype for c in convs) \
+                and not any(c.weight.requires_grad for c in convs):
+            self._standardised(convs, w)
+
     def forward(self, x, taps=None):
         convs = None
         if self.fused_weight_std and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and not torch.is_autocast_enabled():

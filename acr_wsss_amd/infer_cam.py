@@ -18,8 +18,21 @@ import torch.nn.functional as F
 from . import ops
 
 
+_STREAMS = {}
+
+
+def _scale_streams(dev, n):
+    pool = _STREAMS.setdefault(torch.device(dev), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool
+
+
+CONCURRENT_SCALES = os.environ.get("ACR_INFER_STREAMS", "1") != "0"        # A/B: one stream per scale
+
+
 def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", aff=True, scales=(1,), truncate=True,
-                     batch_flips=True):
+                     batch_flips=True, concurrent_scales=None):
     """CAMs of a batch of same-sized network inputs.  imgs (B,3,h,w) normalised, on the GPU; labels (B,C) multi-hot;
     out_hws: B pairs (W,H) = (image height, image width) as infer_cam.py:138 names them (each image keeps its own output
     size).  Returns a list of B (cam_dict, patch_cam_dict): {class index: float32 (W,H) numpy array}, min-max
@@ -29,6 +42,8 @@ def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", 
     ``batch_flips``, the flipped and the plain pass of a scale -- share one forward, and one backward per class rank
     k serves the k-th positive class of every image: d(sum_i logit[i, c_i^k]) / d tokens is block-diagonal in i."""
     dev = imgs.device
+    if concurrent_scales is None:
+        concurrent_scales = CONCURRENT_SCALES
     B, _, h, w = imgs.shape
     C = labels.shape[1]
     labels = labels.to(dev).float()
@@ -49,44 +64,85 @@ def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", 
     attns = [blk.attn for blk in vit.blocks]
     for a in attns:
         a.keep_state_in_training = True
+    # Scales are independent until their maps are summed, and the small ones leave most of the chip idle (a batch-2 pass at
+    # scale 0.5 launches 18-72 workgroups per GEMM): each input geometry runs on a stream of its own and only the final
+    # resize-and-accumulate steps, a few tiny kernels, are issued on the caller's stream in the reference's order -- so the
+    # sums are bit-identical to the one-stream order.
+    main = torch.cuda.current_stream(dev)
+    side = _scale_streams(dev, len(scales)) if (concurrent_scales and len(scales) > 1) else None
+    if side is not None and hasattr(vit.patch_embed, "backbone"):
+        vit.patch_embed.backbone.refresh_frozen(imgs.dtype)     # the shared standardised conv weights: before the fork
+    by_shape, done = {}, []
+
+    def flush(rec):
+        patch_items, cam_items, ev = rec
+        if ev is not None:
+            main.wait_event(ev)
+        for t, i, flipped, ph, pw in patch_items:
+            # patch-token CAM: (1,N,C) -> (C,ph,pw) -> bilinear(align_corners=False) * label, un-flip, sum
+            ops.bilinear_resize(t.reshape(ph, pw, C), out_hws[i], False, chan_mul=labels[i], hflip=flipped, out=patch_acc[i],
+                                channels_last=True)
+            if ev is not None:
+                t.record_stream(main)
+        for t, i, flipped, ph, pw in cam_items:
+            ops.bilinear_resize(t.reshape(len(classes[i]), ph, pw), out_hws[i], True, hflip=flipped, out=cam_acc[i])
+            if ev is not None:
+                t.record_stream(main)
+
     try:
-        for scale in scales:
-            base = F.interpolate(imgs, size=(int(h * scale), int(w * scale)), mode="bilinear", align_corners=False)
-            ph, pw = int((h * scale) // 16), int((w * scale) // 16)
-            # the two passes of a scale (h-flipped first, then plain: infer_cam.py:147-153) are independent samples: run
-            # them as ONE batch -- at small batches the pass is launch-bound, not GPU-bound
-            passes = ((True, False),) if batch_flips else ((True,), (False,))
-            for flips in passes:
-                inp = torch.cat([base.flip(-1) if f else base for f in flips], dim=0)       # sample index = fi * B + i
-                with torch.enable_grad():
-                    cls_pred, _, attn, patch_cam = model.forward_cam(inp)
+        # with side streams the largest geometry is issued first: its long kernels then run while the host is still issuing
+        # the small passes, which fill the gaps (the accumulation order below is the list's order either way)
+        order = sorted(range(len(scales)), key=lambda si: -scales[si]) if side is not None else range(len(scales))
+        for si in order:
+            scale = scales[si]
+            hs, ws = int(h * scale), int(w * scale)
+            st = main
+            if side is not None:
+                st = side[by_shape.setdefault((hs, ws), len(by_shape))]     # one stream per geometry (a PrefixGraph is per geometry)
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                base = F.interpolate(imgs, size=(hs, ws), mode="bilinear", align_corners=False)
+                ph, pw = int((h * scale) // 16), int((w * scale) // 16)
+                # the two passes of a scale (h-flipped first, then plain: infer_cam.py:147-153) are independent samples: run
+                # them as ONE batch -- at small batches the pass is launch-bound, not GPU-bound
+                passes = ((True, False),) if batch_flips else ((True,), (False,))
+                for flips in passes:
+                    inp = torch.cat([base.flip(-1) if f else base for f in flips], dim=0)       # sample index = fi * B + i
+                    patch_items, cam_items = [], []
+                    with torch.enable_grad():
+                        cls_pred, _, attn, patch_cam = model.forward_cam(inp)
+                        pc = patch_cam.detach().float()
+                        for fi, flipped in enumerate(flips):
+                            for i in range(B):
+                                patch_items.append((pc[fi * B + i], i, flipped, ph, pw))
+                        rows = [[[] for _ in range(B)] for _ in flips]
+                        for k in range(kmax):
+                            live = [i for i in range(B) if k < len(classes[i])]
+                            tgt = sum(cls_pred[fi * B + i, classes[i][k]] for fi in range(len(flips)) for i in live)
+                            if truncate:
+                                torch.autograd.grad(tgt, vit.trunc_input, retain_graph=True)
+                            else:
+                                model.zero_grad()
+                                tgt.backward(retain_graph=True)
+                            for fi in range(len(flips)):
+                                for i in live:
+                                    cam, _, _ = model.getam(fi * B + i, start_layer=start_layer, func=func)
+                                    rows[fi][i].append(cam)
                     for fi, flipped in enumerate(flips):
                         for i in range(B):
-                            # patch-token CAM: (1,N,C) -> (C,ph,pw) -> bilinear(align_corners=False) * label, un-flip, sum
-                            ops.bilinear_resize(patch_cam[fi * B + i].detach().float().reshape(ph, pw, C), out_hws[i], False,
-                                                chan_mul=labels[i], hflip=flipped, out=patch_acc[i], channels_last=True)
-                    rows = [[[] for _ in range(B)] for _ in flips]
-                    for k in range(kmax):
-                        live = [i for i in range(B) if k < len(classes[i])]
-                        tgt = sum(cls_pred[fi * B + i, classes[i][k]] for fi in range(len(flips)) for i in live)
-                        if truncate:
-                            torch.autograd.grad(tgt, vit.trunc_input, retain_graph=True)
-                        else:
-                            model.zero_grad()
-                            tgt.backward(retain_graph=True)
-                        for fi in range(len(flips)):
-                            for i in live:
-                                cam, _, _ = model.getam(fi * B + i, start_layer=start_layer, func=func)
-                                rows[fi][i].append(cam)
-                for fi, flipped in enumerate(flips):
-                    for i in range(B):
-                        if not classes[i]:
-                            continue
-                        cams = torch.cat(rows[fi][i], dim=0).contiguous()                # (n_cls, N)
-                        if aff:
-                            cams = ops.aff_refine(attn[fi * B + i].detach().contiguous(), cams)   # patch_aff @ cam (:164-165,183-184)
-                        ops.bilinear_resize(cams.reshape(len(classes[i]), ph, pw), out_hws[i], True, hflip=flipped,
-                                            out=cam_acc[i])
+                            if not classes[i]:
+                                continue
+                            cams = torch.cat(rows[fi][i], dim=0).contiguous()                # (n_cls, N)
+                            if aff:
+                                cams = ops.aff_refine(attn[fi * B + i].detach().contiguous(), cams)   # patch_aff @ cam (:164-165,183-184)
+                            cam_items.append((cams, i, flipped, ph, pw))
+                    rec = (patch_items, cam_items, st.record_event() if side is not None else None)
+                    if side is None:
+                        flush(rec)
+                    else:
+                        done.append((si, rec))
+        for _, rec in sorted(done, key=lambda d: d[0]):      # stable: the passes of a scale keep their order
+            flush(rec)
     finally:
         model.truncate_at = old_trunc
         for p in frozen:
@@ -105,12 +161,12 @@ def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", 
 
 
 def infer_cam_image(model, img, label, out_hw, start_layer=10, func="grad", aff=True, scales=(1,), truncate=True,
-                    batch_flips=True):
+                    batch_flips=True, concurrent_scales=None):
     """CAMs of one image (the unit of infer_cam.py:123 ``chunker(..., 1)``): img (1,3,h,w), label (1,C), out_hw = (W,H).
     Returns (cam_dict, patch_cam_dict); see infer_cam_images."""
     assert img.shape[0] == 1, "one image; use infer_cam_images for a batch"
     return infer_cam_images(model, img, label, [out_hw], start_layer=start_layer, func=func, aff=aff, scales=scales,
-                            truncate=truncate, batch_flips=batch_flips)[0]
+                            truncate=truncate, batch_flips=batch_flips, concurrent_scales=concurrent_scales)[0]
 
 
 def seeds_from_cam_dict(cam_dict, threshold, num_cls=21):
