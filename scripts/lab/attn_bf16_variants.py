@@ -15,9 +15,11 @@ gst = torch.zeros(B, T, ops.pad4(T), device=dev)
 gst[:, :, :T] = torch.randn(B, T, T, device=dev) * 1e-3
 gpm = gst[:, :, :T]
 stack = ops.MeanStack(B, 1, T, dev)
-variants = [("default", {}), ("dq16 (4 waves/SIMD)", {"dq_variant": 16}), ("dq16 (3 waves/SIMD)", {"dq_variant": 163})]
-if "bwd16" in _lib.OPTIONS:
-    variants += [("dq16/4 + dkdv16", {"dq_variant": 16, "bwd16": 1}), ("dq16/3 + dkdv16", {"dq_variant": 163, "bwd16": 1})]
+# the shipped variants; a lab build adds its own (this round: 16 / 163 = dQ on 16-row waves at 4 / 3 waves per SIMD, not kept)
+variants = [("default", {}), ("dQ 2-wave sweep", {"dq_variant": 2}), ("dQ 4-wave sweep", {"dq_variant": 4})]
+for v in os.environ.get("ACR_LAB_DQ_VARIANTS", "").split(","):
+    if v.strip():
+        variants.append(("dq_variant %s" % v.strip(), {"dq_variant": int(v)}))
 for with_g in (True, False):
     o, pm = ops.attention_core(qkv, H, stack, 0, None)
     outs, grads = ([o, pm], [do, gpm]) if with_g else ([o], [do])
