@@ -155,14 +155,18 @@ def _dp_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_grad_sync_two_ranks_gloo():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 8])
+def test_grad_sync_ranks_gloo(world):
+    """GradSync over gloo with 2 ranks and with 8 (BASELINE configs[2] is 8-way data parallel; no 8-GPU node has run this code,
+    so the 8-rank collective sequence is rehearsed here on the CPU: one sample per rank)."""
+    port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
     assert out["nbuckets"] >= 3
     nb = out["nbuckets"]
-    torch.testing.assert_close(out[0], out[1], rtol=0, atol=0)          # replicas stay identical
+    for r in range(1, world):
+        torch.testing.assert_close(out[0], out[r], rtol=0, atol=0)      # replicas stay identical
     # Buckets go out in index order only (identical collective sequences on every rank by construction).  Bucket 0 (first
     # filled by backward) shares its storage with the never-used tensor: in step 0 nothing is known about it, so bucket 0
     # -- and with it every later bucket -- can only be launched from finish(); from step 1 on all of them must go out
