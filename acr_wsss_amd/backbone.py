@@ -362,7 +362,7 @@ class PrefixGraph:
         self.stack = ops.MeanStack(b, vit.depth, T, x.device)
         self.taps = {}
         stem = vit.patch_embed.backbone if isinstance(vit.patch_embed, HybridEmbed) else None
-        side = torch.cuda.Stream(device=x.device)
+        side = torch.cuda.Stream(device=x.device)          # warm-up off the caller's stream, as torch.cuda.graph asks
         side.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(2):                 # MIOpen find / library workspaces / the frozen weight cache happen here, uncaptured
@@ -508,6 +508,11 @@ class VisionTransformer(nn.Module):
 
     graph_prefix = os.environ.get("ACR_INFER_GRAPH", "1") != "0"      # A/B: hipGraph replay of the gradient-free prefix
     max_prefix_graphs = 8
+
+    def train(self, mode=True):
+        if mode:                               # back to training: the captured prefixes' private pools (activations of every
+            self.__dict__.pop("_prefix_graphs", None)      # geometry seen) go back to the allocator
+        return super().train(mode)
 
     def prefix_graph(self, x, k):
         """The PrefixGraph for inputs shaped like ``x`` and a backward truncated at block ``k`` -- or None when the prefix
