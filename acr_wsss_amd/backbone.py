@@ -472,6 +472,11 @@ class VisionTransformer(nn.Module):
         else:
             x = pe(x)
         x = x.flatten(2).transpose(1, 2)
+        if x.shape[1] + self.num_tokens != pos.shape[1]:
+            # the reference fails at the addition below with a bare size mismatch (vision_transformer.py:449-467 sizes the
+            # position embedding with h // 16 while the SAME-padded stem yields ceil(h / 16) rows)
+            raise ValueError("input %dx%d is not a multiple of the %d-pixel patch: %d patch tokens but a %d-entry position "
+                             "embedding" % (h, w, self.patch_size[0], x.shape[1], pos.shape[1] - self.num_tokens))
         toks = [self.cls_token.expand(b, -1, -1)]
         if self.dist_token is not None:
             toks.append(self.dist_token.expand(b, -1, -1))
