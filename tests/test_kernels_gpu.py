@@ -61,6 +61,31 @@ def test_consistency(B, L, p):
     assert abs(float(aff) - float(ref_aff)) <= 5e-6 * abs(float(ref_aff)) + 1e-9
 
 
+def test_consistency_full_size_is_a_mean_over_samples():
+    """The loss at BASELINE size (16 images x 2 views, 12 layers, T = 785: a 946 MB stack) through a size-independent property:
+    both terms are means over equally sized per-sample blocks, so they equal the mean of the 16 one-sample results, and sample
+    i's gradient is 1/16 of its one-sample gradient (checked on the first and the last sample)."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    B, L, p = 16, 12, 28
+    T = p * p + 1
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.rand(2 * B, L, T, T, generator=g).to(dev).requires_grad_(True)
+    cls, aff = ops.consistency(a, p)
+    (cls * 1.7 - aff * 0.6).backward()
+    singles = []
+    for i in range(B):
+        ai = torch.stack([a.detach()[i], a.detach()[B + i]]).requires_grad_(i in (0, B - 1))
+        ci, fi = ops.consistency(ai, p)
+        if ai.requires_grad:
+            (ci * 1.7 - fi * 0.6).backward()
+            for view, row in ((0, i), (1, B + i)):
+                torch.testing.assert_close(a.grad[row], ai.grad[view] / B, rtol=1e-5, atol=1e-12)
+        singles.append((float(ci.detach()), float(fi.detach())))
+    mc, mf = sum(c for c, _ in singles) / B, sum(f for _, f in singles) / B
+    assert abs(float(cls) - mc) <= 2e-6 * abs(mc) and abs(float(aff) - mf) <= 2e-6 * abs(mf)
+
+
 @pytest.mark.parametrize("B,T,H", [(2, 2, 1), (1, 17, 12), (2, 197, 3), (1, 785, 12), (1, 1025, 2),
                                    (1, 2305, 3), (1, 3137, 1)])          # multi-scale inference: 768^2 and 896^2
 @pytest.mark.parametrize("with_g", [True, False])
@@ -123,6 +148,35 @@ def test_attention_bf16(B, T, H, with_g, f32math):
     scale = qd.grad.abs().max()
     assert err.max() <= (1e-2 if f32math else 2.5e-2) * scale, float(err.max() / scale)
     assert err.mean() <= (1.5e-3 if f32math else 3e-3) * scale, float(err.mean() / scale)
+
+
+@pytest.mark.parametrize("B,T,dtype", [(32, 785, torch.float32), (32, 785, torch.bfloat16), (16, 2305, torch.float32)])
+def test_attention_full_size_is_per_sample(B, T, dtype):
+    """BASELINE-size launches (32 views x 12 heads x 785 tokens: one training step; 16 samples x 2305 tokens: eight images at scale 2,
+    a 4 GB score buffer, byte offsets beyond 2^32) checked through a size-independent property: attention is per sample, so the
+    LAST sample of the big batch must come out exactly as when it is run alone -- forward, head mean and every gradient.  (The
+    small-shape tests above pin the values against fp64; this pins the indexing at full size.)"""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    H = 12
+    g = torch.Generator(device="cpu").manual_seed(B + T)
+    qkv = (1.5 * torch.randn(B, T, 3 * H * 64, generator=g)).to(dev).to(dtype)
+    d_o = torch.randn(B, T, H * 64, generator=g).to(dev).to(dtype)
+    gst = torch.zeros(B, T, ops.pad4(T), device=dev)
+    gst[:, :, :T] = torch.randn(B, T, T, generator=g).to(dev) * 1e-2
+    outs = []
+    for sl in (slice(0, B), slice(B - 1, B)):
+        x = qkv[sl].clone().requires_grad_(True)
+        n = x.shape[0]
+        stack = ops.MeanStack(n, 1, T, dev)
+        o, pm = ops.attention_core(x, H, stack, 0, None)
+        torch.autograd.backward([o, pm], [d_o[sl].contiguous(), gst[sl][:, :, :T]])
+        outs.append((o.detach()[-1].clone(), pm.detach()[-1].clone(), x.grad[-1].clone()))
+        del x, o, pm, stack
+        torch.cuda.empty_cache()
+    for name, a, b in zip(("o", "head mean", "dqkv"), outs[0], outs[1]):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
 
 
 def test_probs_dprobs_bf16():
