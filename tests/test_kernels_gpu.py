@@ -83,7 +83,7 @@ def test_consistency_full_size_is_a_mean_over_samples():
                 torch.testing.assert_close(a.grad[row], ai.grad[view] / B, rtol=1e-5, atol=1e-12)
         singles.append((float(ci.detach()), float(fi.detach())))
     mc, mf = sum(c for c, _ in singles) / B, sum(f for _, f in singles) / B
-    assert abs(float(cls) - mc) <= 2e-6 * abs(mc) and abs(float(aff) - mf) <= 2e-6 * abs(mf)
+    assert abs(float(cls.detach()) - mc) <= 2e-6 * abs(mc) and abs(float(aff.detach()) - mf) <= 2e-6 * abs(mf)
 
 
 @pytest.mark.parametrize("B,T,H", [(2, 2, 1), (1, 17, 12), (2, 197, 3), (1, 785, 12), (1, 1025, 2),
@@ -728,6 +728,40 @@ def test_conv1x1_f32(N, cin, cout, H, W):
     for n, a, b in (("y", y, ref), ("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad)):
         err = (a.double() - b).abs().max() / b.abs().max()
         assert err <= 1e-5, (n, float(err))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_kernels_full_size_are_per_sample(dtype):
+    """GroupNorm (+ residual + ReLU) and the NCHW 1x1 convolution at the largest launches of the BASELINE step (32 views, 256 channels
+    at 112 x 112: 103 M elements per tensor), through a size-independent property: both are per sample in y and dx, so the last of the
+    32 samples must equal the same sample run alone, bit for bit (the weight gradients sum over samples and are left to the fp64
+    tests at small N)."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    N, C, Hh, Ww = 32, 256, 112, 112
+    g = torch.Generator(device="cpu").manual_seed(3)
+    one = lambda *shape: torch.randn(*shape, generator=g).to(dev).to(dtype)
+    x, r, dy = one(N, C, Hh, Ww), one(N, C, Hh, Ww), one(N, C, Hh, Ww)
+    gw, gb = (1 + 0.2 * one(C)).contiguous(), (0.3 * one(C)).contiguous()
+    cw = (one(64, C, 1, 1) * C ** -0.5).contiguous()
+    dyc = one(N, 64, Hh, Ww)
+    res = []
+    for sl in (slice(0, N), slice(N - 1, N)):
+        xi = x[sl].clone().requires_grad_(True)
+        ri = r[sl].clone().requires_grad_(True)
+        assert ops.groupnorm_fusable(xi, ri) and ops.conv1x1_fusable(xi, cw, 1)
+        y = ops.groupnorm_act(xi, gw, gb, "add_relu", ri)
+        (y.float() * dy[sl].float()).sum().backward()
+        gn = (y.detach()[-1].clone(), xi.grad[-1].clone(), ri.grad[-1].clone())
+        xc = x[sl].clone().requires_grad_(True)
+        yc = ops.conv1x1(xc, cw)
+        (yc.float() * dyc[sl].float()).sum().backward()
+        res.append(gn + (yc.detach()[-1].clone(), xc.grad[-1].clone()))
+        del xi, ri, y, xc, yc
+        torch.cuda.empty_cache()
+    for name, a, b in zip(("gn y", "gn dx", "gn dres", "conv y", "conv dx"), res[0], res[1]):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
 
 
 def test_f32_input_gradients_on_cached_transposes_are_bit_identical():
