@@ -542,7 +542,8 @@ def test_weight_transposes_cache():
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 32, 32), (130, 200, 72), (785, 2304, 768), (2 * 785 + 3, 768, 3072), (333, 576, 192),
-                                   (25120, 768, 768), (1025, 3072, 768), (1154, 768, 3072), (290, 768, 768)])
+                                   (25120, 768, 768), (1025, 3072, 768), (1154, 768, 3072), (290, 768, 768),
+                                   (256, 256, 2048), (1280, 2176, 256)])     # 4 tiles split 16 ways; 170 tiles (the limit) 3 ways
 @pytest.mark.parametrize("split", [0, 1])
 def test_gemm_f32_linear(M, N, K, split):
     """acr_gemm_f32 (exact-fp32 MFMA, reference precision) through LinearF32Fn: forward NT with bias + residual, input
