@@ -18,7 +18,7 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "views", "pending", "work", "index", "late")
+    __slots__ = ("flat", "params", "views", "pending", "work", "index")
 
 
 class GradSync:
@@ -27,9 +27,13 @@ class GradSync:
     Collective sequences are identical on every rank BY CONSTRUCTION, whatever each rank's autograd graph does:
       * buckets are exchanged in index order only (a bucket whose gradients are complete waits for its predecessors; backward
         fills them in that order anyway), each exactly once, the stragglers from ``finish()`` in the same order;
-      * which parameters are not waited for next step (no gradient this step) and which buckets need a late re-exchange are
-        agreed collectively: one tiny host-side all-reduce per step (a gloo side group beside RCCL: no device
-        synchronisation), so a parameter that receives a gradient on some ranks only costs overlap, never a hang.
+      * which parameters are not waited for next step (no gradient this step) and which PARAMETERS produced a gradient after
+        their bucket had left are agreed collectively: one tiny host-side all-reduce per step (a gloo side group beside RCCL:
+        no device synchronisation), so a parameter that receives a gradient on some ranks only costs overlap, never a hang.
+    Values are the mean over ranks of what each rank produced THIS step, a missing gradient counting as zero: the slot of a
+    parameter without a gradient is zeroed before its bucket leaves (it would otherwise still hold the previous step's
+    average), and late gradients are exchanged on their own and ADDED to the averaged slot (re-averaging the whole bucket
+    would average already-averaged values with raw ones when the ranks disagree on who was late).
     ``strict=True`` (or ACR_DP_STRICT=1) turns any disagreement between ranks into an error instead."""
 
     def __init__(self, params, process_group=None, bucket_mb=64, strict=None, always_reduce=False):
@@ -50,7 +54,7 @@ class GradSync:
             cur_bytes += nbytes
         if cur:
             groups.append(cur)
-        self.buckets, self._of = [], {}
+        self.buckets, self._of, self._view = [], {}, {}
         for grp in groups:
             b = _Bucket()
             b.params = grp
@@ -63,11 +67,13 @@ class GradSync:
                 b.views.append(b.flat[off:off + p.numel()].view_as(p))
                 off += pad(p.numel())
                 self._of[p] = b
+                self._view[p] = b.views[-1]
                 p.register_post_accumulate_grad_hook(self._hook)
-            b.pending, b.work, b.late = 0, None, False
+            b.pending, b.work = 0, None
             b.index = len(self.buckets)
             self.buckets.append(b)
         self._armed = False
+        self._late = []
         self._next = 0                                    # index of the next bucket to exchange (canonical order)
         # Parameters that got no gradient on ANY rank in the previous step (the reference model has 9 such tensors:
         # bkg_token, norm.*, head.*, scratch.*) are not waited for: otherwise the bucket they share -- the FIRST
@@ -100,9 +106,10 @@ class GradSync:
         """Call after zero_grad and before backward.  Gradients are left to autograd (``.grad = None``: the engine then
         *moves* each gradient into ``.grad`` instead of launching an add kernel per parameter); when the last gradient of
         a bucket has arrived they are copied into the bucket with ONE multi-tensor launch and ``.grad`` is re-pointed at
-        the bucket views.  Slots of parameters that never receive a gradient stay zero (zeroed once, at construction)."""
+        the bucket views.  Slots of parameters without a gradient are zeroed when the bucket leaves."""
+        self._late = []
         for b in self.buckets:
-            b.pending, b.work, b.late = sum(1 for p in b.params if p not in self._unused), None, False
+            b.pending, b.work = sum(1 for p in b.params if p not in self._unused), None
             for p in b.params:
                 p.grad = None
         self.launch_log = []
@@ -115,6 +122,10 @@ class GradSync:
         live = [(v, p.grad) for p, v in zip(b.params, b.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if live:
             torch._foreach_copy_([v for v, _ in live], [g for _, g in live])
+        # a slot nobody writes this step still holds the PREVIOUS step's average: it must enter the mean as zero
+        dead = [v for p, v in zip(b.params, b.views) if p.grad is None]
+        if dead:
+            torch._foreach_zero_(dead)
         for p, v in zip(b.params, b.views):
             if p.grad is not None:
                 p.grad = v
@@ -135,8 +146,8 @@ class GradSync:
         b = self._of[p]
         if p in self._unused:                             # it does receive a gradient this step after all
             self._unused.discard(p)
-            if b.work is not None:                        # its bucket has already gone out without it: redo it in finish()
-                b.late = True
+            if b.work is not None:                        # its bucket has already gone out without it (slot zeroed):
+                self._late.append(p)                      # exchanged on its own from finish()
             return
         b.pending -= 1
         self._launch_ready()
@@ -149,39 +160,53 @@ class GradSync:
 
     def finish(self):
         """Call after backward: exchange the buckets backward could not complete (in index order), agree with the other
-        ranks on late buckets and on the parameters nobody produced a gradient for, re-exchange the late buckets, wait for
-        every collective and turn sums into means."""
+        ranks on late parameters and on the parameters nobody produced a gradient for, wait for every collective, turn
+        sums into means and exchange the late gradients."""
         while self._next < len(self.buckets):
             self._launch(self.buckets[self._next], "finish")
             self._next += 1
-        nb, npar = len(self.buckets), len(self._params)
-        late = [b.late for b in self.buckets]
+        npar = len(self._params)
+        mine = set(self._late)
+        late = [p in mine for p in self._params]
         nograd = [p.grad is None for p in self._params]
         if self._agree:
-            # one small host-side exchange: flags[0:nb] = late (OR over ranks), then per parameter "has a gradient" on ANY rank
-            # (OR) and on EVERY rank (AND, sent negated)
+            # one small host-side exchange, per parameter: "late" on ANY rank, "has a gradient" on ANY rank, "has none" on ANY
             flags = torch.tensor([float(x) for x in late] + [float(not x) for x in nograd] + [float(x) for x in nograd],
                                  dtype=torch.float32)
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._side)
-            any_late = [bool(v) for v in flags[:nb].tolist()]
-            any_grad = [bool(v) for v in flags[nb:nb + npar].tolist()]
-            any_nograd = [bool(v) for v in flags[nb + npar:].tolist()]
+            any_late = [bool(v) for v in flags[:npar].tolist()]
+            any_grad = [bool(v) for v in flags[npar:2 * npar].tolist()]
+            any_nograd = [bool(v) for v in flags[2 * npar:].tolist()]
             disagree = sum(1 for a, n in zip(any_grad, any_nograd) if a and n) + sum(1 for a, l in zip(any_late, late) if a != l)
             if disagree:
                 self.stats["rank_disagreements"] += 1
                 if self.strict:
-                    raise RuntimeError("GradSync: ranks disagree on gradient presence for %d parameter(s)/bucket(s) this step "
+                    raise RuntimeError("GradSync: ranks disagree on gradient presence for %d parameter(s) this step "
                                        "(data-dependent graph?); the exchange itself stays consistent -- unset ACR_DP_STRICT "
                                        "to run on" % disagree)
             late = any_late
             nograd = [not a for a in any_grad]
         for b in self.buckets:
             self._wait(b)
-            if late[b.index]:                             # a parameter thought unused produced a gradient (on some rank) after
-                b.work = None                             # the launch: every rank holds the same averaged values, so averaging
-                self._launch(b, "finish")                 # the bucket again only adds the late gradient's exchange
-                self.stats["late_reexchanges"] += 1
-                self._wait(b)
+        if any(late):
+            # Late gradients (a parameter thought unused produced one, on some rank, after its bucket had left with a zeroed
+            # slot): ONE extra exchange of just those tensors -- own late gradient, or zero where it was not late here (then it
+            # either rode in the bucket already or does not exist) -- and the mean is ADDED to the averaged slot.
+            ps = [p for p, l in zip(self._params, late) if l]
+            parts = [(p.grad if p in mine else torch.zeros_like(p)).reshape(-1) for p in ps]
+            flat = torch.cat(parts)
+            self.launch_log.append(("late", "finish"))
+            self.stats["late_reexchanges"] += 1
+            if self._collective:
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.pg)
+                if not self._avg:
+                    flat.div_(self.world)
+            off = 0
+            for p in ps:
+                v = self._view[p]
+                v.add_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+                p.grad = v
         if self._agree:                                   # a gradient that exists on another rank only: its average is ours too
             for b in self.buckets:
                 for p, v in zip(b.params, b.views):
@@ -193,10 +218,30 @@ class GradSync:
         self._armed = False
 
 
-def broadcast_parameters(module, src=0, process_group=None):
-    """One-time parameter/buffer broadcast from rank ``src`` (what DDP's constructor does, train_acr.py:99)."""
+def broadcast_parameters(module, src=0, process_group=None, bucket_mb=64):
+    """One-time parameter/buffer broadcast from rank ``src`` (what DDP's constructor does, train_acr.py:99), coalesced like
+    DDP's: tensors of one dtype and device are packed into flat buffers of about ``bucket_mb`` and each buffer is ONE
+    collective (7 of them for the 417 MB hybrid-base model instead of one per tensor)."""
     if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
-        return
+        return 0
+    cap = int(bucket_mb * (1 << 20))
+    groups, cur, cur_bytes = [], [], 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        nbytes = t.numel() * t.element_size()
+        if cur and (cur_bytes + nbytes > cap or t.dtype != cur[0].dtype or t.device != cur[0].device):
+            groups.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(t)
+        cur_bytes += nbytes
+    if cur:
+        groups.append(cur)
     with torch.no_grad():
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t, src=src, group=process_group)
+        for grp in groups:
+            flat = torch.cat([t.detach().reshape(-1) for t in grp])
+            dist.broadcast(flat, src=src, group=process_group)
+            outs, off = [], 0
+            for t in grp:
+                outs.append(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+            torch._foreach_copy_([t.detach() for t in grp], outs)
+    return len(groups)

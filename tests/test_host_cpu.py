@@ -177,7 +177,7 @@ def test_grad_sync_ranks_gloo(world):
     assert all(in_order(lg) for lg in logs)
     assert logs[0] == [(i, "finish") for i in range(nb)]
     assert logs[1] == [(i, "backward") for i in range(nb)]
-    assert logs[2] == [(i, "backward") for i in range(nb)] + [(0, "finish")]   # late gradient: bucket 0 exchanged again
+    assert logs[2] == [(i, "backward") for i in range(nb)] + [("late", "finish")]   # late gradient: exchanged on its own
     assert logs[3] == [(i, "finish") for i in range(nb)]   # the set is re-learned every step: one step of waiting, ...
     assert logs[4] == [(i, "backward") for i in range(nb)]                      # ... then overlap again
     assert out["stats"]["late_reexchanges"] == 1 and out["stats"]["rank_disagreements"] == 0
@@ -198,6 +198,12 @@ def test_grad_sync_ranks_gloo(world):
     torch.testing.assert_close(out[0], ref, rtol=1e-5, atol=1e-6)
 
 
+# which ranks let the otherwise unused tensor take part, step by step: absent; rank 0 only, twice in a row (the second time its
+# slot still holds the first step's average -- VERDICT r3 weak #2: that stale value used to ride into the mean); every rank;
+# rank 1 only right after a step where every rank had it; absent; rank 0 only
+_UNEVEN_SCHEDULE = [(), (0,), (0,), (0, 1), (1,), (), (0,)]
+
+
 def _dp_uneven_worker(rank, world, port, out):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -207,17 +213,17 @@ def _dp_uneven_worker(rank, world, port, out):
     torch.manual_seed(5)
     net = _dp_net()
     unused = net[3].unused
-    broadcast_parameters(net, 0)
+    ncoll = broadcast_parameters(net, 0, bucket_mb=0.0003)
     sync = GradSync(net.parameters(), bucket_mb=0.0003)
     g = torch.Generator().manual_seed(9)
     x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
     xs, ys = x[rank::world], y[rank::world]
     grads = []
-    for it in range(4):
-        # steps 1 and 2: the otherwise unused tensor takes part ON RANK 0 ONLY (a data-dependent branch): rank 0 sees a
-        # late gradient / waits for it, rank 1 does not -- without the collective agreement the ranks would issue different
-        # numbers of all-reduces and hang
-        extra = unused.sum() * 1e-2 if (rank == 0 and it in (1, 2)) else 0.0
+    for it, who in enumerate(_UNEVEN_SCHEDULE):
+        # a data-dependent branch: the ranks in `who` see a (late) gradient for the tensor, the others do not -- without the
+        # collective agreement the ranks would issue different numbers of all-reduces and hang.  No optimizer step: every
+        # step's expected gradients are the same function of the schedule
+        extra = unused.sum() * 1e-2 if rank in who else 0.0
         loss = ((net(xs + extra) - ys) ** 2).mean()
         sync.prepare()
         loss.backward()
@@ -225,30 +231,43 @@ def _dp_uneven_worker(rank, world, port, out):
         grads.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in net.parameters()]).clone())
     out[rank] = torch.stack(grads)
     out["stats%d" % rank] = dict(sync.stats)
-    out["logs%d" % rank] = None
+    out["bcast%d" % rank] = ncoll
     dist.destroy_process_group()
 
 
 def test_grad_sync_survives_rank_dependent_gradient_presence():
-    """ADVICE r2 / VERDICT r2 #10: a parameter that receives a gradient on one rank only must not desynchronise the
-    collective sequences (it used to: `late` was rank-local).  Both ranks finish, hold identical averaged gradients,
-    and the disagreement is counted."""
+    """ADVICE r2 / VERDICT r2 #10: a parameter that receives a gradient on some ranks only must not desynchronise the
+    collective sequences (it used to: `late` was rank-local).  VERDICT r3 weak #2: and its VALUE must be the mean over ranks of
+    this step's gradients with a missing one counting as zero -- the slot used to keep last step's average (0.75 g instead of
+    0.5 g in the second of two such steps).  Every step of the schedule is compared with a single-process computation."""
     world, port = 2, _free_port()
     out = mp.Manager().dict()
     mp.spawn(_dp_uneven_worker, args=(world, port, out), nprocs=world, join=True)
     torch.testing.assert_close(out[0], out[1], rtol=0, atol=0)
     s0, s1 = out["stats0"], out["stats1"]
-    assert s0["rank_disagreements"] >= 1 and s0["rank_disagreements"] == s1["rank_disagreements"]
+    assert s0["rank_disagreements"] >= 3 and s0["rank_disagreements"] == s1["rank_disagreements"]
     assert s0["late_reexchanges"] == s1["late_reexchanges"] >= 1
     # the same number of collectives on both ranks (WHERE a bucket goes out -- backward or finish -- may differ per rank)
     total = lambda s: s["bucket_launches_in_backward"] + s["bucket_launches_in_finish"]
     assert total(s0) == total(s1)
-    # the rank-0-only gradient arrives averaged (half of it) on both ranks in steps 1 and 2, and is absent in 0 and 3
+    assert out["bcast0"] == out["bcast1"] and 2 <= out["bcast0"] < len(list(_dp_net().parameters()))   # coalesced broadcast
+    # single process: per-rank gradients of the same shards, averaged by hand
+    torch.manual_seed(5)
     net = _dp_net()
+    unused = net[3].unused
+    g = torch.Generator().manual_seed(9)
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
     off = sum(p.numel() for p in list(net.parameters())[:4])            # Linear0 w,b, Linear2 w,b precede the holder
-    seg = out[0][:, off:off + 5]
-    assert float(seg[0].abs().max()) == 0.0 and float(seg[3].abs().max()) == 0.0
-    assert float(seg[1].abs().min()) > 0.0 and float(seg[2].abs().min()) > 0.0
+    for it, who in enumerate(_UNEVEN_SCHEDULE):
+        want = 0
+        for r in range(world):
+            net.zero_grad(set_to_none=True)
+            extra = unused.sum() * 1e-2 if r in who else 0.0
+            ((net(x[r::world] + extra) - y[r::world]) ** 2).mean().backward()
+            want = want + torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in net.parameters()]) / world
+        torch.testing.assert_close(out[0][it], want, rtol=1e-6, atol=1e-9, msg=lambda m: "step %d (%s): %s" % (it, who, m))
+        seg = out[0][it, off:off + 5]
+        assert (float(seg.abs().max()) == 0.0) == (not who)
 
 
 def test_infer_list_sharding():
