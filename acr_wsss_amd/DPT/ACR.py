@@ -129,7 +129,9 @@ class DPT(BaseModel):
 
 
 class ACR(DPT):
-    def __init__(self, num_classes, backbone_name, path=None, **kwargs):
+    def __init__(self, num_classes, backbone_name, path=None, math="f32", **kwargs):
+        """Reference signature (DPT/ACR.py:148) plus ``math``: how this model's fp32 matrix products are evaluated
+        ("f32" exact-fp32 MFMA = the reference's arithmetic, "f32_split" = bf16x3 split products; backbone.set_math)."""
         self.num_class = num_classes
         kwargs["use_bn"] = True
         backbone_dict = {"vitb_hybrid": "vitb_rn50_384", "vitb": "vitb16_384", "deit": "deitb16_384",
@@ -137,8 +139,20 @@ class ACR(DPT):
         cur_backbone = backbone_dict[backbone_name]
         self.cur_backbone = cur_backbone
         super().__init__(backbone=cur_backbone, **kwargs)
+        self.math = "f32"
+        self.set_math(math)
         if path is not None:
             self.load(path)
+
+    def set_math(self, math):
+        """"f32" | "f32_split" for every fp32 product of this model (a per-model property carried into each C-ABI call)."""
+        from ..backbone import set_math
+        from .._lib import MATH
+        if math not in MATH:
+            raise ValueError("math must be one of %s, got %r" % (sorted(MATH), math))
+        set_math(self, math)
+        self.math = math
+        return self
 
     def forward_mirror(self, x1, x2):
         """DPT/ACR.py:170-174.  One 2B pass instead of two sequential B passes."""

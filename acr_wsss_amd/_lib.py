@@ -13,7 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ACR_LIB_PATH: a lab build of the same library (scripts/lab/_build/*.so, e.g. EXTRA=-DLAB_TL stamps) for A/B runs
 LIB_PATH = os.environ.get("ACR_LIB_PATH") or os.path.join(_HERE, "libacr_hip.so")
 
-ACR_F32, ACR_BF16, ACR_BF16_F32MATH = 0, 1, 2
+ACR_F32, ACR_BF16, ACR_BF16_F32MATH, ACR_F32_BF16X3 = 0, 1, 2, 3
+# acr_math (include/acr_hip.h): how an fp32 entry point multiplies -- a per-call argument.  "f32": exact-fp32 MFMA;
+# "f32_split": six bf16-MFMA terms of a three-way operand split (fp32 tensors, fp32 accumulate, fp32-accurate)
+MATH = {"f32": 0, "f32_split": 1}
 BF16_F32MATH = False      # True: bf16 tensors take the exact-fp32 MFMA kernels (reference for the bf16-MFMA ones)
 GETAM_FUNCS = {"grad": 0, "cam_grad": 1, "grad_s": 2, "cam_grad_s": 3}
 
@@ -45,6 +48,8 @@ SIGNATURES = {
                                       c_void_p]),
     "acr_attn_bwd_scores": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "acr_attn_bwd_ws_floats": (c_int64, [_P]),
+    "acr_split3_bf16": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "acr_attn_probs": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acr_attn_dprobs": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acr_consistency_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),
@@ -55,7 +60,7 @@ SIGNATURES = {
     "acr_linear_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int32, c_int32, c_int32, c_void_p]),
     "acr_gemm_f32_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
-    "acr_gemm_f32": (c_int32, [c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+    "acr_gemm_f32": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "acr_wgrad_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),
     "acr_wgrad_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p,
@@ -66,9 +71,9 @@ SIGNATURES = {
     "acr_conv1x1_wgrad_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "acr_conv1x1_wgrad_bf16": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                          c_void_p]),
-    "acr_conv1x1_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "acr_conv1x1_f32": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "acr_conv1x1_wgrad_f32_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
-    "acr_conv1x1_wgrad_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "acr_conv1x1_wgrad_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "acr_maxpool3x3s2_fwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                             c_int32, c_void_p]),
     "acr_maxpool3x3s2_bwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -133,8 +138,7 @@ SIGNATURES = {
 OPTIONS = {"gemm_variant": (0, "ACR_GEMM_VARIANT"), "gemm_nowide": (1, "ACR_GEMM_NOWIDE"), "gemm_regstage": (2, "ACR_GEMM_REGSTAGE"),
            "wgrad_variant": (3, "ACR_WGRAD_VARIANT"), "wgrad_waves": (4, "ACR_WGRAD_WAVES"), "dq_variant": (5, "ACR_DQ_VARIANT"),
            "gemm_f32_regstage": (6, "ACR_GEMM_F32_REGSTAGE"), "attn_f32_gen1": (7, "ACR_ATTN_F32_GEN1"), "attn_f32_nw": (8, "ACR_ATTN_F32_NW"),
-           "gemm_f32_notail": (9, "ACR_GEMM_F32_NOTAIL"), "attn_f32_nosplittail": (10, "ACR_ATTN_F32_NOSPLITTAIL"),
-           "gemm_f32_split": (11, "ACR_GEMM_F32_SPLIT")}
+           "gemm_f32_notail": (9, "ACR_GEMM_F32_NOTAIL"), "attn_f32_nosplittail": (10, "ACR_ATTN_F32_NOSPLITTAIL")}
 
 _lib = None
 
@@ -160,8 +164,8 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
-        if lib.acr_version() != 1:
-            raise AcrHipError("libacr_hip.so ABI version %d != 1" % lib.acr_version())
+        if lib.acr_version() != 2:
+            raise AcrHipError("libacr_hip.so ABI version %d != 2 (rebuild it: __graft_entry__.build())" % lib.acr_version())
         _lib = lib
         for name, (code, env) in OPTIONS.items():            # the library itself never reads the environment
             val = os.environ.get(env)

@@ -23,6 +23,22 @@ import torch.nn.functional as F
 from . import ops
 
 
+def set_math(module, math):
+    """Select how the fp32 matrix products of ``module`` (a whole model or any part of it) are evaluated -- a property of the
+    MODEL (its modules carry it into every call of the C ABI), not of the process:
+      "f32"        exact-fp32 MFMA, the reference's arithmetic (default; what CAM inference and the parity fixtures run);
+      "f32_split"  the same fp32 tensors with every product of the block Linears, the stem's 1x1 convolutions and the
+                   attention as six bf16-MFMA terms of a three-way operand split (include/acr_hip.h: acr_math) --
+                   fp32-accurate, 24 mantissa bits per operand, fp32 accumulate.
+    Has no effect on a bf16 model.  Returns the module."""
+    from . import _lib
+    code = _lib.MATH[math] if isinstance(math, str) else int(math)
+    for m in module.modules():
+        if hasattr(type(m), "acr_math"):
+            m.acr_math = code
+    return module
+
+
 # ------------------------------------------------------------------------------------------------
 # ResNetV2 pieces
 # ------------------------------------------------------------------------------------------------
@@ -55,7 +71,7 @@ class StdConv2dSame(nn.Conv2d):
             x = pad_same(x, self.kernel_size[0], self.stride[0])
         w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
         if self.hip_1x1 and ops.conv1x1_fusable(x, w_hat, self.stride[0]):
-            return ops.conv1x1(x, w_hat, self._w_hat_t)     # NCHW 1x1 conv = per-sample MFMA GEMM, no layout transposes
+            return ops.conv1x1(x, w_hat, self._w_hat_t, self.acr_math)     # NCHW 1x1 conv = per-sample MFMA GEMM, no layout transposes
         return F.conv2d(x, w_hat, None, self.stride, self.padding)
 
     def forward_skip(self, x):
@@ -63,10 +79,11 @@ class StdConv2dSame(nn.Conv2d):
         gradient is then added inside the input-gradient GEMM."""
         w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
         if self.hip_1x1 and x.requires_grad and ops.conv1x1_fusable(x, w_hat, self.stride[0]):
-            return ops.conv1x1_skip(x, w_hat, self._w_hat_t)
+            return ops.conv1x1_skip(x, w_hat, self._w_hat_t, self.acr_math)
         return self.forward(x), x
 
     hip_1x1 = True
+    acr_math = 0            # _lib.MATH code of the fp32 products (set_math)
 
     _w_hat = None           # set for one forward by ResNetV2 when all weights are standardised in one fused launch
     _w_hat_t = None         # bf16 1x1 convolutions: its (cin, cout) copy, written by the same launch
@@ -246,10 +263,12 @@ class Mlp(nn.Module):
             return ops.mlp(x, self.fc1, self.fc2, resid)     # GELU / GELU' inside the GEMM epilogues
         if (Mlp.fused and Attention.hip_linear and isinstance(self.act, nn.GELU) and ops.mlp_f32_usable(x, self.fc1, self.fc2)
                 and not torch.is_autocast_enabled()):
-            return ops.mlp_f32(x, self.fc1, self.fc2, resid)  # reference precision: exact-fp32 MFMA GEMMs, same fusion
+            return ops.mlp_f32(x, self.fc1, self.fc2, resid, self.acr_math)  # reference precision: fp32 GEMMs, same fusion
         lib = Mlp.mlp_on_lib                                 # A/B: fc1 forward and the MLP input gradients on hipBLASLt
-        h = self.act(ops.linear_or_hip(x, self.fc1, None, Attention.hip_linear, hip_dx=not lib, hip_fwd=not lib))
-        return ops.linear_or_hip(h, self.fc2, resid, Attention.hip_linear, hip_dx=not lib, hip_fwd=Mlp.fc2_hip_fwd)
+        h = self.act(ops.linear_or_hip(x, self.fc1, None, Attention.hip_linear, hip_dx=not lib, hip_fwd=not lib, math=self.acr_math))
+        return ops.linear_or_hip(h, self.fc2, resid, Attention.hip_linear, hip_dx=not lib, hip_fwd=Mlp.fc2_hip_fwd, math=self.acr_math)
+
+    acr_math = 0            # _lib.MATH code of the fp32 products (set_math)
 
     fused = os.environ.get("ACR_MLP_FUSED", "1") != "0"
     mlp_on_lib = os.environ.get("ACR_MLP_LIB", "0") == "1"
@@ -281,15 +300,16 @@ class Attention(nn.Module):
         self.last_pm = None         # (B,T,T) head-mean map of the last forward (slice of the MeanStack)
 
     hip_linear = True       # qkv / proj on the hand-written MFMA GEMMs (acr_linear_bf16 / acr_gemm_f32)
+    acr_math = 0            # _lib.MATH code of the fp32 products: Linears and, in training, the attention core (set_math)
     keep_state_in_training = False      # True: get_attn() / get_attn_gradients() also work after a train()-mode forward
 
     def forward(self, x, stack=None, layer=0, resid=None):
         """Returns proj(attention(qkv(x))) (+ resid when given: the block's residual add is fused into the
         proj GEMM epilogue on the bf16 path)."""
         self._override = {}
-        qkv = ops.linear_or_hip(x, self.qkv, None, self.hip_linear)  # packed (B, T, 3*H*64): no permute copy
-        o, self.last_pm = ops.attention_core(qkv, self.num_heads, stack, layer, self)
-        return ops.linear_or_hip(o, self.proj, resid, self.hip_linear)
+        qkv = ops.linear_or_hip(x, self.qkv, None, self.hip_linear, math=self.acr_math)  # packed (B, T, 3*H*64): no permute copy
+        o, self.last_pm = ops.attention_core(qkv, self.num_heads, stack, layer, self, self.acr_math)
+        return ops.linear_or_hip(o, self.proj, resid, self.hip_linear, math=self.acr_math)
 
     # -- reference state API (vision_transformer.py:186-196) --
     def get_attn(self):
@@ -468,7 +488,7 @@ class VisionTransformer(nn.Module):
         pe = self.patch_embed.proj
         if (isinstance(self.patch_embed, HybridEmbed) and StdConv2dSame.hip_1x1 and pe.bias is not None
                 and ops.conv1x1_fusable(x, pe.weight, pe.stride[0])):
-            x = ops.conv1x1(x, pe.weight) + pe.bias.view(1, -1, 1, 1)      # 1024 -> 768 projection on the NCHW GEMM kernels
+            x = ops.conv1x1(x, pe.weight, None, self.acr_math) + pe.bias.view(1, -1, 1, 1)      # 1024 -> 768 projection on the NCHW GEMM kernels
         else:
             x = pe(x)
         x = x.flatten(2).transpose(1, 2)
@@ -511,6 +531,7 @@ class VisionTransformer(nn.Module):
         x = self.run_blocks(x, stack, taps, k, len(self.blocks))
         return self.norm(x) if truncate_at is None else None, res_features
 
+    acr_math = 0            # _lib.MATH code of the patch-embedding projection's fp32 products (set_math)
     graph_prefix = os.environ.get("ACR_INFER_GRAPH", "1") != "0"      # A/B: hipGraph replay of the gradient-free prefix
     max_prefix_graphs = 8
 
@@ -528,7 +549,7 @@ class VisionTransformer(nn.Module):
                 or any(p.requires_grad for p in self.parameters())):
             return None
         key = (tuple(x.shape), x.dtype, x.device, x.is_contiguous(memory_format=torch.channels_last), k, self.training,
-               self.blocks[0].attn.keep_state_in_training)
+               self.blocks[0].attn.keep_state_in_training, self.acr_math, self.blocks[0].attn.acr_math)
         cache = self.__dict__.setdefault("_prefix_graphs", OrderedDict())
         g = cache.get(key)
         if g is not None and g is not False and not g.valid(self):

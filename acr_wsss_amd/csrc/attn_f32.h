@@ -22,3 +22,18 @@ void acr_attn_fwd_f32_sres(const AttnGeom& g, const float* q, const float* k, co
 void acr_attn_bwd_f32_sres(const AttnGeom& g, const float* q, const float* k, const float* v, const float* o, const float* d_o,
                            const float* lse2, const float* scores, const float* gm, int64_t gm_sb, int64_t gm_st, float* dq,
                            float* dk, float* dv, float* delta, hipStream_t st);
+// the two HBM-stream kernels of the resident-score generation on their own (shared with the split-product generation)
+void acr_attn_pmean_sres(const AttnGeom& g, const float* scores, const float* lse2, float* pmean, int64_t pmean_sb, int64_t pmean_st,
+                         hipStream_t st);
+void acr_attn_delta_sres(const AttnGeom& g, const float* scores, const float* o, const float* d_o, const float* lse2, const float* gm,
+                         int64_t gm_sb, int64_t gm_st, float* delta, hipStream_t st);
+
+// split-product generation (attn_f32_x3.hip; acr_dtype ACR_F32_BF16X3): fp32 tensors, products as six bf16-MFMA terms.
+// `scores` = acr_attn_x3_scores_floats floats (score blocks + the bf16 planes of q, k, v, kept for the backward), `delta_ws` =
+// acr_attn_x3_bwd_ws_floats floats (delta + the bf16 planes of dO).
+int64_t acr_attn_x3_scores_floats(const AttnGeom& g);
+int64_t acr_attn_x3_bwd_ws_floats(const AttnGeom& g);
+void acr_attn_fwd_f32_x3(const AttnGeom& g, const float* q, const float* k, const float* v, float* o, float* lse2, float* scores,
+                         float* pmean, int64_t pmean_sb, int64_t pmean_st, hipStream_t st);
+void acr_attn_bwd_f32_x3(const AttnGeom& g, const float* o, const float* d_o, const float* lse2, const float* scores, const float* gm,
+                         int64_t gm_sb, int64_t gm_st, float* dq, float* dk, float* dv, float* delta_ws, hipStream_t st);

@@ -526,7 +526,8 @@ static int check_desc(const acr_attn_desc* d, const char* who) {
     ACR_CHECK_ARG(d != nullptr, "%s: null desc", who);
     ACR_CHECK_ARG(d->B > 0 && d->H > 0 && d->T > 0, "%s: bad geometry B=%d H=%d T=%d", who, d->B, d->H, d->T);
     ACR_CHECK_ARG(d->head_dim == 64, "%s: head_dim %d unsupported (library is built for 64)", who, d->head_dim);
-    ACR_CHECK_ARG(d->dtype == ACR_F32 || d->dtype == ACR_BF16 || d->dtype == ACR_BF16_F32MATH, "%s: unknown dtype %d", who, d->dtype);
+    ACR_CHECK_ARG(d->dtype == ACR_F32 || d->dtype == ACR_BF16 || d->dtype == ACR_BF16_F32MATH || d->dtype == ACR_F32_BF16X3,
+                  "%s: unknown dtype %d", who, d->dtype);
     ACR_CHECK_ARG((d->qkv_sb % 4) == 0 && (d->qkv_st % 4) == 0 && (d->qkv_sh % 4) == 0 && (d->o_sb % 4) == 0 &&
                       (d->o_st % 4) == 0 && (d->o_sh % 4) == 0,
                   "%s: strides must be multiples of 4 elements (vector loads)", who);
@@ -631,15 +632,30 @@ extern "C" int acr_attn_bwd(const acr_attn_desc* d, const void* q, const void* k
 // ---- resident-score generation (fp32 only; attn_f32_sres.hip) ------------------------------------------------------------
 extern "C" int64_t acr_attn_scores_floats(const acr_attn_desc* d) {
     if (d == nullptr || d->B <= 0 || d->H <= 0 || d->T <= 0) return 0;
+    if (d->dtype == ACR_F32_BF16X3) return acr_attn_x3_scores_floats(geom(d));
     const int64_t nb = (d->T + 31) / 32;
     return (int64_t)d->B * d->H * nb * nb * 1024;
+}
+
+extern "C" int64_t acr_attn_bwd_ws_floats(const acr_attn_desc* d) {
+    if (d == nullptr || d->B <= 0 || d->H <= 0 || d->T <= 0) return 0;
+    if (d->dtype == ACR_F32_BF16X3) return acr_attn_x3_bwd_ws_floats(geom(d));
+    return (int64_t)d->B * d->H * d->T;
+}
+
+// the split-product kernels address the bf16 planes with 32-bit lane offsets inside one 32-row tile and need the plain packed
+// layouts of the reference's activations (head h of a token = 64 contiguous elements)
+static int check_x3(const acr_attn_desc* d, const char* who) {
+    ACR_CHECK_ARG(d->qkv_sh >= 64 && d->o_sh >= 64, "%s: ACR_F32_BF16X3 needs head strides >= 64", who);
+    ACR_CHECK_ARG((int64_t)32 * d->H * 64 < (1ll << 30), "%s: too many heads", who);
+    return ACR_OK;
 }
 
 extern "C" int acr_attn_fwd_scores(const acr_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse2,
                                    float* scores, float* pmean, int64_t pmean_sb, int64_t pmean_st, void* stream) {
     int rc = check_desc(d, "acr_attn_fwd_scores");
     if (rc) return rc;
-    if (d->dtype != ACR_F32) {
+    if (d->dtype != ACR_F32 && d->dtype != ACR_F32_BF16X3) {
         acr_set_error("acr_attn_fwd_scores: fp32 tensors only (the bf16 kernels recompute the logits)");
         return ACR_ERR_UNSUPPORTED;
     }
@@ -648,6 +664,13 @@ extern "C" int acr_attn_fwd_scores(const acr_attn_desc* d, const void* q, const 
                   "acr_attn_fwd_scores: q/k/v/o/scores must be 16-byte aligned");
     ACR_CHECK_ARG(!pmean || (pmean_st >= d->T && pmean_sb >= (int64_t)d->T * pmean_st),
                   "acr_attn_fwd_scores: pmean row pitch < T or batch stride < T*pitch");
+    if (d->dtype == ACR_F32_BF16X3) {
+        rc = check_x3(d, "acr_attn_fwd_scores");
+        if (rc) return rc;
+        acr_attn_fwd_f32_x3(geom(d), (const float*)q, (const float*)k, (const float*)v, (float*)o, lse2, scores, pmean, pmean_sb, pmean_st,
+                            (hipStream_t)stream);
+        return acr_check_launch("acr_attn_fwd_scores");
+    }
     acr_attn_fwd_f32_sres(geom(d), (const float*)q, (const float*)k, (const float*)v, (float*)o, lse2, scores, pmean, pmean_sb,
                           pmean_st, (hipStream_t)stream);
     return acr_check_launch("acr_attn_fwd_scores");
@@ -658,7 +681,7 @@ extern "C" int acr_attn_bwd_scores(const acr_attn_desc* d, const void* q, const 
                                    int64_t gmean_st, void* dq, void* dk, void* dv, float* delta_ws, void* stream) {
     int rc = check_desc(d, "acr_attn_bwd_scores");
     if (rc) return rc;
-    if (d->dtype != ACR_F32) {
+    if (d->dtype != ACR_F32 && d->dtype != ACR_F32_BF16X3) {
         acr_set_error("acr_attn_bwd_scores: fp32 tensors only (the bf16 kernels recompute the logits)");
         return ACR_ERR_UNSUPPORTED;
     }
@@ -669,6 +692,14 @@ extern "C" int acr_attn_bwd_scores(const acr_attn_desc* d, const void* q, const 
                   "acr_attn_bwd_scores: gmean row pitch < T or batch stride < T*pitch");
     ACR_CHECK_ARG(!gmean || ((gmean_st & 3) == 0 && (gmean_sb & 3) == 0 && aligned16(gmean)),
                   "acr_attn_bwd_scores: gmean must be 16-byte aligned with pitch and batch stride multiples of 4 floats");
+    if (d->dtype == ACR_F32_BF16X3) {                        // q, k, v are read from the planes the forward left behind the scores
+        rc = check_x3(d, "acr_attn_bwd_scores");
+        if (rc) return rc;
+        ACR_CHECK_ARG(aligned16(delta_ws) && aligned16(dq) && aligned16(dk) && aligned16(dv), "acr_attn_bwd_scores: delta_ws / dq / dk / dv must be 16-byte aligned");
+        acr_attn_bwd_f32_x3(geom(d), (const float*)o, (const float*)d_o, lse2, scores, gmean, gmean_sb, gmean_st, (float*)dq, (float*)dk,
+                            (float*)dv, delta_ws, (hipStream_t)stream);
+        return acr_check_launch("acr_attn_bwd_scores");
+    }
     acr_attn_bwd_f32_sres(geom(d), (const float*)q, (const float*)k, (const float*)v, (const float*)o, (const float*)d_o, lse2,
                           scores, gmean, gmean_sb, gmean_st, (float*)dq, (float*)dk, (float*)dv, delta_ws, (hipStream_t)stream);
     return acr_check_launch("acr_attn_bwd_scores");

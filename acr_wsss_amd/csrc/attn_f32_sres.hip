@@ -941,17 +941,28 @@ void acr_attn_fwd_f32_sres(const AttnGeom& g, const float* q, const float* k, co
         const int nmain = g.B * g.H * (ntail ? NB / 4 : (NB + 3) / 4);
         hipLaunchKernelGGL(attn_fwd_sres_kernel<4>, dim3(nmain + ntail), dim3(256), 0, st, g, q, k, v, o, lse2, scores, ntail);
     }
-    if (pmean)
-        hipLaunchKernelGGL(attn_pmean_sres_kernel, dim3((g.B * NB * NB + 3) / 4), dim3(256), 0, st, g, NB, (const float*)scores,
-                           (const float*)lse2, pmean, pmean_sb, pmean_st);
+    if (pmean) acr_attn_pmean_sres(g, scores, lse2, pmean, pmean_sb, pmean_st, st);
+}
+
+void acr_attn_pmean_sres(const AttnGeom& g, const float* scores, const float* lse2, float* pmean, int64_t pmean_sb, int64_t pmean_st,
+                         hipStream_t st) {
+    const int NB = (g.T + 31) / 32;
+    hipLaunchKernelGGL(attn_pmean_sres_kernel, dim3((g.B * NB * NB + 3) / 4), dim3(256), 0, st, g, NB, scores, lse2, pmean, pmean_sb,
+                       pmean_st);
+}
+
+void acr_attn_delta_sres(const AttnGeom& g, const float* scores, const float* o, const float* d_o, const float* lse2, const float* gm,
+                         int64_t gm_sb, int64_t gm_st, float* delta, hipStream_t st) {
+    const int NB = (g.T + 31) / 32;
+    hipLaunchKernelGGL(attn_delta_sres_kernel, dim3((g.B * NB * g.H + 3) / 4), dim3(256), 0, st, g, NB, scores, o, d_o, lse2, gm, gm_sb,
+                       gm_st, delta);
 }
 
 void acr_attn_bwd_f32_sres(const AttnGeom& g, const float* q, const float* k, const float* v, const float* o, const float* d_o,
                            const float* lse2, const float* scores, const float* gm, int64_t gm_sb, int64_t gm_st, float* dq,
                            float* dk, float* dv, float* delta, hipStream_t st) {
     const int nt = (g.T + 127) / 128, NB = (g.T + 31) / 32;
-    hipLaunchKernelGGL(attn_delta_sres_kernel, dim3((g.B * NB * g.H + 3) / 4), dim3(256), 0, st, g, NB, scores, o, d_o, lse2, gm,
-                       gm_sb, gm_st, delta);
+    acr_attn_delta_sres(g, scores, o, d_o, lse2, gm, gm_sb, gm_st, delta, st);
     const int ntail = split_tail(NB) ? g.B * g.H : 0;
     const int nmain = g.B * g.H * (ntail ? NB / 4 : nt);
     hipLaunchKernelGGL(attn_bwd_sres_kernel, dim3(2 * nmain + 2 * ntail), dim3(256), 0, st, g, q, k, v, d_o, lse2, (const float*)delta,

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// fp32 products on the bf16 MFMA (ACR_OPT_GEMM_F32_SPLIT): the same tiles, operands, epilogues and tail plan as the kernels
+// fp32 products on the bf16 MFMA (math = ACR_MATH_BF16X3, a per-call argument): the same tiles, operands, epilogues and tail plan as the kernels
 // above, but every fp32 product is evaluated on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA's rate) as SIX exact terms of a
 // three-way operand split,
 //     a = a0 + a1 + a2,  b = b0 + b1 + b2   (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 3 x 8 = 24 mantissa bits)
@@ -788,12 +788,13 @@ extern "C" size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t M, int32_t N, int
     return (size_t)p.nsplit * ((size_t)M * N + (size_t)M);
 }
 
-extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                             const float* aux, int64_t ldaux, float* c, int64_t ldc, float* c2, float* colsum, int32_t M, int32_t N,
                             int32_t K, float* ws, void* stream) {
     ACR_CHECK_ARG(a && b && c, "acr_gemm_f32: null pointer");
     ACR_CHECK_ARG(M > 0 && N > 0 && K > 0, "acr_gemm_f32: empty problem (M=%d N=%d K=%d)", M, N, K);
     ACR_CHECK_ARG(mode >= ACR_GEMM_NT && mode <= ACR_GEMM_TN && act >= 0 && act <= 2, "acr_gemm_f32: bad mode %d / act %d", mode, act);
+    ACR_CHECK_ARG(math == ACR_MATH_F32 || math == ACR_MATH_BF16X3, "acr_gemm_f32: bad math %d", math);
     ACR_CHECK_ARG(al16(a) && al16(b) && (lda % 4) == 0 && (ldb % 4) == 0, "acr_gemm_f32: operands must be 16-byte aligned with pitches %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
     GemmF32Args g;
@@ -815,7 +816,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         g.nsplit = p.nsplit; g.kps = p.kps; g.k_zs = p.kps;
         g.c = ws; g.ldc = N;
         g.cs = colsum ? ws + (size_t)p.nsplit * M * N : nullptr;
-        if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && acr_opt(ACR_OPT_GEMM_F32_SPLIT) != 0)
+        if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && math == ACR_MATH_BF16X3)
             hipLaunchKernelGGL((gemm_f32_split_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
         else if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0)
             hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
@@ -837,7 +838,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t l
         else if (dma) hipLaunchKernelGGL((gemm_f32_dma_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);          \
         else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, ACTV>), grid, dim3(256), 0, st, g);                      \
     } while (0)
-    const bool split = acr_opt(ACR_OPT_GEMM_F32_SPLIT) != 0;      // products as six bf16 MFMA terms of a three-way split
+    const bool split = math == ACR_MATH_BF16X3;                   // products as six bf16 MFMA terms of a three-way split
     const bool dma = (K % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && off32_ok(M, N, K, lda, ldb, mode);
     TailPlan tp = gemm_tail_plan(M, N, K);
     const bool vec_ok = al16(c) && (ldc % 4) == 0 && (!bias || al16(bias)) && (!aux || (al16(aux) && (ldaux % 4) == 0)) &&
@@ -892,7 +893,7 @@ static void conv_args(GemmF32Args& g, int M, int N, int K) {
     g.tile0 = 0; g.tiles_launch = g.tiles_m * g.tiles_n;
 }
 
-extern "C" int acr_conv1x1_f32(const float* w, int32_t w_transposed, const float* x, const float* addend, float* y, int32_t nsamp,
+extern "C" int acr_conv1x1_f32(int32_t math, const float* w, int32_t w_transposed, const float* x, const float* addend, float* y, int32_t nsamp,
                                int32_t cout, int32_t cin, int32_t hw, void* stream) {
     // cout / cin are the channel counts of THIS product.  w_transposed = 0: w is (cout, cin).  w_transposed = 1: w is stored
     // (cin, cout) -- the forward convolution's weight handed over as is for the input gradient, where the roles swap.
@@ -909,7 +910,8 @@ extern "C" int acr_conv1x1_f32(const float* w, int32_t w_transposed, const float
     g.nsplit = nsamp;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n * nsamp));
     const bool dma = (cin % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0;
-    const bool split = dma && acr_opt(ACR_OPT_GEMM_F32_SPLIT) != 0;
+    ACR_CHECK_ARG(math == ACR_MATH_F32 || math == ACR_MATH_BF16X3, "acr_conv1x1_f32: bad math %d", math);
+    const bool split = dma && math == ACR_MATH_BF16X3;
     if (!w_transposed) {                    // w = (cout, cin): rows = output channels, k contiguous
         g.lda = cin;
         if (split) hipLaunchKernelGGL((gemm_f32_split_kernel<true, false, 0>), grid, dim3(256), 0, st, g);
@@ -939,7 +941,7 @@ extern "C" size_t acr_conv1x1_wgrad_f32_ws_floats(int32_t nsamp, int32_t cout, i
     return (size_t)nsamp * conv_wgrad_ksplit(nsamp, cout, cin, hw) * cout * cin;
 }
 
-extern "C" int acr_conv1x1_wgrad_f32(const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw, float* ws,
+extern "C" int acr_conv1x1_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw, float* ws,
                                      float* dw, void* stream) {
     ACR_CHECK_ARG(dy && x && ws && dw, "acr_conv1x1_wgrad_f32: null pointer");
     ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && hw > 0 && (hw % 4) == 0 && (cin % 4) == 0 && (cout % 4) == 0,
@@ -958,7 +960,8 @@ extern "C" int acr_conv1x1_wgrad_f32(const float* dy, const float* x, int32_t ns
     g.k_zs = g.kps;
     g.nsplit = nsamp * ks;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.nsplit));
-    if ((hw % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && acr_opt(ACR_OPT_GEMM_F32_SPLIT) != 0)
+    ACR_CHECK_ARG(math == ACR_MATH_F32 || math == ACR_MATH_BF16X3, "acr_conv1x1_wgrad_f32: bad math %d", math);
+    if ((hw % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && math == ACR_MATH_BF16X3)
         hipLaunchKernelGGL((gemm_f32_split_kernel<true, true, 3>), grid, dim3(256), 0, st, g);
     else if ((hw % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0)
         hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 3>), grid, dim3(256), 0, st, g);

@@ -20,13 +20,14 @@ def pad4(n):
     return (n + 3) & ~3
 
 
-def _desc(B, H, T, dtype, packed_qkv=True):
+def _desc(B, H, T, dtype, packed_qkv=True, math=0):
     """Descriptor for q/k/v aliasing slices of the packed qkv Linear output (B,T,3,H,64) and o / do in
-    the reference's (B,T,H*64) activation layout (models/vision_transformer.py:200-201,211)."""
+    the reference's (B,T,H*64) activation layout (models/vision_transformer.py:200-201,211).  ``math`` = 1 on fp32 tensors:
+    ACR_F32_BF16X3 (split products on the bf16 MFMA; resident-score entry points only)."""
     D = H * HEAD_DIM
     d = L.AttnDesc()
     d.B, d.H, d.T, d.head_dim = B, H, T, HEAD_DIM
-    d.dtype = L.dtype_code(dtype)
+    d.dtype = L.ACR_F32_BF16X3 if (math == 1 and dtype == torch.float32) else L.dtype_code(dtype)
     d.scale = HEAD_DIM ** -0.5
     d.qkv_sb, d.qkv_st, d.qkv_sh = T * 3 * D, 3 * D, HEAD_DIM
     d.o_sb, d.o_st, d.o_sh = T * D, D, HEAD_DIM
@@ -100,7 +101,7 @@ class AttnCoreFn(Function):
     """o = softmax(q k^T d^-0.5) v  (+ head-mean side output), packed qkv in, (B,T,D) out."""
 
     @staticmethod
-    def forward(ctx, qkv, heads, stack, layer, owner):
+    def forward(ctx, qkv, heads, stack, layer, owner, math=0):
         L.require_gpu(qkv)
         # an output nobody differentiated arrives as None in backward, not as a zero tensor: CAM generation back-propagates
         # the class logit through `o` only, and a materialised zero head-mean gradient would cost a (B,T,T) fill + re-layout
@@ -112,7 +113,10 @@ class AttnCoreFn(Function):
         D = heads * HEAD_DIM
         assert D3 == 3 * D, "qkv last dim %d != 3*heads*64" % D3
         lib = L.load()
-        d = _desc(B, heads, T, qkv.dtype)
+        keep_scores = ctx.needs_input_grad[0]
+        # split products (math = 1) exist for the resident-score kernels of fp32 tensors; every other path is exact
+        ctx.math = math = int(math == 1 and ATTN_F32_SCORES and qkv.dtype == torch.float32 and (keep_scores or stack is not None))
+        d = _desc(B, heads, T, qkv.dtype, math=math)
         o = torch.empty((B, T, D), dtype=qkv.dtype, device=qkv.device)
         lse2 = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device)
         pm = None
@@ -126,7 +130,6 @@ class AttnCoreFn(Function):
         # logits once and streaming them into the head mean beats the recompute generation's second q.k product; the buffer
         # is then a temporary)
         scores = None
-        keep_scores = ctx.needs_input_grad[0]
         if ATTN_F32_SCORES and qkv.dtype == torch.float32 and (keep_scores or pm is not None):
             scores = torch.empty(lib.acr_attn_scores_floats(d), dtype=torch.float32, device=qkv.device)
         tok = _t0("attn_fwd" if pm is not None else "attn_fwd_nomean", B, heads, T)
@@ -181,9 +184,9 @@ class AttnCoreFn(Function):
                 buf[:, :, :T].copy_(g_pm)
                 g_pm = buf[:, :, :T]
             gm_sb, gm_st = g_pm.stride(0), g_pm.stride(1)
-        d = _desc(B, heads, T, qkv.dtype)
+        d = _desc(B, heads, T, qkv.dtype, math=ctx.math if scores is not None else 0)
         dqkv = torch.empty_like(qkv)
-        delta = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device)
+        delta = torch.empty(lib.acr_attn_bwd_ws_floats(d) if scores is not None else B * heads * T, dtype=torch.float32, device=qkv.device)
         qp, kp, vp = _qkv_ptrs(qkv, heads)
         dqp, dkp, dvp = _qkv_ptrs(dqkv, heads)
         tok = _t0("attn_bwd" if g_pm is not None else "attn_bwd_nomean", B, heads, T)
@@ -197,7 +200,7 @@ class AttnCoreFn(Function):
         if ctx.owner is not None:
             ctx.owner._saved_do = d_o
             ctx.owner._saved_gpm = g_pm       # dLoss/d(mean_h P): reaches every head's P as G/H (get_attn_gradients)
-        return dqkv, None, None, None, None
+        return dqkv, None, None, None, None, None
 
 
 class StackAliasFn(Function):
@@ -215,8 +218,8 @@ class StackAliasFn(Function):
         return (None,) + tuple(g[:, l] for l in range(ctx.n))
 
 
-def attention_core(qkv, heads, stack=None, layer=0, owner=None):
-    return AttnCoreFn.apply(qkv, heads, stack, layer, owner)
+def attention_core(qkv, heads, stack=None, layer=0, owner=None, math=0):
+    return AttnCoreFn.apply(qkv, heads, stack, layer, owner, math)
 
 
 def attn_probs(qkv, lse2, heads):
@@ -388,12 +391,12 @@ def weight_t(weight, owner=None, make=True):
 F32_WT = os.environ.get("ACR_F32_WT", "1") != "0"      # A/B switch: fp32 input gradients on the cached W^T (NT) vs W as stored (NN)
 
 
-def _dx_f32(dy2, weight, owner, out, aux=None, act=0):
+def _dx_f32(dy2, weight, owner, out, aux=None, act=0, math=0):
     """out = dy2 W (optionally * GELU'(aux)): NT on the cached (in, out) copy when it is current, else NN on W as stored."""
     wt = weight_t(weight, owner, make=False) if F32_WT else None
     if wt is not None:
-        return gemm_f32_raw("nt", dy2, wt, out, aux=aux, act=act)
-    return gemm_f32_raw("nn", dy2, weight, out, aux=aux, act=act)
+        return gemm_f32_raw("nt", dy2, wt, out, aux=aux, act=act, math=math)
+    return gemm_f32_raw("nn", dy2, weight, out, aux=aux, act=act, math=math)
 
 
 class LinearBf16Fn(Function):
@@ -514,9 +517,10 @@ def mlp(x, fc1, fc2, resid=None):
 GEMM_MODES = {"nt": 0, "nn": 1, "tn": 2}
 
 
-def gemm_f32_raw(mode, a, b, c, bias=None, aux=None, act=0, c2=None, colsum=None):
+def gemm_f32_raw(mode, a, b, c, bias=None, aux=None, act=0, c2=None, colsum=None, math=0):
     """c = op(a) op(b) through acr_gemm_f32 (see include/acr_hip.h): 'nt' c[M,N] = a[M,K] b[N,K]^T, 'nn' c = a[M,K] b[K,N],
-    'tn' c = a[K,M]^T b[K,N] (+ colsum[M] = column sums of a).  fp32, unit inner strides."""
+    'tn' c = a[K,M]^T b[K,N] (+ colsum[M] = column sums of a).  fp32, unit inner strides.  ``math``: _lib.MATH code (0 = exact-fp32
+    MFMA, 1 = six bf16-MFMA terms of a three-way operand split), a per-call argument."""
     lib = L.load()
     md = GEMM_MODES[mode]
     M, N = c.shape
@@ -524,7 +528,7 @@ def gemm_f32_raw(mode, a, b, c, bias=None, aux=None, act=0, c2=None, colsum=None
     nws = lib.acr_gemm_f32_ws_floats(md, M, N, K)
     ws = torch.empty(nws, dtype=torch.float32, device=a.device) if nws else None
     tok = _t0("gemm_f32_" + mode, M, N, K)
-    L.check(lib.acr_gemm_f32(md, act, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(bias), L.ptr(aux),
+    L.check(lib.acr_gemm_f32(md, math, act, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(bias), L.ptr(aux),
                              aux.stride(0) if aux is not None else 0, L.ptr(c), c.stride(0), L.ptr(c2), L.ptr(colsum), M, N, K,
                              L.ptr(ws), L.stream_ptr()), "acr_gemm_f32")
     _t1(tok)
@@ -551,7 +555,8 @@ class LinearF32Fn(Function):
     in one TN sweep over dy (models/vision_transformer.py:200,212 and their autograd backward)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, resid, owner=None):
+    def forward(ctx, x, weight, bias, resid, owner=None, math=0):
+        ctx.math = math
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         N = weight.shape[0]
@@ -559,7 +564,7 @@ class LinearF32Fn(Function):
         if r2 is not None and not r2.is_contiguous():
             r2 = r2.contiguous()
         y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
-        gemm_f32_raw("nt", x2, weight, y, bias=bias, aux=r2)
+        gemm_f32_raw("nt", x2, weight, y, bias=bias, aux=r2, math=math)
         ctx.save_for_backward(x2, weight)
         ctx.has_bias, ctx.has_resid, ctx.owner = bias is not None, resid is not None, owner
         return y.reshape(*shp[:-1], N)
@@ -574,16 +579,16 @@ class LinearF32Fn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((dy2.shape[0], K), dtype=torch.float32, device=dy.device)
-            _dx_f32(dy2, weight, ctx.owner, dx)
+            _dx_f32(dy2, weight, ctx.owner, dx, math=ctx.math)
             dx = dx.reshape(*dy.shape[:-1], K)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
             db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_db else None
-            gemm_f32_raw("tn", dy2, x2, dw, colsum=db)
+            gemm_f32_raw("tn", dy2, x2, dw, colsum=db, math=ctx.math)
         elif want_db:
             db = dy2.sum(0)
-        return dx, dw, db, (dy if ctx.has_resid else None), None
+        return dx, dw, db, (dy if ctx.has_resid else None), None, None
 
 
 class MlpF32Fn(Function):
@@ -591,20 +596,20 @@ class MlpF32Fn(Function):
     epilogues: fc1 writes h and GELU(h) in one pass; fc2's input gradient comes out multiplied by GELU'(h)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, resid, fc1=None, fc2=None):
-        ctx.fc1, ctx.fc2 = fc1, fc2
+    def forward(ctx, x, w1, b1, w2, b2, resid, fc1=None, fc2=None, math=0):
+        ctx.fc1, ctx.fc2, ctx.math = fc1, fc2, math
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         M = x2.shape[0]
         Hd, D = w1.shape[0], w2.shape[0]
         h = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
         a = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
-        gemm_f32_raw("nt", x2, w1, h, bias=b1, act=1, c2=a)          # a = GELU(h), and GELU'(h) in place of h (all backward needs)
+        gemm_f32_raw("nt", x2, w1, h, bias=b1, act=1, c2=a, math=math)          # a = GELU(h), and GELU'(h) in place of h (all backward needs)
         r2 = resid.reshape(-1, D) if resid is not None else None
         if r2 is not None and not r2.is_contiguous():
             r2 = r2.contiguous()
         y = torch.empty((M, D), dtype=torch.float32, device=x.device)
-        gemm_f32_raw("nt", a, w2, y, bias=b2, aux=r2)
+        gemm_f32_raw("nt", a, w2, y, bias=b2, aux=r2, math=math)
         ctx.save_for_backward(x2, h, a, w1, w2)
         ctx.has_resid = resid is not None
         return y.reshape(*shp[:-1], D)
@@ -618,26 +623,27 @@ class MlpF32Fn(Function):
             dy2 = dy2.contiguous()
         M, Hd = h.shape
         dev = dy.device
+        math = ctx.math
         dw1 = db1 = dw2 = db2 = dx = None
         if need[3]:
             dw2 = torch.empty_like(w2)
             db2 = torch.empty(w2.shape[0], dtype=torch.float32, device=dev) if need[4] else None
-            gemm_f32_raw("tn", dy2, a, dw2, colsum=db2)
+            gemm_f32_raw("tn", dy2, a, dw2, colsum=db2, math=math)
         elif need[4]:
             db2 = dy2.sum(0)
         dh = torch.empty_like(h)
-        _dx_f32(dy2, w2, ctx.fc2, dh, aux=h, act=2)                   # (dY W2) * GELU'(h); `h` holds GELU'(h) (see forward)
+        _dx_f32(dy2, w2, ctx.fc2, dh, aux=h, act=2, math=math)                   # (dY W2) * GELU'(h); `h` holds GELU'(h) (see forward)
         if need[1]:
             dw1 = torch.empty_like(w1)
             db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if need[2] else None
-            gemm_f32_raw("tn", dh, x2, dw1, colsum=db1)
+            gemm_f32_raw("tn", dh, x2, dw1, colsum=db1, math=math)
         elif need[2]:
             db1 = dh.sum(0)
         if need[0]:
             dx = torch.empty_like(x2)
-            _dx_f32(dh, w1, ctx.fc1, dx)
+            _dx_f32(dh, w1, ctx.fc1, dx, math=math)
             dx = dx.reshape(*dy.shape[:-1], w1.shape[1])
-        return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None), None, None
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None), None, None, None
 
 
 def mlp_f32_usable(x, fc1, fc2):
@@ -645,18 +651,18 @@ def mlp_f32_usable(x, fc1, fc2):
             and fc2.bias is not None and fc2.weight.is_contiguous() and fc2.weight.shape[0] % 4 == 0)
 
 
-def mlp_f32(x, fc1, fc2, resid=None):
-    return MlpF32Fn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, resid, fc1, fc2)
+def mlp_f32(x, fc1, fc2, resid=None, math=0):
+    return MlpF32Fn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, resid, fc1, fc2, math)
 
 
-def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hip_fwd=True):
+def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hip_fwd=True, math=0):
     """nn.Linear forward; bf16 CUDA tensors with K % 64 == 0 take the hand-written GEMM (resid fused).
     ``hip_dx`` = False leaves the input gradient on hipBLASLt (shapes where the library kernel is faster)."""
     if (use_hip and x.is_cuda and x.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16
             and lin.weight.shape[1] % 64 == 0 and x.is_contiguous()):
         return LinearBf16Fn.apply(x, lin.weight, lin.bias, resid, hip_dx, hip_dw, hip_fwd, lin)
     if use_hip and linear_f32_usable(x, lin.weight) and not torch.is_autocast_enabled():
-        return LinearF32Fn.apply(x, lin.weight, lin.bias, resid, lin)
+        return LinearF32Fn.apply(x, lin.weight, lin.bias, resid, lin, math)
     y = torch.nn.functional.linear(x, lin.weight, lin.bias)
     return y if resid is None else resid + y
 
@@ -713,15 +719,15 @@ class Conv1x1Fn(Function):
     the shortcut is added in the epilogue of the input-gradient GEMM (no separate accumulation pass)."""
 
     @staticmethod
-    def forward(ctx, x, weight, wt=None):
-        ctx.wt = wt                                          # (cin, cout) copy of the weight, or None
+    def forward(ctx, x, weight, wt=None, math=0):
+        ctx.wt, ctx.math = wt, math                          # wt: (cin, cout) copy of the weight, or None
         N, C, H, W = x.shape
         co = weight.shape[0]
         w2 = weight.reshape(co, C)
         y = torch.empty((N, co, H, W), dtype=x.dtype, device=x.device)
         if x.dtype == torch.float32:
             w2 = w2.contiguous()
-            L.check(L.load().acr_conv1x1_f32(L.ptr(w2), 0, L.ptr(x), None, L.ptr(y), N, co, C, H * W, L.stream_ptr()), "acr_conv1x1_f32")
+            L.check(L.load().acr_conv1x1_f32(math, L.ptr(w2), 0, L.ptr(x), None, L.ptr(y), N, co, C, H * W, L.stream_ptr()), "acr_conv1x1_f32")
         else:
             L.check(L.load().acr_conv1x1_bf16(L.ptr(w2), w2.stride(0), L.ptr(x), None, L.ptr(y), N, co, C, H * W, L.stream_ptr()),
                     "acr_conv1x1_bf16")
@@ -736,7 +742,7 @@ class Conv1x1Fn(Function):
         co = weight.shape[0]
         lib = L.load()
         if dy is None:
-            return dskip, None, None
+            return dskip, None, None, None
         if not dy.is_contiguous():
             dy = dy.contiguous()
         if dskip is not None and (not dskip.is_contiguous() or dskip.dtype != x.dtype):
@@ -748,14 +754,14 @@ class Conv1x1Fn(Function):
             if ctx.needs_input_grad[0]:
                 w2 = weight.reshape(co, C).contiguous()
                 dx = torch.empty_like(x)
-                L.check(lib.acr_conv1x1_f32(L.ptr(w2), 1, L.ptr(dy), L.ptr(dskip), L.ptr(dx), N, C, co, H * W, L.stream_ptr()),
+                L.check(lib.acr_conv1x1_f32(ctx.math, L.ptr(w2), 1, L.ptr(dy), L.ptr(dskip), L.ptr(dx), N, C, co, H * W, L.stream_ptr()),
                         "acr_conv1x1_f32")
             if ctx.needs_input_grad[1]:
                 ws = torch.empty(lib.acr_conv1x1_wgrad_f32_ws_floats(N, co, C, H * W), dtype=torch.float32, device=x.device)
                 dw = torch.empty((co, C, 1, 1), dtype=torch.float32, device=x.device)
-                L.check(lib.acr_conv1x1_wgrad_f32(L.ptr(dy), L.ptr(x), N, co, C, H * W, L.ptr(ws), L.ptr(dw), L.stream_ptr()),
+                L.check(lib.acr_conv1x1_wgrad_f32(ctx.math, L.ptr(dy), L.ptr(x), N, co, C, H * W, L.ptr(ws), L.ptr(dw), L.stream_ptr()),
                         "acr_conv1x1_wgrad_f32")
-            return dx, dw, None
+            return dx, dw, None, None
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if ctx.wt is not None else weight.reshape(co, C).t().contiguous()     # (cin, cout): dX = W^T . dY
             dx = torch.empty_like(x)
@@ -766,18 +772,18 @@ class Conv1x1Fn(Function):
             dw = torch.empty((co, C, 1, 1), dtype=weight.dtype, device=x.device)
             L.check(lib.acr_conv1x1_wgrad_bf16(L.ptr(dy), L.ptr(x), N, co, C, H * W, L.ptr(ws), L.ptr(dw), L.stream_ptr()),
                     "acr_conv1x1_wgrad_bf16")
-        return dx, dw, None
+        return dx, dw, None, None
 
 
-def conv1x1(x, weight, wt=None):
-    return Conv1x1Fn.apply(x, weight, wt)[0]
+def conv1x1(x, weight, wt=None, math=0):
+    return Conv1x1Fn.apply(x, weight, wt, math)[0]
 
 
-def conv1x1_skip(x, weight, wt=None):
+def conv1x1_skip(x, weight, wt=None, math=0):
     """(conv(x), x_skip): see Conv1x1Fn.  ``wt``: the (cin, cout) copy of the weight when the caller already has one."""
     if not SKIP_FUSION:
-        return Conv1x1Fn.apply(x, weight, wt)[0], x
-    return Conv1x1Fn.apply(x, weight, wt)
+        return Conv1x1Fn.apply(x, weight, wt, math)[0], x
+    return Conv1x1Fn.apply(x, weight, wt, math)
 
 
 class LayerNormFn(Function):

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- ACR training-step throughput (BASELINE.json metric) on N MI355X GPUs of one node.
 
-The HEADLINE (`value`, `dtype: "f32"`) is measured at the reference's precision: fp32 end to end (train_acr.py:137,
-autocast(enabled=False)).  The same invocation then runs the bf16 training mode of this build (bf16 tensors + bf16 MFMA,
-fp32 master weights / accumulate / softmax / loss; parity pinned by tests/test_model_gpu.py::test_bf16_train_step_448)
-and reports it as the sub-record `"bf16": {...}` -- never as `value`.
+The HEADLINE (`value`, `dtype: "f32_split"`) is measured on fp32 tensors end to end (train_acr.py:137, autocast(enabled=False))
+with the model's matrix products evaluated as six bf16-MFMA terms of a three-way operand split (24 mantissa bits per operand,
+fp32 accumulate: ACR(..., math="f32_split"); every fp32 parity test runs under it at the fp32 tolerances).  The
+same invocation then runs the exact-fp32-MFMA arithmetic (sub-record `"f32"`, the previous rounds' headline) and the bf16
+training mode of this build (bf16 tensors + bf16 MFMA, fp32 master weights / accumulate / softmax / loss; parity pinned by
+tests/test_model_gpu.py::test_bf16_train_step_448; sub-record `"bf16"` -- never `value`).  ACR_BENCH_HEADLINE=f32 puts the
+exact arithmetic back in front.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
         N = 1: runs in this process.  N > 1 without WORLD_SIZE in the environment: this process touches no GPU, starts
@@ -35,13 +38,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_IMG_448 = 1.1307e12          # SURVEY 6 [probe]: 2 views, fwd+bwd, hybrid-base @448^2
-PEAK_MFMA = {"f32": 157.3e12, "f32_split": 157.3e12, "bf16": 2.5e15}   # MI355X_MICROARCH.md: dense matrix peaks
+# MI355X_MICROARCH.md: dense matrix peaks.  f32_split: six bf16 MFMAs per fp32-equivalent product -> bf16 peak / 6
+PEAK_MFMA = {"f32": 157.3e12, "f32_split": 2.5e15 / 6, "bf16": 2.5e15}
 PRECISION = {"f32": "fp32 end to end (reference precision, exact-fp32 MFMA)",
-             "f32_split": "fp32 tensors end to end; every Linear / 1x1-convolution product evaluated on the bf16 MFMA as six exact terms of a "
-                          "three-way operand split (24 mantissa bits), fp32 accumulation -- as accurate against fp64 as the fp32 FMA chain "
-                          "(tests: same tolerances as f32); attention, norms, loss: exact fp32 as in f32",
+             "f32_split": "fp32 tensors end to end; every Linear / 1x1-convolution / attention product evaluated on the bf16 MFMA as six exact "
+                          "terms of a three-way operand split (24 mantissa bits per operand), fp32 accumulation -- as accurate against fp64 as the "
+                          "fp32 FMA chain (every fp32 parity test runs under it at the same tolerances; adversarial-operand test <= 2x the exact "
+                          "kernel's error); softmax, norms, loss, optimizer and the stem's 3x3 / 7x7 convolutions: exact fp32 as in f32",
              "bf16": "bf16 params/activations/grads + bf16 MFMA, fp32 master weights + fp32 accumulate/softmax/loss"}
-IN_STEP = os.path.join(ROOT, "profiles", "r03_in_step_kernels.json")     # rocprofv3 kernel-trace of this bench, per dtype
+IN_STEP = os.path.join(ROOT, "profiles", "r04_in_step_kernels.json")     # rocprofv3 kernel-trace of this bench, per dtype
+if not os.path.exists(IN_STEP):
+    IN_STEP = os.path.join(ROOT, "profiles", "r03_in_step_kernels.json")
 
 
 def parse():
@@ -114,7 +121,8 @@ def roofline_probe(args, dev, dtype, live=None):
     from acr_wsss_amd import _lib as L, ops
     lib = L.load()
     B, H, T = 2 * args.batch, 12, (args.size // 16) ** 2 + 1
-    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    dt = torch.float32 if dtype in ("f32", "f32_split") else torch.bfloat16
+    math = 1 if dtype == "f32_split" else 0              # acr_math: the per-call arithmetic of the fp32 entry points
     peak = PEAK_MFMA[dtype]
     g = torch.Generator(device="cpu").manual_seed(0)
     qkv = torch.randn(B, T, 3 * H * 64, generator=g).to(dev).to(dt)
@@ -124,13 +132,13 @@ def roofline_probe(args, dev, dtype, live=None):
     lse2 = torch.empty(B, H, T, dtype=torch.float32, device=dev)
     pm = torch.empty(B, T, T, dtype=torch.float32, device=dev)
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(B, H, T, dtype=torch.float32, device=dev)
-    d = ops._desc(B, H, T, dt)
+    d = ops._desc(B, H, T, dt, math=math)
+    delta = torch.empty(lib.acr_attn_bwd_ws_floats(d) if dt == torch.float32 else B * H * T, dtype=torch.float32, device=dev)
     qp, kp, vp = ops._qkv_ptrs(qkv, H)
     dqp, dkp, dvp = ops._qkv_ptrs(dqkv, H)
     st = L.stream_ptr()
 
-    scores_path = dtype == "f32" and ops.ATTN_F32_SCORES   # what ops.AttnCoreFn launches in fp32: logits resident in HBM
+    scores_path = dt == torch.float32 and ops.ATTN_F32_SCORES   # what ops.AttnCoreFn launches in fp32: logits resident in HBM
     if scores_path:
         sres = torch.empty(lib.acr_attn_scores_floats(d), dtype=torch.float32, device=dev)
 
@@ -152,7 +160,7 @@ def roofline_probe(args, dev, dtype, live=None):
     t_bwd = time_kernel(bwd)
     unit = 2.0 * T * T * 64 * B * H                      # one T x T x 64 product over all (b, h)
     if scores_path:                                      # executed products: 2 forward, 5 backward (dP dQ | dP dV dK)
-        sbytes = 4.0 * sres.numel()
+        sbytes = 4.0 * B * H * ((T + 31) // 32) ** 2 * 1024
         kernels = {
             "acr_attn_bwd": _mfma_rec("acr_attn_bwd_scores (row term stream + dq + dkdv, logits read from HBM)", 4 * unit, 5 * unit, t_bwd,
                                       peak, {"scores_bytes_read_per_launch": 3 * sbytes}),
@@ -205,12 +213,16 @@ def roofline_probe(args, dev, dtype, live=None):
         dww = torch.empty(Nw, Kw, dtype=dt, device=dev)
         wt32 = w.t().contiguous()                          # what train.refresh_weight_transposes keeps per Linear
         for key, name, call in (
-                ("acr_gemm_f32_nt", "gemm_f32 NT (fc1 forward, %dx%dx%d)" % (Mtok, Nw, Kw), lambda: ops.gemm_f32_raw("nt", x, w, y, bias=bias)),
+                ("acr_gemm_f32_nt", "gemm_f32 NT (fc1 forward, %dx%dx%d)" % (Mtok, Nw, Kw), lambda: ops.gemm_f32_raw("nt", x, w, y, bias=bias, math=math)),
                 ("acr_gemm_f32_dx", "gemm_f32 NT on the cached W^T (fc1 input gradient, %dx%dx%d; same shape as fc2 forward)" % (Mtok, Kw, Nw),
-                 lambda: ops.gemm_f32_raw("nt", dy, wt32, dx)),
-                ("acr_gemm_f32_tn", "gemm_f32 TN (fc1 weight gradient)", lambda: ops.gemm_f32_raw("tn", dy, x, dww))):
+                 lambda: ops.gemm_f32_raw("nt", dy, wt32, dx, math=math)),
+                ("acr_gemm_f32_tn", "gemm_f32 TN (fc1 weight gradient)", lambda: ops.gemm_f32_raw("tn", dy, x, dww, math=math))):
             t = time_kernel(call, iters=5)
-            kernels[key] = _mfma_rec(name, fl, fl, t, peak)
+            kernels[key] = _mfma_rec(name + (" [split products: 6 bf16 MFMAs per fp32 product]" if math else ""), fl, fl, t, peak)
+    if math:
+        for r in kernels.values():
+            if r.get("bound") == "mfma":
+                r["peak_note"] = "fp32-equivalent FLOP against the dense bf16 MFMA peak / 6 (2.5 PF / 6 = 416.7 TF)"
     # durations measured inside the timed steps take precedence over the isolated replays above
     Mt = B * T
     live_keys = {"acr_attn_fwd": "attn_fwd %dx%dx%d" % (B, H, T), "acr_attn_bwd": "attn_bwd %dx%dx%d" % (B, H, T),
@@ -466,11 +478,10 @@ def run_mode(args, dtype, world, rank, dev):
     from acr_wsss_amd.train import MasterWeights, PolyOptimizer, train_step
     from acr_wsss_amd.dp import GradSync, broadcast_parameters
 
-    from acr_wsss_amd import _lib
-    _lib.set_option("gemm_f32_split", 1 if dtype == "f32_split" else int(os.environ.get("ACR_GEMM_F32_SPLIT", "0") == "1"))
     torch.manual_seed(0)
-    model = ACR(num_classes=args.classes, backbone_name="vitb_hybrid", use_pretrain=False,
-                channels_last=args.channels_last).to(dev)
+    # the arithmetic is a property of the model (a per-call argument of the C ABI), not a process-wide switch
+    model = ACR(num_classes=args.classes, backbone_name="vitb_hybrid", use_pretrain=False, channels_last=args.channels_last,
+                math="f32_split" if dtype == "f32_split" else "f32").to(dev)
     if args.channels_last:
         model = model.to(memory_format=torch.channels_last)
     model.train()
@@ -497,7 +508,7 @@ def run_mode(args, dtype, world, rank, dev):
     # per-kernel durations are taken INSIDE the timed steps: HIP events around the first launch of every hooked kernel shape
     # in every step, on the launch stream (ops.KernelTimer; ~20 event pairs per step, < 0.1 % of a step)
     from acr_wsss_amd import ops
-    timer = ops.KernelTimer() if (world == 1 and not args.no_roofline) else None
+    timer = ops.KernelTimer() if (rank == 0 and not args.no_roofline) else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -525,7 +536,6 @@ def run_mode(args, dtype, world, rank, dev):
            "step_mfma_frac": round(value * FLOP_PER_IMG_448 * (args.size / 448.0) ** 2 / (world * PEAK_MFMA[dtype]), 4),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     rec["_live_ms"] = live                               # popped by main(): feeds the roofline records
-    _lib.set_option("gemm_f32_split", int(os.environ.get("ACR_GEMM_F32_SPLIT", "0") == "1"))
     if sync is not None:
         info = sync.describe()
         per_step = max(1, info["steps"])
@@ -569,7 +579,10 @@ def main():
     if args.stock_linear:
         from acr_wsss_amd.backbone import Attention
         Attention.hip_linear = False
-    modes = ["f32", "f32_split", "bf16"] if args.dtype == "both" else [args.dtype]
+    if args.dtype == "both":
+        modes = ["f32", "f32_split", "bf16"] if os.environ.get("ACR_BENCH_HEADLINE", "f32_split") == "f32" else ["f32_split", "f32", "bf16"]
+    else:
+        modes = [args.dtype]
     if args.probe_only:
         print(json.dumps({m: roofline_probe(args, dev, m) for m in modes}), flush=True)
         return
@@ -580,7 +593,7 @@ def main():
     runs = {m: run_mode(args, m, world, rank, dev) for m in modes}
     lives = {m: runs[m].pop("_live_ms", {}) for m in modes}
     syncs = {m: runs[m].pop("_sync", None) for m in modes}
-    dist_info = dist_record(args, world, rank, local, dev, syncs[modes[0]]) if world > 1 else None
+    dist_info = dist_record(args, world, rank, local, dev, {"sync": {m: syncs[m] for m in modes}}) if world > 1 else None
     if rank == 0:
         head = runs[modes[0]]                              # fp32 unless a single dtype was asked for
         head_live = lives[modes[0]]
@@ -597,25 +610,27 @@ def main():
             "loss": head["loss"], "step_mfma_frac": head["step_mfma_frac"], "peak_mem_gb": head["peak_mem_gb"],
             "tuned_library_gemms": bool(tuned),
         }
-        if world == 1 and not args.no_roofline:
+        # rank 0 probes its own GPU while the other ranks wait at the closing barrier (N > 1: the line says how much of each
+        # kernel's peak a rank reaches and what the exchange looked like)
+        if not args.no_roofline:
             out["roofline"] = roofline_probe(args, dev, head["dtype"], head_live)
             log("roofline probe (%s) done" % head["dtype"])
         for m in modes[1:]:
             sub = dict(runs[m])
-            if world == 1 and not args.no_roofline and m != "f32_split":
+            if not args.no_roofline:
                 sub["roofline"] = roofline_probe(args, dev, m, lives[m])
                 log("roofline probe (%s) done" % m)
-            if m == "f32_split":
-                sub["vs_f32"] = round(sub["value"] / head["value"], 3) if head["dtype"] == "f32" else None
-                sub["note"] = ("NOT the headline: the same fp32 step with acr_set_option(ACR_OPT_GEMM_F32_SPLIT, 1); parity tests run in this "
-                               "mode at the fp32 tolerances (tests/test_model_gpu.py::test_split_gemm_mode_matches_the_reference_fixtures, "
-                               "test_kernels_gpu.py::test_gemm_f32_linear[split=1])")
+            if "f32" in runs and "f32_split" in runs and m in ("f32", "f32_split"):
+                sub["vs_" + head["dtype"]] = round(sub["value"] / head["value"], 3)
+            if m == "f32":
+                sub["note"] = ("the exact-fp32-MFMA arithmetic (rounds 1-3's headline), kept beside the split-product headline: same tensors, "
+                               "same kernels' tile structure, v_mfma_f32_32x32x2_f32 products; its bound is 157.3 TF / 1.131 TF per image = 139 img/s")
             out[m] = sub
         if dist_info is not None:
             out["dist"] = dist_info
         if world == 1 and not args.no_infer:
             out["infer"] = infer_record(args, dev, not args.no_cpu_baseline)
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:

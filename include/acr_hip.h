@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ACR_ABI_VERSION 1
+#define ACR_ABI_VERSION 2      /* 2: per-call `math` argument of the fp32 GEMM / 1x1-convolution entries, ACR_F32_BF16X3, acr_attn_bwd_ws_floats, acr_split3_bf16 */
 
 typedef enum acr_status {
     ACR_OK = 0,
@@ -37,8 +37,20 @@ typedef enum acr_status {
 
 /* ACR_F32: fp32 tensors, exact-fp32 MFMA (parity / inference precision).
  * ACR_BF16: bf16 tensors, bf16 MFMA with fp32 accumulate and fp32 softmax (training throughput precision).
- * ACR_BF16_F32MATH: bf16 tensors, every product in exact fp32 (debug / reference for the bf16 kernels). */
-typedef enum acr_dtype { ACR_F32 = 0, ACR_BF16 = 1, ACR_BF16_F32MATH = 2 } acr_dtype;
+ * ACR_BF16_F32MATH: bf16 tensors, every product in exact fp32 (debug / reference for the bf16 kernels).
+ * ACR_F32_BF16X3: fp32 tensors; every matrix product is evaluated on the bf16 MFMA as six exact terms of a three-way
+ *   operand split (acr_math below), fp32 accumulate, fp32 softmax / lse / delta / head mean -- fp32-accurate results at the
+ *   bf16 matrix rate.  Accepted by acr_attn_fwd_scores / acr_attn_bwd_scores (training attention). */
+typedef enum acr_dtype { ACR_F32 = 0, ACR_BF16 = 1, ACR_BF16_F32MATH = 2, ACR_F32_BF16X3 = 3 } acr_dtype;
+
+/* How an fp32 entry point multiplies (a PER-CALL argument: two models, or two calls of one model, may differ).
+ * ACR_MATH_F32: v_mfma_f32_32x32x2_f32, exact fp32 products (157 TF peak).
+ * ACR_MATH_BF16X3: a = a0 + a1 + a2 with a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1) (3 x 8 = 24 mantissa
+ *   bits = all of an fp32 mantissa), a.b ~ a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0 on v_mfma_f32_32x32x16_bf16 (the dropped
+ *   terms are <= 2^-24 |a.b|); every bf16 x bf16 product is exact in fp32 and the sums accumulate in fp32.  Same tensors,
+ *   layouts, epilogues and determinism as ACR_MATH_F32; as accurate against float64 as the fp32 FMA chain
+ *   (tests/test_kernels_gpu.py::test_split_math_adversarial_operands).  Peak: bf16 MFMA peak / 6 = 417 TF-equivalent. */
+typedef enum acr_math { ACR_MATH_F32 = 0, ACR_MATH_BF16X3 = 1 } acr_math;
 
 typedef enum acr_getam_func {   /* DPT/ACR.py:189-205 */
     ACR_GETAM_GRAD = 0, ACR_GETAM_CAM_GRAD = 1, ACR_GETAM_GRAD_S = 2, ACR_GETAM_CAM_GRAD_S = 3
@@ -77,7 +89,7 @@ typedef enum acr_option {
     ACR_OPT_ATTN_F32_NW = 8,    /* acr_attn_fwd_scores: 5 = five 32-query blocks (waves) per forward workgroup instead of four (A/B: slower) */
     ACR_OPT_GEMM_F32_NOTAIL = 9, /* 1: acr_gemm_f32 NT / NN never K-splits the tiles beyond the last whole half-round (A/B) */
     ACR_OPT_ATTN_F32_NOSPLITTAIL = 10, /* 1: resident-score attention keeps the leftover 32-row block as an ordinary (1 live wave) workgroup (A/B) */
-    ACR_OPT_GEMM_F32_SPLIT = 11, /* 1: acr_gemm_f32 evaluates every fp32 product as six bf16-MFMA terms of a three-way operand split (fp32-accurate, see gemm_f32.hip) */
+    ACR_OPT_RESERVED_11 = 11,   /* was ACR_OPT_GEMM_F32_SPLIT (ABI 1): the split-product arithmetic is now the per-call `math` argument */
     ACR_OPT_COUNT_
 } acr_option;
 int     acr_set_option(int32_t option, int32_t value);
@@ -109,8 +121,20 @@ int acr_attn_bwd(const acr_attn_desc* desc, const void* q, const void* k, const 
  * the `scores` of the matching forward call -- runs 5 matrix products instead of 8.  gmean additionally has to be 16-byte
  * aligned with row pitch and batch stride multiples of 4 floats.  Replaces the same reference lines as acr_attn_fwd /
  * acr_attn_bwd (models/vision_transformer.py:203-211 and its autograd backward; there P itself, (B,H,T,T), is what stays
- * resident between forward and backward). */
+ * resident between forward and backward).
+ *
+ * desc->dtype = ACR_F32_BF16X3 (csrc/attn_f32_x3.hip): the same contract on the same fp32 tensors, with S, PV, dP, dQ, dK, dV
+ * as split products on the bf16 MFMA (acr_math ACR_MATH_BF16X3); softmax, lse2, delta and the head mean stay fp32.  The
+ * forward splits q, k, v once into bf16 planes kept BEHIND the score blocks (acr_attn_scores_floats(desc) accounts for them:
+ * nine bf16 planes of B*T*H*64 elements), the backward reads them from there (its q / k / v
+ * arguments are ignored) and splits d_o into planes behind delta: delta_ws must hold acr_attn_bwd_ws_floats(desc) floats
+ * (B*H*T for ACR_F32) and be 16-byte aligned.  head strides must be >= 64. */
 int64_t acr_attn_scores_floats(const acr_attn_desc* desc);
+int64_t acr_attn_bwd_ws_floats(const acr_attn_desc* desc);
+/* x (rows, cols) fp32 with row pitch ld -> three dense bf16 (rows, cols) planes p0, p1, p2 at planes + i * plane_stride
+ * (elements) with x = p0 + p1 + p2 exactly (barring bf16 underflow): p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1).
+ * The operand form of acr_math ACR_MATH_BF16X3.  cols %% 8 == 0, 16-byte aligned pointers. */
+int acr_split3_bf16(const float* x, int64_t rows, int64_t cols, int64_t ld, void* planes, int64_t plane_stride, void* stream);
 int acr_attn_fwd_scores(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
                         void* o, float* lse2, float* scores, float* pmean, int64_t pmean_sb, int64_t pmean_st, void* stream);
 int acr_attn_bwd_scores(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
@@ -159,11 +183,12 @@ int acr_linear_dgelu_bf16(const void* a, int64_t lda, const void* w, int64_t ldw
  *      place of the pre-activation, the derivative its backward needs (one erff serves both; h itself is used nowhere else);
  *   2: c = acc * aux with aux = the saved GELU'(h) (fc2's input gradient taken through the activation).
  * Pitches in elements, multiples of 4; pointers 16-byte aligned; K %% 4 == 0 (NT/NN), M, N %% 4 == 0 and ldc == N (TN).
+ * math: acr_math (how the products are evaluated; everything else is identical).
  * ws: caller-owned scratch of acr_gemm_f32_ws_floats(mode, M, N, K) floats (TN: the split slabs; NT / NN: slabs for the K-split
  * tail tiles, 0 when the tile count needs none -- ws may then be NULL; without ws the product runs unsplit). */
 typedef enum acr_gemm_mode { ACR_GEMM_NT = 0, ACR_GEMM_NN = 1, ACR_GEMM_TN = 2 } acr_gemm_mode;
 size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K);
-int acr_gemm_f32(int32_t mode, int32_t act, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                  const float* aux, int64_t ldaux, float* c, int64_t ldc, float* c2, float* colsum, int32_t M, int32_t N,
                  int32_t K, float* ws, void* stream);
 
@@ -199,11 +224,12 @@ int acr_conv1x1_wgrad_bf16(const void* dy, const void* x, int32_t nsamp, int32_t
 /* The same 1x1 convolutions at the reference precision (fp32 NCHW) on the fp32 GEMM kernels, one slice per sample.
  * acr_conv1x1_f32: y[n] = W . x[n] (+ addend[n]); w_transposed = 0: w is (cout, cin); w_transposed = 1: w is stored (cin, cout),
  * i.e. the forward weight handed over as is for the input gradient (no transposed copy).  cout / cin / hw multiples of 4.
- * acr_conv1x1_wgrad_f32: dw (cout, cin) = sum_n dy[n] . x[n]^T through one fp32 slab per sample (ws: nsamp*cout*cin floats). */
-int acr_conv1x1_f32(const float* w, int32_t w_transposed, const float* x, const float* addend, float* y, int32_t nsamp,
+ * acr_conv1x1_wgrad_f32: dw (cout, cin) = sum_n dy[n] . x[n]^T through one fp32 slab per sample (ws: nsamp*cout*cin floats).
+ * math: acr_math, as for acr_gemm_f32. */
+int acr_conv1x1_f32(int32_t math, const float* w, int32_t w_transposed, const float* x, const float* addend, float* y, int32_t nsamp,
                     int32_t cout, int32_t cin, int32_t hw, void* stream);
 size_t acr_conv1x1_wgrad_f32_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t hw);
-int acr_conv1x1_wgrad_f32(const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw, float* ws,
+int acr_conv1x1_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw, float* ws,
                           float* dw, void* stream);
 
 /* ---- 3x3 stride-2 max-pool of the stem with TF-SAME -inf padding folded in (models/resnetv2.py:322-328) ----

@@ -1,4 +1,5 @@
-"""GPU lab: fp32 attention at the bench geometry (B = 32 views, H = 12, T = 785), recompute generation vs resident scores:
+"""GPU lab: fp32 attention at the bench geometry (B = 32 views, H = 12, T = 785), recompute generation vs resident scores vs resident scores with split
+products (csrc/attn_f32_x3.hip):
 forward (+ head mean) and backward (with the head-mean gradient) time per launch, HIP events on the launch stream, plus a
 max-abs comparison of the two generations' outputs.  usage: attn_gen.py [B] [T]"""
 import sys, os, torch
@@ -18,13 +19,13 @@ gst = torch.zeros(B, T, ops.pad4(T), device=dev)
 gst[:, :, :T] = torch.randn(B, T, T, device=dev) * 1e-3
 gpm = gst[:, :, :T]
 res = {}
-for gen in ("recompute", "scores nw4", "scores nw5"):
+for gen in ("recompute", "scores nw4", "split x3"):
     ops.ATTN_F32_SCORES = gen != "recompute"
     _lib.set_option("attn_f32_nw", 5 if gen.endswith("5") else 4)
     stack = ops.MeanStack(B, 1, T, dev)
     def run():
         qkv.grad = None
-        o, pm = ops.attention_core(qkv, H, stack, 0, None)
+        o, pm = ops.attention_core(qkv, H, stack, 0, None, 1 if gen.startswith("split") else 0)
         return o, pm
     o, pm = run()
     torch.autograd.backward([o, pm], [do, gpm])
@@ -43,7 +44,7 @@ for gen in ("recompute", "scores nw4", "scores nw5"):
     prod = 2.0 * T * T * 64 * B * H
     print("%-10s B %d T %d: fwd+pmean %.3f ms (%.1f TF algorithmic)   bwd %.3f ms (%.1f TF algorithmic)" % (
         gen, B, T, tf / reps, 2 * prod / (tf / reps) * 1e-9, tb / reps, 4 * prod / (tb / reps) * 1e-9), flush=True)
-a, b = res["recompute"], res["scores nw5"]
+a, b = res["scores nw4"], res["split x3"]
 for name, x, y in zip(("o", "pmean", "dqkv"), a, b):
-    print("%-6s max |recompute - scores| = %.3e  (max |x| %.3e)  finite %s" % (name, float((x - y).abs().max()), float(x.abs().max()),
+    print("%-6s max |scores - split| = %.3e  (max |x| %.3e)  finite %s" % (name, float((x - y).abs().max()), float(x.abs().max()),
                                                                              bool(torch.isfinite(y).all())))

@@ -75,9 +75,9 @@ int main(int argc, char** argv) {
 #ifdef LAB_STAMP
     hipMalloc(&g_lab_stamp, 2 * 8192 * 8); hipMemset(g_lab_stamp, 0, 2 * 8192 * 8);
 #endif
-    run("NT x W^T + b", [&] { acr_gemm_f32(ACR_GEMM_NT, 0, a, K, b, K, bias, nullptr, 0, c, N, nullptr, nullptr, M, N, K, nullptr, 0); });
-    run("NN dy W", [&] { acr_gemm_f32(ACR_GEMM_NN, 0, dy, N, b, K, nullptr, nullptr, 0, a, K, nullptr, nullptr, M, K, N, nullptr, 0); });
-    run("TN dy^T x", [&] { acr_gemm_f32(ACR_GEMM_TN, 0, dy, N, a, K, nullptr, nullptr, 0, dw, K, nullptr, nullptr, N, K, M, ws, 0); });
+    run("NT x W^T + b", [&] { acr_gemm_f32(ACR_GEMM_NT, ACR_MATH_F32, 0, a, K, b, K, bias, nullptr, 0, c, N, nullptr, nullptr, M, N, K, nullptr, 0); });
+    run("NN dy W", [&] { acr_gemm_f32(ACR_GEMM_NN, ACR_MATH_F32, 0, dy, N, b, K, nullptr, nullptr, 0, a, K, nullptr, nullptr, M, K, N, nullptr, 0); });
+    run("TN dy^T x", [&] { acr_gemm_f32(ACR_GEMM_TN, ACR_MATH_F32, 0, dy, N, a, K, nullptr, nullptr, 0, dw, K, nullptr, nullptr, N, K, M, ws, 0); });
     printf("last error: %s\n", g_err);
     return 0;
 }

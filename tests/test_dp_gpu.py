@@ -139,8 +139,9 @@ def test_bench_two_ranks_gloo_rehearsal(tmp_path):
     environment (the driver's command shape) must start the two ranks itself (child torch.distributed.run, one process per
     rank), relay ONE JSON line and return the child's code.  The ranks share cuda:0 with gloo collectives (`--backend gloo`:
     RCCL needs one GPU per rank and the test box has one).  Checks the contract fields: whole-job img/s over both ranks,
-    weak scaling, fp32 headline with the bf16 sub-record, and the `dist` record (what the process group looked like,
-    GradSync's buckets going out inside backward)."""
+    weak scaling, the split-product fp32 headline with the exact-fp32 and bf16 sub-records, `roofline` on the line (rank 0's
+    probe; the CPU baseline is switched off here for time, its N > 1 placement is the same code path as N = 1) and the `dist`
+    record: what the process group looked like and GradSync's buckets going out inside backward, PER MODE (VERDICT r3 #11)."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
@@ -153,16 +154,21 @@ def test_bench_two_ranks_gloo_rehearsal(tmp_path):
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["dtype"] == "f32" and rec["config"]["global_batch"] == 4
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["dtype"] == "f32_split" and rec["config"]["global_batch"] == 4
     assert rec["config"]["parallelism"] == "dp2" and rec["unit"] == "img/s" and rec["higher_is_better"] is True
     assert abs(rec["value"] - 4 * 1e3 / rec["ms_per_step"]) <= 0.02 * rec["value"]          # whole job: both ranks' images
-    assert rec["bf16"]["dtype"] == "bf16" and rec["bf16"]["value"] > 0 and "roofline" not in rec and "infer" not in rec
+    assert rec["bf16"]["dtype"] == "bf16" and rec["bf16"]["value"] > 0 and rec["f32"]["dtype"] == "f32" and "infer" not in rec
+    for r in (rec["roofline"], rec["f32"]["roofline"], rec["bf16"]["roofline"]):
+        assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["unit"] == "TFLOP/s" and "kernels" in r
+    assert abs(rec["roofline"]["peak"] - 2500.0 / 6) < 0.1 and rec["f32"]["roofline"]["peak"] == 157.3
     d = rec["dist"]
     assert d["backend"] == "gloo" and d["world_size"] == 2 and [r["rank"] for r in d["ranks_devices"]] == [0, 1]
-    assert d["buckets"] >= 1 and len(d["bucket_mb"]) == d["buckets"] and d["rank_disagreements"] == 0
-    # step 0 learns the unused tensors (everything from finish()); from step 1 on every bucket goes out inside backward
-    assert d["steps_counted"] == 4 and d["bucket_launches_in_backward"] == 3 * d["buckets"]
-    assert d["bucket_launches_in_finish"] == d["buckets"] and d["late_reexchanges"] == 0
+    assert sorted(d["sync"]) == ["bf16", "f32", "f32_split"]
+    for m, sy in d["sync"].items():
+        assert sy["buckets"] >= 1 and len(sy["bucket_mb"]) == sy["buckets"] and sy["rank_disagreements"] == 0, m
+        # step 0 learns the unused tensors (everything from finish()); from step 1 on every bucket goes out inside backward
+        assert sy["steps_counted"] == 4 and sy["bucket_launches_in_backward"] == 3 * sy["buckets"], m
+        assert sy["bucket_launches_in_finish"] == sy["buckets"] and sy["late_reexchanges"] == 0, m
     # a wrong WORLD_SIZE is still an error, not a silent single-rank run
     bad = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                          cwd=str(tmp_path))

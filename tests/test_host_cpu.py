@@ -33,8 +33,17 @@ def test_library_exports_every_declared_symbol(built):
     lib = built.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.acr_version() == 1
+    assert lib.acr_version() == 2
     assert lib.acr_consistency_ws_floats(16, 12, 785) > 0          # host-only helper, no GPU touched
+    # size queries of the attention entry points per arithmetic (host-only): the split-product dtype keeps the bf16 planes of
+    # q, k, v behind the score blocks and those of dO behind delta
+    d = built.AttnDesc()
+    d.B, d.H, d.T, d.head_dim, d.dtype = 2, 12, 785, 64, built.ACR_F32
+    blocks = 2 * 12 * 25 * 25 * 1024
+    assert lib.acr_attn_scores_floats(d) == blocks and lib.acr_attn_bwd_ws_floats(d) == 2 * 12 * 785
+    d.dtype = built.ACR_F32_BF16X3
+    assert lib.acr_attn_scores_floats(d) == blocks + 9 * (2 * 785 * 768) // 2
+    assert lib.acr_attn_bwd_ws_floats(d) == 2 * 12 * 785 + 3 * (2 * 785 * 768) // 2
 
 
 def test_state_dict_layout_matches_reference():

@@ -89,23 +89,32 @@ def test_consistency_full_size_is_a_mean_over_samples():
 @pytest.mark.parametrize("B,T,H", [(2, 2, 1), (1, 17, 12), (2, 197, 3), (1, 785, 12), (1, 1025, 2),
                                    (1, 2305, 3), (1, 3137, 1)])          # multi-scale inference: 768^2 and 896^2
 @pytest.mark.parametrize("with_g", [True, False])
-@pytest.mark.parametrize("gen", ["scores", "recompute"])
+@pytest.mark.parametrize("gen", ["scores", "recompute", "split"])
 def test_attention_f32(B, T, H, with_g, gen, monkeypatch):
-    """Both fp32 generations (resident scores: csrc/attn_f32_sres.hip, the default; recompute: csrc/attn_f32_dma.hip) against
-    fp64 math of models/vision_transformer.py:203-211 + the head mean of DPT/ACR.py:107-112."""
+    """The fp32 generations (resident scores: csrc/attn_f32_sres.hip, the default; recompute: csrc/attn_f32_dma.hip; split:
+    csrc/attn_f32_x3.hip -- resident scores with S, PV, dP, dQ, dK, dV as six bf16-MFMA terms of a three-way operand split,
+    math = "f32_split") against fp64 math of models/vision_transformer.py:203-211 + the head mean of DPT/ACR.py:107-112, all
+    three at the SAME tolerances."""
     from acr_wsss_amd import ops
-    monkeypatch.setattr(ops, "ATTN_F32_SCORES", gen == "scores")
+    monkeypatch.setattr(ops, "ATTN_F32_SCORES", gen != "recompute")
+    math = 1 if gen == "split" else 0
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(T * 3 + H)
     qkv = (1.5 * torch.randn(B, T, 3 * H * 64, generator=g)).to(dev).requires_grad_(True)
     Ly = 2
     stack = ops.MeanStack(B, Ly, T, dev)
     stack.buf.fill_(float("nan"))
-    o, pm = ops.attention_core(qkv, H, stack, 1, None)
+    o, pm = ops.attention_core(qkv, H, stack, 1, None, math)
     d_o = torch.randn(B, T, H * 64, generator=g).to(dev)
     gpm = torch.randn(B, T, T, generator=g).to(dev) if with_g else None
     loss = (o * d_o).sum() + ((pm * gpm).sum() if with_g else 0.0)
     loss.backward()
+    if gen == "split":                                       # deterministic: a second run repeats bit for bit
+        q2 = qkv.detach().clone().requires_grad_(True)
+        stack2 = ops.MeanStack(B, Ly, T, dev)
+        o2, pm2 = ops.attention_core(q2, H, stack2, 1, None, math)
+        ((o2 * d_o).sum() + ((pm2 * gpm).sum() if with_g else 0.0)).backward()
+        assert torch.equal(o2, o) and torch.equal(pm2, pm) and torch.equal(q2.grad, qkv.grad)
 
     qd = qkv.detach().double().requires_grad_(True)
     o_ref, P = _ref_attn(qd, H)
@@ -551,25 +560,20 @@ def test_gemm_f32_linear(M, N, K, split):
     of 128), N with a partial tile (200, 576), K tails (72 = 2.25 chunks) and a token count that is not a multiple of
     the 32-deep chunk in the TN contraction (785, 1573, 1025); products of a few dozen tiles (CAM generation at batch 2:
     1154 = 2 x 577 and 290 = 2 x 145 tokens), which run entirely as K-split parts + the tail epilogue.
-    split = 1: the same products as six bf16-MFMA terms of a three-way operand split (ACR_OPT_GEMM_F32_SPLIT) -- held to the
-    SAME 1e-5 against fp64 as the exact-fp32 MFMA, and bit-reproducible."""
-    from acr_wsss_amd import ops, _lib
-    dev = _dev()
-    _lib.set_option("gemm_f32_split", split)
-    try:
-        _gemm_f32_linear_case(ops, dev, M, N, K)
-    finally:
-        _lib.set_option("gemm_f32_split", int(os.environ.get("ACR_GEMM_F32_SPLIT", "0") == "1"))
+    split = 1: the same products as six bf16-MFMA terms of a three-way operand split (math = ACR_MATH_BF16X3, a per-call
+    argument) -- held to the SAME 1e-5 against fp64 as the exact-fp32 MFMA, and bit-reproducible."""
+    from acr_wsss_amd import ops
+    _gemm_f32_linear_case(ops, _dev(), M, N, K, split)
 
 
-def _gemm_f32_linear_case(ops, dev, M, N, K):
+def _gemm_f32_linear_case(ops, dev, M, N, K, math=0):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).to(dev).requires_grad_(True)
     w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).requires_grad_(True)
     b = torch.randn(N, generator=g).to(dev).requires_grad_(True)
     r = torch.randn(M, N, generator=g).to(dev).requires_grad_(True)
     assert ops.linear_f32_usable(x, w)
-    y = ops.LinearF32Fn.apply(x, w, b, r)
+    y = ops.LinearF32Fn.apply(x, w, b, r, None, math)
     dy = torch.randn(M, N, generator=g).to(dev)
     (y * dy).sum().backward()
     xd, wd, bd, rd = (t.detach().double().requires_grad_(True) for t in (x, w, b, r))
@@ -582,19 +586,159 @@ def _gemm_f32_linear_case(ops, dev, M, N, K):
     # deterministic (split-token slabs are summed in a fixed order)
     w.grad = None
     x.grad = None
-    y2 = ops.LinearF32Fn.apply(x, w, b, r)
+    y2 = ops.LinearF32Fn.apply(x, w, b, r, None, math)
     (y2 * dy).sum().backward()
     assert torch.equal(y2, y)
     dw1 = w.grad.clone()
     w.grad = None
-    (ops.LinearF32Fn.apply(x, w, b, r) * dy).sum().backward()
+    (ops.LinearF32Fn.apply(x, w, b, r, None, math) * dy).sum().backward()
     assert torch.equal(dw1, w.grad)
 
 
+def _gemm_pair(ops, mode, a, b, shape):
+    """(exact-fp32 MFMA result, split-product result, fp64 reference, condition scale sum_k |a||b|) of one acr_gemm_f32 call."""
+    outs = []
+    for math in (0, 1):
+        c = torch.empty(shape, dtype=torch.float32, device=a.device)
+        ops.gemm_f32_raw(mode, a, b, c, math=math)
+        outs.append(c.double())
+    ad, bd = a.double(), b.double()
+    if mode == "nt":
+        ref, scale = ad @ bd.t(), ad.abs() @ bd.abs().t()
+    elif mode == "nn":
+        ref, scale = ad @ bd, ad.abs() @ bd.abs()
+    else:
+        ref, scale = ad.t() @ bd, ad.abs().t() @ bd.abs()
+    return outs[0], outs[1], ref, scale
+
+
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("case", ["range", "cancel", "underflow"])
+def test_split_math_adversarial_operands(mode, case):
+    """the split-product arithmetic (math = ACR_MATH_BF16X3: six bf16-MFMA terms of a three-way operand
+    split) on operands chosen to break a narrower format, held to <= 2x the exact-fp32 MFMA kernel's OWN error against fp64
+    on the same inputs (errors normalised by sum_k |a||b|, the scale fp32 rounding errors live on):
+      range      every contraction row spans 2^-40 .. 2^+40 (bf16 alone would keep 8 bits of the large terms and nothing of
+                 the small ones; the three pieces carry 24 bits of EACH element, whatever its exponent);
+      cancel     dot products that cancel to ~1e-6 of their terms (the second half of the contraction repeats the first with
+                 the opposite sign and a 1e-6 relative perturbation): the result is made of the low-order bits;
+      underflow  operands of magnitude 2^-112: their second / third pieces fall below bf16's normal range.  Measured and
+                 documented behaviour: the lost pieces are an ABSOLUTE error of at most 2^-126 per product factor, i.e.
+                 <= 2^-126 * (sum_k |a| + sum_k |b|) per output on top of the 2x bound -- operands above ~2^-100 (every
+                 activation and gradient of this network by > 60 binades) are unaffected."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, N, K = 384, 256, 768
+    am, bm = ((M, K), (N, K)) if mode == "nt" else (((M, K), (K, N)) if mode == "nn" else ((K, M), (K, N)))
+    kdim_a = 1 if mode in ("nt", "nn") else 0
+    kdim_b = 1 if mode == "nt" else 0
+    a, b = torch.randn(am, generator=g), torch.randn(bm, generator=g)
+    if case == "range":
+        a = a * torch.exp2(torch.randint(-40, 41, am, generator=g).float())
+        b = b * torch.exp2(torch.randint(-20, 21, bm, generator=g).float())
+    elif case == "cancel":
+        h = K // 2
+        ia, ib = [slice(None)] * 2, [slice(None)] * 2
+        ia2, ib2 = list(ia), list(ib)
+        ia[kdim_a], ia2[kdim_a], ib[kdim_b], ib2[kdim_b] = slice(0, h), slice(h, K), slice(0, h), slice(h, K)
+        a[tuple(ia2)] = a[tuple(ia)]
+        b[tuple(ib2)] = -b[tuple(ib)] * (1 + 1e-6 * torch.randn(b[tuple(ib)].shape, generator=g))
+    else:
+        a = a * 2.0 ** -112
+    a, b = a.to(dev).contiguous(), b.to(dev).contiguous()
+    exact, split, ref, scale = _gemm_pair(ops, mode, a, b, (M, N))
+    assert torch.isfinite(exact).all() and torch.isfinite(split).all()
+    if case == "cancel":                                     # the instance really cancels: |result| ~ 1e-6 .. 1e-5 of its terms
+        assert float((ref.abs() / scale).median()) < 2e-5
+    e_exact, e_split = (exact - ref).abs() / scale, (split - ref).abs() / scale
+    floor = 2.0 ** -126 * (a.double().abs().sum(kdim_a).reshape(-1, 1) + b.double().abs().sum(kdim_b).reshape(1, -1)) / scale \
+        if case == "underflow" else 0.0
+    print("%s/%s: max normalised error exact %.3e split %.3e; rms exact %.3e split %.3e" % (
+        mode, case, float(e_exact.max()), float(e_split.max()), float(e_exact.pow(2).mean().sqrt()), float(e_split.pow(2).mean().sqrt())))
+    assert float(e_split.max()) <= 2 * float(e_exact.max()) + float(torch.as_tensor(floor).max())
+    assert float(e_split.pow(2).mean().sqrt()) <= 2 * float(e_exact.pow(2).mean().sqrt()) + float(torch.as_tensor(floor).max())
+    assert float(e_exact.max()) < 1e-6                       # sanity: the yardstick itself is an fp32-accurate kernel
+
+
+def test_split_math_propagates_non_finite_values():
+    """inf / NaN operands under the split-product arithmetic: a non-finite input never yields a finite output where the exact
+    arithmetic has none (a NaN stays a NaN; an inf becomes a NaN because inf - bf16(inf) is one: documented in
+    include/acr_hip.h's acr_math), and rows / columns without one are untouched."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, N, K = 256, 128, 256
+    a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    a[3, 17], a[40, 200], a[77, 5] = float("inf"), float("nan"), float("-inf")
+    b[9, 100] = float("nan")
+    a, b = a.to(dev), b.to(dev)
+    exact, split, ref, _ = _gemm_pair(ops, "nt", a, b, (M, N))
+    bad = ~torch.isfinite(ref)
+    assert bad[3].all() and bad[40].all() and bad[77].all() and bad[:, 9].all() and int(bad.sum()) == 3 * N + M - 3
+    assert (~torch.isfinite(split))[bad].all() and (~torch.isfinite(exact))[bad].all()
+    assert torch.isnan(split[40]).all() and torch.isnan(split[:, 9]).all()
+    ok = ~bad
+    assert torch.isfinite(split[ok]).all()
+    assert float((split[ok] - ref[ok]).abs().max()) <= 2 * float((exact[ok] - ref[ok]).abs().max()) + 1e-6
+
+
+def test_split3_planes_sum_to_the_operand_exactly():
+    """acr_split3_bf16 (the operand form of the split-product arithmetic): x = p0 + p1 + p2 EXACTLY for every fp32 value whose
+    pieces stay in bf16's normal range -- 3 x 8 significand bits cover the 24 of an fp32 -- incl. values spanning 2^+-60."""
+    from acr_wsss_amd import _lib as L
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rows, cols, ld = 300, 192, 200
+    buf = (torch.randn(rows, ld, generator=g) * torch.exp2(torch.randint(-60, 61, (rows, ld), generator=g).float())).to(dev)
+    x = buf[:, :cols]
+    planes = torch.empty((3, rows, cols), dtype=torch.bfloat16, device=dev)
+    L.check(L.load().acr_split3_bf16(L.ptr(x), rows, cols, ld, L.ptr(planes), rows * cols, L.stream_ptr()), "acr_split3_bf16")
+    p = planes.double()
+    assert torch.equal(p[0] + p[1] + p[2], x.double())
+    assert torch.equal(planes[0], x.to(torch.bfloat16))
+    assert float((p[1].abs() / x.double().abs().clamp_min(1e-300)).max()) <= 2.0 ** -8
+    assert float((p[2].abs() / x.double().abs().clamp_min(1e-300)).max()) <= 2.0 ** -16
+
+
+def test_attention_split_math_sharp_softmax_is_as_accurate_as_exact():
+    """The split-product attention on an adversarial instance for a narrower format: logits of +-200 (q, k scaled 6x: one-hot
+    softmax rows beside flat ones), v with a 2^+-20 spread inside a row.  Output, head mean and dqkv errors against fp64 are
+    held to <= 2x those of the exact-fp32 kernels on the same inputs (+ a floor of 1e-6 of the tensor's max)."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(2)
+    B, T, H = 1, 197, 2
+    qkv = torch.randn(B, T, 3, H, 64, generator=g)
+    qkv[:, :, :2] *= 6.0
+    qkv[:, :, 2] *= torch.exp2(torch.randint(-20, 21, (B, T, H, 64), generator=g).float())
+    qkv = qkv.reshape(B, T, 3 * H * 64).to(dev)
+    d_o = torch.randn(B, T, H * 64, generator=g).to(dev)
+    gpm = torch.randn(B, T, T, generator=g).to(dev)
+    res = []
+    for math in (0, 1):
+        q = qkv.clone().requires_grad_(True)
+        stack = ops.MeanStack(B, 1, T, dev)
+        o, pm = ops.attention_core(q, H, stack, 0, None, math)
+        ((o * d_o).sum() + (pm * gpm).sum()).backward()
+        res.append((o.detach().double(), pm.detach().double(), q.grad.double()))
+    qd = qkv.double().requires_grad_(True)
+    o_ref, P = _ref_attn(qd, H)
+    pm_ref = P.mean(1)
+    ((o_ref * d_o.double()).sum() + (pm_ref * gpm.double()).sum()).backward()
+    for name, i, want in (("o", 0, o_ref.detach()), ("pmean", 1, pm_ref.detach()), ("dqkv", 2, qd.grad)):
+        e0 = float((res[0][i] - want).abs().max() / want.abs().max())
+        e1 = float((res[1][i] - want).abs().max() / want.abs().max())
+        print("%s: exact %.3e split %.3e of max" % (name, e0, e1))
+        assert e1 <= 2 * e0 + 1e-6, (name, e0, e1)
+
+
+@pytest.mark.parametrize("math", [0, 1])
 @pytest.mark.parametrize("M,D,Hd", [(197 * 2, 192, 768), (785, 768, 3072), (131, 128, 260), (290, 768, 3072)])
-def test_fused_mlp_f32(M, D, Hd):
+def test_fused_mlp_f32(M, D, Hd, math):
     """MlpF32Fn (GELU / GELU' inside the fp32 GEMM epilogues) against fp64 fc2(gelu(fc1(x))) + resid and against the
-    stock torch fp32 ops it replaces (same exact-erf GELU): output and all six gradients."""
+    stock torch fp32 ops it replaces (same exact-erf GELU): output and all six gradients.  math = 1: split products on the bf16
+    MFMA, same tolerance."""
     from acr_wsss_amd import ops
     import torch.nn.functional as F
     dev = _dev()
@@ -608,7 +752,7 @@ def test_fused_mlp_f32(M, D, Hd):
     r = torch.randn(1, M, D, generator=g).to(dev).requires_grad_(True)
     dy = torch.randn(1, M, D, generator=g).to(dev)
     assert ops.mlp_f32_usable(x, fc1, fc2)
-    y = ops.mlp_f32(x, fc1, fc2, r)
+    y = ops.mlp_f32(x, fc1, fc2, r, math)
     (y * dy).sum().backward()
     got = [y, x.grad, r.grad, fc1.weight.grad, fc1.bias.grad, fc2.weight.grad, fc2.bias.grad]
     xd, rd = x.detach().double().requires_grad_(True), r.detach().double().requires_grad_(True)
@@ -708,10 +852,12 @@ def test_groupnorm_f32(N, C, H, W, act):
 
 @pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 64, 8, 8), (3, 64, 256, 16, 24), (2, 256, 64, 28, 28), (2, 1024, 256, 28, 28),
                                              (2, 128, 512, 56, 56), (1, 64, 256, 112, 112), (2, 1024, 768, 28, 28)])
-def test_conv1x1_f32(N, cin, cout, H, W):
+@pytest.mark.parametrize("math", [0, 1])
+def test_conv1x1_f32(N, cin, cout, H, W, math):
     """fp32 NCHW 1x1 convolution on the fp32 GEMM kernels (one z-slice per sample): forward, input gradient with the shortcut's
     gradient added in the epilogue, weight gradient through per-sample slabs -- vs fp64 conv2d.  28x28 = 784 pixels is not a
-    multiple of the 32-deep chunk (register-staged kernel for the weight gradient), cout = 64 fills half a tile."""
+    multiple of the 32-deep chunk (register-staged kernel for the weight gradient), cout = 64 fills half a tile.  math = 1: split
+    products on the bf16 MFMA (the LDS-DMA shapes; the others stay on the exact kernels), same tolerance."""
     from acr_wsss_amd import ops
     import torch.nn.functional as F
     dev = _dev()
@@ -719,7 +865,7 @@ def test_conv1x1_f32(N, cin, cout, H, W):
     x = torch.randn(N, cin, H, W, generator=g).to(dev).requires_grad_(True)
     w = (torch.randn(cout, cin, 1, 1, generator=g) * cin ** -0.5).to(dev).requires_grad_(True)
     assert ops.conv1x1_fusable(x, w, 1)
-    y, skip = ops.conv1x1_skip(x, w)
+    y, skip = ops.conv1x1_skip(x, w, None, math)
     dy = torch.randn(N, cout, H, W, generator=g).to(dev)
     ds = torch.randn(N, cin, H, W, generator=g).to(dev)
     ((y * dy).sum() + (skip * ds).sum()).backward()
@@ -866,7 +1012,7 @@ def test_c_abi_launches_capture_into_a_hip_graph():
         L.check(lib.acr_attn_fwd(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(pm), T * T, T, st), "fwd")
         L.check(lib.acr_attn_bwd(d, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(gm), gm.stride(0), gm.stride(1), dqp, dkp, dvp,
                                  L.ptr(delta), st), "bwd")
-        L.check(lib.acr_gemm_f32(0, 0, L.ptr(o.view(B * T, 768)), 768, L.ptr(w), 768, L.ptr(bias), L.ptr(x), 768, L.ptr(y), 768, None, None,
+        L.check(lib.acr_gemm_f32(0, 0, 0, L.ptr(o.view(B * T, 768)), 768, L.ptr(w), 768, L.ptr(bias), L.ptr(x), 768, L.ptr(y), 768, None, None,
                                  B * T, 768, 768, None, st), "gemm")
 
     def eager():
