@@ -39,6 +39,54 @@ typedef const __attribute__((address_space(1))) void* x3_glb_vp;
 #define X3_STORE_NT(p, v) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p))
 #define X3_LOAD_NT(p) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p))
 
+#ifdef LAB_TL                      // lab builds only (scripts/lab/attn_x3_phases.py): per-phase cycle sums of every wave 0
+__device__ unsigned long long g_lab_x3[8 * 16384];
+extern "C" int acr_lab_x3_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_x3), (size_t)n * 8);
+}
+#define X3L_T() __builtin_amdgcn_s_memtime()
+#define X3L_DECL unsigned long long lt_[6] = {0, 0, 0, 0, 0, 0}, lp_ = 0; (void)lp_
+#define X3L_MARK() (lp_ = X3L_T())
+#define X3L_ADD(i) do { const unsigned long long n_ = X3L_T(); lt_[i] += n_ - lp_; lp_ = n_; } while (0)
+#define X3L_OUT(kind, nsteps) do { if (threadIdx.x == 0 && blockIdx.x < 16384) { unsigned long long* d_ = g_lab_x3 + 8 * blockIdx.x; \
+        for (int i_ = 0; i_ < 6; ++i_) d_[i_] = lt_[i_]; d_[6] = (nsteps); d_[7] = (kind); } } while (0)
+#define X3L_USE(v) asm volatile("" :: "v"(v))
+#else
+#define X3L_DECL
+#define X3L_MARK()
+#define X3L_ADD(i)
+#define X3L_OUT(kind, nsteps)
+#define X3L_USE(v)
+#endif
+
+// ---- counted waits ------------------------------------------------------------------------------------------------------------
+// A step's tile DMA must have landed at the step's barrier, but the streams that run further ahead (score blocks two steps
+// ahead, G one step, the forward's score stores) are YOUNGER vector-memory operations and may stay in flight: vmcnt retires in
+// issue order, so "at most n outstanding" with n = the number of younger operations is exactly "the tile has landed".  n is
+// wave-uniform; a count that is not listed waits for the next smaller one (stricter, never wrong).
+template <int N>
+__device__ __forceinline__ void x3_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void x3_wait_vm(int n) {
+    if (n >= 9) x3_vmcnt<9>();
+    else if (n >= 8) x3_vmcnt<8>();
+    else if (n >= 7) x3_vmcnt<7>();
+    else if (n >= 5) x3_vmcnt<5>();
+    else if (n >= 4) x3_vmcnt<4>();
+    else if (n >= 1) x3_vmcnt<1>();
+    else x3_vmcnt<0>();
+}
+// compiler-only fence: vector-memory operations written after it are issued after the ones before it (the counts above rely
+// on the issue order; loads from global memory and LDS-DMA writes do not alias, so nothing else orders them for the compiler)
+#define X3_FENCE() asm volatile("" ::: "memory")
+#ifdef LAB_TL
+#define x3_barrier(n_younger) do { x3_wait_vm(n_younger); X3L_ADD(5); __syncthreads(); } while (0)      /* lab: the wait on its own */
+#else
+__device__ __forceinline__ void x3_barrier(int n_younger) {
+    x3_wait_vm(n_younger);
+    __syncthreads();
+}
+#endif
+
 struct X3Geom {
     int B, H, T, D;                        // D = H * 64: row pitch (elements) of every plane
     float scale;
@@ -157,71 +205,129 @@ __device__ __forceinline__ void x3_dma_tile(char* lds, const bf16_t* __restrict_
         __builtin_amdgcn_global_load_lds((x3_glb_vp)(src + p * plane), (x3_lds_vp)(lds + p * X3_PLANE_B + wave * 1024), 16, 0, 0);
 }
 
-// ---- fragment addresses (byte offsets inside one plane image; lane-dependent part, computed once per wave) -------------------------
-struct X3Lane { int rowb[4]; int trb[2][2]; };
-__device__ __forceinline__ X3Lane x3_lane(int lane) {
+// ---- fragment addresses (LDS byte addresses of plane 0 of the tile at ring offset 0; lane-dependent part, computed once) -------
+struct X3Lane { uint32_t rowb[4]; uint32_t trb[2][2]; };
+__device__ __forceinline__ uint32_t x3_lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ X3Lane x3_lane(int lane, const char* smem) {
     X3Lane lb;
+    const uint32_t lds0 = x3_lds_addr(smem);
     const int r = lane & 31, h = lane >> 5;
     const int fr = x3_swz(r);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) lb.rowb[s] = r * 128 + (((2 * s + h) ^ fr) << 4);
+    for (int s = 0; s < 4; ++s) lb.rowb[s] = lds0 + r * 128 + (((2 * s + h) ^ fr) << 4);
     const int i = lane & 15, g1 = (lane >> 4) & 1, q = i >> 2, p = i & 3;
 #pragma unroll
     for (int hi = 0; hi < 2; ++hi) {
         const int row = 8 * hi + 4 * h + q;                // + 16 s rows per k-step: f is unchanged by it
         const int f = x3_swz(row);
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) lb.trb[hi][blk] = row * 128 + (((4 * blk + 2 * g1 + (p >> 1)) ^ f) << 4) + 8 * (p & 1);
+        for (int blk = 0; blk < 2; ++blk) lb.trb[hi][blk] = lds0 + row * 128 + (((4 * blk + 2 * g1 + (p >> 1)) ^ f) << 4) + 8 * (p & 1);
     }
     return lb;
 }
+// Every LDS read that follows an LDS-DMA in program order is INLINE ASM with its own counted lgkmcnt wait: hipcc cannot tell a
+// DMA's LDS write from a read of another slot and puts s_waitcnt vmcnt(0) in front of every LDS load builtin behind one --
+// which made each step wait for the tiles and score blocks it had just sent for (found in the first version's ISA; the same
+// finding as gemm_bf16.hip).  LDS operations of a wave return in order, so "at most n outstanding" = "all but my n newest
+// reads have landed"; operations the compiler adds around them only make a wait stricter.  Outputs are early-clobber and the
+// waits name the registers that must have landed.
+#define X3_RD128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
+#define X3_RD32(dst, addr, OFF) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
+#define X3_RDTR(lo, hi, alo, ahi, OFF)                                                                  \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"          \
+                 : "=&v"(lo), "=&v"(hi) : "v"(alo), "v"(ahi), "i"(OFF))
+#define X3_WAIT3(cnt, x) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]))
+#define X3_WAIT6(cnt, l, h_) \
+    asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(h_[0]), "+v"(h_[1]), "+v"(h_[2]))
 // rows of the tile as an MFMA operand: element j of lane (r, h) = tile[r][16 S + 8 h + j], planes 0..2
-template <int TILE_OFF, int S>
-__device__ __forceinline__ void x3_rowfrag(bf16x8 (&a)[3], const char* sm, const X3Lane& lb) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(sm + lb.rowb[S] + (TILE_OFF + p * X3_PLANE_B));
+#define X3_ROWFRAG(a, lb, TOFF, S) \
+    { X3_RD128(a[0], lb.rowb[S], TOFF); X3_RD128(a[1], lb.rowb[S], (TOFF) + X3_PLANE_B); X3_RD128(a[2], lb.rowb[S], (TOFF) + 2 * X3_PLANE_B); }
+// the tile transposed: element j of lane (r, h) = tile[16 S + 8 (j >> 2) + 4 h + (j & 3)][32 BLK + r] (lo: j < 4, hi: j >= 4)
+#define X3_TRFRAG(l, h_, lb, TOFF, S, BLK)                                                      \
+    { X3_RDTR(l[0], h_[0], lb.trb[0][BLK], lb.trb[1][BLK], (TOFF) + (S) * 2048);                 \
+      X3_RDTR(l[1], h_[1], lb.trb[0][BLK], lb.trb[1][BLK], (TOFF) + X3_PLANE_B + (S) * 2048);    \
+      X3_RDTR(l[2], h_[2], lb.trb[0][BLK], lb.trb[1][BLK], (TOFF) + 2 * X3_PLANE_B + (S) * 2048); }
+#define X3_JOIN(a, l, h_)                                                                       \
+    const bf16x8 a[3] = {__builtin_shufflevector(l[0], h_[0], 0, 1, 2, 3, 4, 5, 6, 7),           \
+                         __builtin_shufflevector(l[1], h_[1], 0, 1, 2, 3, 4, 5, 6, 7),           \
+                         __builtin_shufflevector(l[2], h_[2], 0, 1, 2, 3, 4, 5, 6, 7)}
+
+// FILLERS.  Both waves of a SIMD run the same program from the same barrier: left alone they reach their matrix work together
+// and their vector work together (first version: 56-59 % of a step's cycles were one wave waiting for its partner at the
+// barrier, scripts/lab/attn_x3_phases.py).  A six-MFMA group keeps the matrix pipe for ~190 cycles; the operations below take
+// callables f0..f2 that run BETWEEN the groups -- the step's DMA issue and the operand splits go there -- so that a wave's
+// stream alternates matrix and vector work in ~200-cycle pieces and the partner's groups fall into the gaps.
+struct X3Nop { __device__ __forceinline__ void operator()() const {} };
+
+// acc[krow(reg,h)][r] += sum_d tile[krow][d] * y[r][d]: tile rows = A operand, y = the lane's row held as fragments y[plane][k-step].
+// The reads of k-step S + 1 are in flight while the six MFMAs of k-step S run.
+template <int TILE_OFF, class F0 = X3Nop, class F1 = X3Nop, class F2 = X3Nop>
+__device__ __forceinline__ void x3_rowop(f32x16& acc, const X3Lane& lb, const bf16x8 (&y)[3][4], F0&& f0 = F0(), F1&& f1 = F1(),
+                                         F2&& f2 = F2()) {
+    bf16x8 a0[3], a1[3];
+    X3_ROWFRAG(a0, lb, TILE_OFF, 0);
+    X3_ROWFRAG(a1, lb, TILE_OFF, 1);
+    X3_WAIT3(3, a0);
+    { const bf16x8 b_[3] = {y[0][0], y[1][0], y[2][0]}; X3_MFMA6(acc, a0, b_); }
+    f0();
+    X3_ROWFRAG(a0, lb, TILE_OFF, 2);
+    X3_WAIT3(3, a1);
+    { const bf16x8 b_[3] = {y[0][1], y[1][1], y[2][1]}; X3_MFMA6(acc, a1, b_); }
+    f1();
+    X3_ROWFRAG(a1, lb, TILE_OFF, 3);
+    X3_WAIT3(3, a0);
+    { const bf16x8 b_[3] = {y[0][2], y[1][2], y[2][2]}; X3_MFMA6(acc, a0, b_); }
+    f2();
+    X3_WAIT3(0, a1);
+    { const bf16x8 b_[3] = {y[0][3], y[1][3], y[2][3]}; X3_MFMA6(acc, a1, b_); }
 }
-// the tile transposed: element j of lane (r, h) = tile[16 S + 8 (j >> 2) + 4 h + (j & 3)][32 BLK + r]
-template <int TILE_OFF, int S, int BLK>
-__device__ __forceinline__ void x3_trfrag(bf16x8 (&a)[3], const char* sm, const X3Lane& lb) {
-    typedef __attribute__((address_space(3))) bf16x4* lds_p;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(sm + lb.trb[0][BLK] + (TILE_OFF + p * X3_PLANE_B + S * 2048)));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(sm + lb.trb[1][BLK] + (TILE_OFF + p * X3_PLANE_B + S * 2048)));
-        a[p] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
+// The accumulator tile z (pieces z0: rows 0-15, z1: rows 16-31) times the transposed tile, both 32-column blocks:
+//   ZA = true :  acc_blk[i = z-lane][j = tile column 32 blk + r]      (z is the A operand)
+//   ZA = false:  acc_blk[i = tile column 32 blk + krow][j = z-lane]   (z is the B operand)
+// Group order (k-step, block): (0,0) (0,1) (1,0) (1,1) -- z1 is first read after f1, so f0 / f1 may still be producing it.
+template <int TILE_OFF, bool ZA, class F0 = X3Nop, class F1 = X3Nop, class F2 = X3Nop>
+__device__ __forceinline__ void x3_accop(f32x16& acc0, f32x16& acc1, const bf16x8 (&z0)[3], const bf16x8 (&z1)[3], const X3Lane& lb,
+                                         F0&& f0 = F0(), F1&& f1 = F1(), F2&& f2 = F2()) {
+    bf16x4 l0[3], h0[3], l1[3], h1[3];
+    X3_TRFRAG(l0, h0, lb, TILE_OFF, 0, 0);
+    X3_TRFRAG(l1, h1, lb, TILE_OFF, 0, 1);
+    X3_WAIT6(6, l0, h0);
+    { X3_JOIN(t, l0, h0); if (ZA) { X3_MFMA6(acc0, z0, t); } else { X3_MFMA6(acc0, t, z0); } }
+    f0();
+    X3_TRFRAG(l0, h0, lb, TILE_OFF, 1, 0);
+    X3_WAIT6(6, l1, h1);
+    { X3_JOIN(t, l1, h1); if (ZA) { X3_MFMA6(acc1, z0, t); } else { X3_MFMA6(acc1, t, z0); } }
+    f1();
+    X3_TRFRAG(l1, h1, lb, TILE_OFF, 1, 1);
+    X3_WAIT6(6, l0, h0);
+    { X3_JOIN(t, l0, h0); if (ZA) { X3_MFMA6(acc0, z1, t); } else { X3_MFMA6(acc0, t, z1); } }
+    f2();
+    X3_WAIT6(0, l1, h1);
+    { X3_JOIN(t, l1, h1); if (ZA) { X3_MFMA6(acc1, z1, t); } else { X3_MFMA6(acc1, t, z1); } }
 }
-// acc[krow(reg,h)][r] += sum_d tile[krow][d] * y[r][d]: tile rows = A operand, y = the lane's row held as fragments y[plane][k-step]
-template <int TILE_OFF>
-__device__ __forceinline__ void x3_rowop(f32x16& acc, const char* sm, const X3Lane& lb, const bf16x8 (&y)[3][4]) {
-    bf16x8 a[3];
-#define X3_ROWSTEP(S)                                          \
-    {                                                          \
-        x3_rowfrag<TILE_OFF, S>(a, sm, lb);                    \
-        const bf16x8 b_[3] = {y[0][S], y[1][S], y[2][S]};      \
-        X3_MFMA6(acc, a, b_);                                  \
-    }
-    X3_ROWSTEP(0) X3_ROWSTEP(1) X3_ROWSTEP(2) X3_ROWSTEP(3)
-#undef X3_ROWSTEP
-}
-// z as B operand: acc[i = tile column 32 BLK + krow][j = z-lane] += sum over z's rows
-template <int TILE_OFF, int BLK>
-__device__ __forceinline__ void x3_accop_b(f32x16& acc, const bf16x8 (&z0)[3], const bf16x8 (&z1)[3], const char* sm, const X3Lane& lb) {
-    bf16x8 a[3];
-    x3_trfrag<TILE_OFF, 0, BLK>(a, sm, lb);
-    X3_MFMA6(acc, a, z0);
-    x3_trfrag<TILE_OFF, 1, BLK>(a, sm, lb);
-    X3_MFMA6(acc, a, z1);
-}
-// z as A operand: acc[i = z-lane][j = tile column 32 BLK + r]
-template <int TILE_OFF, int BLK>
-__device__ __forceinline__ void x3_accop_a(f32x16& acc, const bf16x8 (&z0)[3], const bf16x8 (&z1)[3], const char* sm, const X3Lane& lb) {
-    bf16x8 b[3];
-    x3_trfrag<TILE_OFF, 0, BLK>(b, sm, lb);
-    X3_MFMA6(acc, z0, b);
-    x3_trfrag<TILE_OFF, 1, BLK>(b, sm, lb);
-    X3_MFMA6(acc, z1, b);
+// the same with ONE fragment set (12 registers less): a group's reads are issued behind the previous group's filler, their
+// latency is covered by the SIMD partner, not by this wave's own MFMAs (dK/dV body: 256 registers are all there is)
+template <int TILE_OFF, bool ZA, class F0 = X3Nop, class F1 = X3Nop, class F2 = X3Nop>
+__device__ __forceinline__ void x3_accop1(f32x16& acc0, f32x16& acc1, const bf16x8 (&z0)[3], const bf16x8 (&z1)[3], const X3Lane& lb,
+                                          F0&& f0 = F0(), F1&& f1 = F1(), F2&& f2 = F2()) {
+    bf16x4 l0[3], h0[3];
+    X3_TRFRAG(l0, h0, lb, TILE_OFF, 0, 0);
+    X3_WAIT6(0, l0, h0);
+    { X3_JOIN(t, l0, h0); if (ZA) { X3_MFMA6(acc0, z0, t); } else { X3_MFMA6(acc0, t, z0); } }
+    X3_TRFRAG(l0, h0, lb, TILE_OFF, 0, 1);
+    f0();
+    X3_WAIT6(0, l0, h0);
+    { X3_JOIN(t, l0, h0); if (ZA) { X3_MFMA6(acc1, z0, t); } else { X3_MFMA6(acc1, t, z0); } }
+    X3_TRFRAG(l0, h0, lb, TILE_OFF, 1, 0);
+    f1();
+    X3_WAIT6(0, l0, h0);
+    { X3_JOIN(t, l0, h0); if (ZA) { X3_MFMA6(acc0, z1, t); } else { X3_MFMA6(acc0, t, z1); } }
+    X3_TRFRAG(l0, h0, lb, TILE_OFF, 1, 1);
+    f2();
+    X3_WAIT6(0, l0, h0);
+    { X3_JOIN(t, l0, h0); if (ZA) { X3_MFMA6(acc1, z1, t); } else { X3_MFMA6(acc1, t, z1); } }
 }
 // the lane's row (row0 + r, clamped) of an operand's planes as fragments y[plane][k-step]
 __device__ __forceinline__ void x3_rows_from_global(bf16x8 (&y)[3][4], const bf16_t* __restrict__ base, int64_t plane, int D, int row0,
@@ -265,24 +371,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
     x3_rows_from_global(qf, qp + pbase, g.plane, g.D, q0, g.T, r, h);
     float m = -INFINITY, l = 0.f;
     f32x16 o0 = {0}, o1 = {0};
-    const X3Lane lb = x3_lane(lane);
+    const X3Lane lb = x3_lane(lane, smem);
     const int doff = x3_dma_off(g.D, wave, lane);
     const float c2 = g.scale * ACR_LOG2E;
     float* sblk = sres + x3_block(g.H, NB, b, hd, min(q0 >> 5, NB - 1), 0) + lane * 4;
+    X3L_DECL;
     auto step = [&](int k0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int KOFF = SLOT * X3_SLOT_B, VOFF = KOFF + X3_TILE_B;
-        acr_dma_barrier();                                 // slot SLOT has landed; the other slot is free
-        if (k0 + 64 <= g.T) {                              // next tile fully inside: precomputed lane offset, uniform base
-            x3_dma_tile_i(smem + (SLOT ^ 1) * X3_SLOT_B, kb + (int64_t)(k0 + 32) * g.D, g.plane, doff, wave);
-            x3_dma_tile_i(smem + (SLOT ^ 1) * X3_SLOT_B + X3_TILE_B, vb + (int64_t)(k0 + 32) * g.D, g.plane, doff, wave);
-        } else if (k0 + 32 < g.T) {                        // partial last tile: clamped rows
-            x3_dma_tile(smem + (SLOT ^ 1) * X3_SLOT_B, kb, g.plane, g.D, k0 + 32, g.T, wave, lane);
-            x3_dma_tile(smem + (SLOT ^ 1) * X3_SLOT_B + X3_TILE_B, vb, g.plane, g.D, k0 + 32, g.T, wave, lane);
+        X3L_MARK();
+        x3_barrier((k0 > 0 && live) ? 4 : 0);              // slot SLOT has landed (the previous step's 4 score stores may be in flight); the other slot is free
+        X3L_ADD(0);
+        // the next tile's DMA (K planes, then V planes) is issued between the MFMA groups of this tile's first product
+        auto dma_next = [&](const bf16_t* base, int toff) {
+            if (k0 + 64 <= g.T) x3_dma_tile_i(smem + (SLOT ^ 1) * X3_SLOT_B + toff, base + (int64_t)(k0 + 32) * g.D, g.plane, doff, wave);
+            else if (k0 + 32 < g.T) x3_dma_tile(smem + (SLOT ^ 1) * X3_SLOT_B + toff, base, g.plane, g.D, k0 + 32, g.T, wave, lane);
+            X3_FENCE();
+        };
+        if (!live) {                                       // waves past the end only help with the DMA
+            dma_next(kb, 0);
+            dma_next(vb, X3_TILE_B);
+            return;
         }
-        if (!live) return;
+        X3L_ADD(1);
         f32x16 s = {0};
-        x3_rowop<KOFF>(s, smem, lb, qf);                   // s[reg] = q.k of key k0 + krow, query q0 + r
+        x3_rowop<KOFF>(s, lb, qf, [&] { dma_next(kb, 0); }, [&] { dma_next(vb, X3_TILE_B); });      // s[reg] = q.k of key k0 + krow, query q0 + r
+        X3L_USE(s[15]);
+        X3L_ADD(2);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) s[reg] *= c2;   // scaled base-2 logits
         if (k0 + 32 > g.T) {                               // only the last key tile has keys beyond T (uniform branch)
@@ -291,11 +406,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
                 if (k0 + acr_krow(reg, h) >= g.T) s[reg] = -INFINITY;
         }
         float* sp = sblk + (int64_t)(k0 >> 5) * X3_SB_FLOATS;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f32x4 t = {s[4 * gq], s[4 * gq + 1], s[4 * gq + 2], s[4 * gq + 3]};
-            X3_STORE_NT(sp + gq * 256, t);
-        }
+        const f32x4 st0 = {s[0], s[1], s[2], s[3]}, st1 = {s[4], s[5], s[6], s[7]}, st2 = {s[8], s[9], s[10], s[11]},
+                    st3 = {s[12], s[13], s[14], s[15]};                     // stored between the MFMA groups of the second product
         float mx = s[0];
 #pragma unroll
         for (int reg = 1; reg < 16; ++reg) mx = fmaxf(mx, s[reg]);
@@ -315,14 +427,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
         l += rs;
         bf16x8 p0[3], p1[3];
         x3_split_acc<0>(p, p0);
-        x3_split_acc<1>(p, p1);
-        x3_accop_b<VOFF, 0>(o0, p0, p1, smem, lb);         // o[reg] = O^T[d = 32*blk + krow][query = r]
-        x3_accop_b<VOFF, 1>(o1, p0, p1, smem, lb);
+        X3L_USE(p0[2][7]);
+        X3L_ADD(3);
+        x3_accop<VOFF, false>(o0, o1, p0, p1, lb,           // o[reg] = O^T[d = 32*blk + krow][query = r]
+                              [&] { x3_split_acc<1>(p, p1); },
+                              [&] { X3_STORE_NT(sp, st0); X3_STORE_NT(sp + 256, st1); },
+                              [&] { X3_STORE_NT(sp + 512, st2); X3_STORE_NT(sp + 768, st3); });
+        X3L_USE(o0[15]); X3L_USE(o1[15]);
+        X3L_ADD(4);
     };
     for (int k0 = 0; k0 < g.T; k0 += 64) {
         step(k0, std::integral_constant<int, 0>{});
         if (k0 + 32 < g.T) step(k0 + 32, std::integral_constant<int, 1>{});
     }
+    X3L_OUT(3, (g.T + 31) >> 5);
     if (live && q0 + r < g.T) {
         const float inv = 1.f / l;
         float* ob = o + (int64_t)b * g.osb + (int64_t)(q0 + r) * g.ost + (int64_t)hd * g.osh;
@@ -338,16 +456,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// dQ: workgroup = (b, h, 128 queries); the dO planes of the wave's 32 queries in registers; K / V tile planes stream through the
-// ring; the wave's score block and G rows for the NEXT step are in flight (registers) while this step's MFMAs run.
-//   dP^T = V dO^T (24 MFMAs)   dS^T = exp2(S - lse2) (dP^T + G/H - delta)   dQ += dS K (24 MFMAs)
+// Backward: EIGHT-wave workgroups (512 threads, one per CU, two waves per SIMD).  Measured on the first, four-wave version
+// (scripts/lab/attn_x3_phases.py, profiles/r04_x3_phases.txt): a 6-term product needs only 768 matrix-pipe cycles per 32 x 32 x 64
+// block, so what a wave pays per step is its vector-memory INSTRUCTIONS -- an LDS-DMA piece costs 150-240 cycles to issue under
+// load, a dK/dV step issued 28 of them (3.3k cycles), and its 256 registers spilled (every scratch reload waits for all of them).
+// With eight waves sharing each tile a wave issues 3 tile pieces per step instead of 6, and G travels through a private LDS tile
+// (4 DMA pieces, no registers) instead of 2 x 16 registers filled by 16 scalar loads.
+//   wave w: tile DMA of operand w >> 2 (dkdv: Q | dO, dq: K | V), rows 8 (w & 3) .. + 7 of its three planes.
 // ---------------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void attn_dq_x3_body(char* smem, int bid, int nblk, const X3Geom& g, const bf16_t* __restrict__ kp,
-                                                const bf16_t* __restrict__ vp, const bf16_t* __restrict__ dop,
-                                                const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                const float* __restrict__ sres, const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st,
-                                                float* __restrict__ dq) {
-    const int NB = (g.T + 31) >> 5, nqt = (NB + 3) >> 2;
+#define X3_BW 8                            // waves per backward workgroup
+
+// dQ: workgroup = (b, h, 256 queries); the dO planes of the wave's 32 queries in registers; K / V tile planes stream through the
+// ring; every wave streams ITS score blocks (its q-block x key block j, as stored: query on the lane) into a private two-slot
+// LDS ring two steps ahead and ITS 32 x 32 block of G into a private single-slot tile one step ahead -- all by LDS-DMA (register
+// prefetch rings become loop-carried copies that hipcc waits for right after issuing the loads).
+//   dP^T = V dO^T (24 MFMAs)   dS^T = exp2(S - lse2) (dP^T + G/H - delta)   dQ += dS K (24 MFMAs)
+__device__ __forceinline__ void attn_dq_x3_body(char* smem, float* ssm, float* gsm, int bid, int nblk, const X3Geom& g,
+                                                const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
+                                                const bf16_t* __restrict__ dop, const float* __restrict__ lse2,
+                                                const float* __restrict__ delta, const float* __restrict__ sres,
+                                                const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st, float* __restrict__ dq) {
+    const int NB = (g.T + 31) >> 5, nqt = (NB + X3_BW - 1) / X3_BW;
     int id = acr_xcd_remap(bid, nblk);
     const int qt = id % nqt; id /= nqt;
     const int hd = id % g.H;
@@ -355,74 +484,121 @@ __device__ __forceinline__ void attn_dq_x3_body(char* smem, int bid, int nblk, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int q0 = qt * 128 + wave * 32;
+    const int q0 = (qt * X3_BW + wave) * 32;
     const bool live = q0 < g.T;
     const int64_t pbase = (int64_t)b * g.T * g.D + (int64_t)hd * 64;
-    const bf16_t* kb = kp + pbase;
-    const bf16_t* vb = vp + pbase;
-    x3_dma_tile(smem, kb, g.plane, g.D, 0, g.T, wave, lane);
-    x3_dma_tile(smem + X3_TILE_B, vb, g.plane, g.D, 0, g.T, wave, lane);
+    const int op = wave >> 2, pc = wave & 3;               // this wave's share of the tile DMA: operand (K | V), 8-row piece
+    const bf16_t* tb = (op ? vp : kp) + pbase;
+    char* tdst = smem + op * X3_TILE_B;
+    // score blocks of this wave: (qb = q0 / 32, kb = step), copied as stored (lane l of piece gq owns floats gq*256 + 4 l ..)
+    const float* srow = sres + x3_block(g.H, NB, b, hd, min(q0 >> 5, NB - 1), 0) + lane * 4;
+    float* sw = ssm + wave * 2 * X3_SB_FLOATS;
+    auto dma_scores = [&](int kblk, int slot) {
+        const float* src = srow + (int64_t)kblk * X3_SB_FLOATS;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            __builtin_amdgcn_global_load_lds((x3_glb_vp)(src + gq * 256), (x3_lds_vp)(sw + slot * X3_SB_FLOATS + gq * 256), 16, 0, 0);
+    };
+    // G block of the step: rows = this wave's 32 queries (fixed), 128 bytes = the step's 32 keys; 16-byte chunk c of row q is
+    // stored in slot c ^ ((q >> 1) & 7) (the lane's row reads are then bank-conflict free); columns clamped into the row
+    const float* gb0 = gm ? gm + (int64_t)b * gm_sb : nullptr;          // uniform
+    float* gw = gsm + wave * X3_SB_FLOATS;
+    const float* grow[4];
+    int gchunk[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = 8 * p + (lane >> 3);
+        grow[p] = gb0 ? gb0 + (int64_t)min(q0 + row, g.T - 1) * gm_st : nullptr;
+        gchunk[p] = 4 * ((lane & 7) ^ ((row >> 1) & 7));
+    }
+    auto dma_g = [&](int k0) {
+        if (gb0 == nullptr) return;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_global_load_lds((x3_glb_vp)(grow[p] + min(k0 + gchunk[p], (int)gm_st - 4)), (x3_lds_vp)(gw + p * 256), 16, 0, 0);
+    };
+    x3_dma_tile(tdst, tb, g.plane, g.D, 0, g.T, pc, lane);
+    if (live) {
+        dma_g(0);
+        dma_scores(0, 0);
+        if (32 < g.T) dma_scores(1, 1);
+    }
     bf16x8 dof[3][4];
     x3_rows_from_global(dof, dop + pbase, g.plane, g.D, q0, g.T, r, h);
     const bool qok = q0 + r < g.T;
     const float l2q = qok ? lse2[((int64_t)b * g.H + hd) * g.T + q0 + r] : INFINITY;    // queries beyond T: p = exp2(-inf) = 0
     const float dl = qok ? delta[((int64_t)b * g.H + hd) * g.T + q0 + r] : 0.f;
-    const float invH = 1.f / (float)g.H;
-    const float* grow = gm ? gm + (int64_t)b * gm_sb + (int64_t)min(q0 + r, g.T - 1) * gm_st : nullptr;
-    const float* sblk = sres + x3_block(g.H, NB, b, hd, min(q0 >> 5, NB - 1), 0) + lane * 4;
+    const float invH = gb0 ? 1.f / (float)g.H : 0.f;
     f32x16 dq0 = {0}, dq1 = {0};
-    const X3Lane lb = x3_lane(lane);
-    const int doff = x3_dma_off(g.D, wave, lane);
-    f32x4 sbuf[2][4], gbuf[2][4];                          // [ring slot][register quad]
-    auto load_sg = [&](int k0, f32x4 (&s4)[4], f32x4 (&g4)[4]) {
-        const float* sp = sblk + (int64_t)(k0 >> 5) * X3_SB_FLOATS;
+    const X3Lane lb = x3_lane(lane, smem);
+    const int doff = x3_dma_off(g.D, pc, lane);
+    const uint32_t saddr = x3_lds_addr(sw) + lane * 16;                                 // + slot * 4096 + gq * 1024
+    uint32_t gaddr[4];                                                                  // quad gq = keys 8 gq + 4 h .. + 3 of row r
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) s4[gq] = X3_LOAD_NT(sp + gq * 256);
-        if (grow == nullptr) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) g4[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else if (k0 + 32 <= g.T) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) g4[gq] = *reinterpret_cast<const f32x4*>(grow + k0 + 8 * gq + 4 * h);
-        } else {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g4[gq][e] = grow[min(k0 + 8 * gq + 4 * h + e, g.T - 1)];
-        }
-    };
-    if (live) load_sg(0, sbuf[0], gbuf[0]);
+    for (int gq = 0; gq < 4; ++gq) gaddr[gq] = x3_lds_addr(gw) + r * 128 + (((2 * gq + h) ^ ((r >> 1) & 7)) << 4);
+    X3L_DECL;
     auto step = [&](int k0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int KOFF = SLOT * X3_SLOT_B, VOFF = KOFF + X3_TILE_B;
-        acr_dma_barrier();
-        if (k0 + 64 <= g.T) {
-            x3_dma_tile_i(smem + (SLOT ^ 1) * X3_SLOT_B, kb + (int64_t)(k0 + 32) * g.D, g.plane, doff, wave);
-            x3_dma_tile_i(smem + (SLOT ^ 1) * X3_SLOT_B + X3_TILE_B, vb + (int64_t)(k0 + 32) * g.D, g.plane, doff, wave);
-        } else if (k0 + 32 < g.T) {
-            x3_dma_tile(smem + (SLOT ^ 1) * X3_SLOT_B, kb, g.plane, g.D, k0 + 32, g.T, wave, lane);
-            x3_dma_tile(smem + (SLOT ^ 1) * X3_SLOT_B + X3_TILE_B, vb, g.plane, g.D, k0 + 32, g.T, wave, lane);
-        }
-        if (!live) return;
-        if (k0 + 32 < g.T) load_sg(k0 + 32, sbuf[SLOT ^ 1], gbuf[SLOT ^ 1]);
+        X3L_MARK();
+        // Issue order of a live wave's step (younger to the right):  tile(t+1) [3] | G(t+1) [4]  scores(t+2) [4], all LDS-DMA.
+        // At this barrier tile(t) must have landed; behind it the previous step issued G(t) and scores(t+1).
+        x3_barrier((k0 > 0 && live) ? (gb0 ? 4 : 0) + (k0 + 32 < g.T ? 4 : 0) : 0);
+        X3L_ADD(0);
+        auto dma_next = [&] {                              // this wave's three pieces of tile(t+1)
+            if (k0 + 64 <= g.T) x3_dma_tile_i(tdst + (SLOT ^ 1) * X3_SLOT_B, tb + (int64_t)(k0 + 32) * g.D, g.plane, doff, pc);
+            else if (k0 + 32 < g.T) x3_dma_tile(tdst + (SLOT ^ 1) * X3_SLOT_B, tb, g.plane, g.D, k0 + 32, g.T, pc, lane);
+            X3_FENCE();
+        };
+        if (!live) { dma_next(); return; }
+        X3L_ADD(1);
         f32x16 dp = {0};
-        x3_rowop<VOFF>(dp, smem, lb, dof);                 // dP^T[key = krow][query = r]
+        x3_rowop<VOFF>(dp, lb, dof, dma_next);             // dP^T[key = krow][query = r]; tile(t+1) issued after the first MFMA group
+        X3L_USE(dp[15]);
+        X3L_ADD(2);
+        // G(t) (issued in the previous step) must have landed in this wave's tile: behind it are scores(t+1) [4] and this step's
+        // tile(t+1) [3].  The score block (t) is older than it.
+        if (k0 > 0) x3_wait_vm(k0 + 32 < g.T ? 7 : 0);
+        f32x4 s4[4], g4[4];
+        X3_RD128(s4[0], saddr, SLOT * 4096); X3_RD128(s4[1], saddr, SLOT * 4096 + 1024);
+        X3_RD128(s4[2], saddr, SLOT * 4096 + 2048); X3_RD128(s4[3], saddr, SLOT * 4096 + 3072);
+        if (gb0 != nullptr) {
+            X3_RD128(g4[0], gaddr[0], 0); X3_RD128(g4[1], gaddr[1], 0); X3_RD128(g4[2], gaddr[2], 0); X3_RD128(g4[3], gaddr[3], 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g4[0]), "+v"(g4[1]), "+v"(g4[2]), "+v"(g4[3]));
+            if (k0 + 32 > g.T) {                           // keys beyond T: their columns hold whatever the row pitch holds
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k0 + 8 * gq + 4 * h + e >= g.T) g4[gq][e] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) g4[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s4[0]), "+v"(s4[1]), "+v"(s4[2]), "+v"(s4[3]));
         f32x16 ds;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float gv = gbuf[SLOT][reg >> 2][reg & 3] * invH;
-            ds[reg] = __builtin_amdgcn_exp2f(sbuf[SLOT][reg >> 2][reg & 3] - l2q) * (dp[reg] + gv - dl);
-        }
+        for (int reg = 0; reg < 16; ++reg)
+            ds[reg] = __builtin_amdgcn_exp2f(s4[reg >> 2][reg & 3] - l2q) * (dp[reg] + g4[reg >> 2][reg & 3] * invH - dl);
+        // the private tiles have been read: G is refilled for the next step and the score slot for the step AFTER next -- between
+        // the MFMA groups of the second product, like the second half of the split
         bf16x8 z0[3], z1[3];
         x3_split_acc<0>(ds, z0);
-        x3_split_acc<1>(ds, z1);
-        x3_accop_a<KOFF, 0>(dq0, z0, z1, smem, lb);        // dQ[query = krow][d = 32*blk + r]
-        x3_accop_a<KOFF, 1>(dq1, z0, z1, smem, lb);
+        X3L_USE(z0[2][7]);
+        X3L_ADD(3);
+        x3_accop<KOFF, true>(dq0, dq1, z0, z1, lb,          // dQ[query = krow][d = 32*blk + r]
+                             [&] { x3_split_acc<1>(ds, z1); },
+                             [&] { if (k0 + 32 < g.T) dma_g(k0 + 32); X3_FENCE(); },
+                             [&] { if (k0 + 64 < g.T) dma_scores((k0 >> 5) + 2, SLOT); X3_FENCE(); });
+        X3L_USE(dq0[15]); X3L_USE(dq1[15]);
+        X3L_ADD(4);
     };
     for (int k0 = 0; k0 < g.T; k0 += 64) {
         step(k0, std::integral_constant<int, 0>{});
         if (k0 + 32 < g.T) step(k0 + 32, std::integral_constant<int, 1>{});
     }
+    X3L_OUT(1, (g.T + 31) >> 5);
     if (!live) return;
     const int64_t base = (int64_t)b * g.sb + (int64_t)hd * g.sh;
 #pragma unroll
@@ -436,19 +612,19 @@ __device__ __forceinline__ void attn_dq_x3_body(char* smem, int bid, int nblk, c
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// dK, dV: workgroup = (b, h, 128 keys); the V planes of the wave's 32 keys in registers; Q / dO tile planes stream through the
+// dK, dV: workgroup = (b, h, 256 keys); the V planes of the wave's 32 keys in registers; Q / dO tile planes stream through the
 // shared ring; every wave also streams ITS score blocks (q-block j x its key block) by LDS-DMA into a private two-slot ring and
-// reads them transposed (key on the lane), exactly as attn_dkdv_sres_body does; lse2 / delta of the step's 32 queries sit one
-// per lane and reach the accumulator rows by ds_bpermute (no LDS bytes: the two workgroups of a CU use all 160 KiB).
+// reads them transposed (key on the lane), exactly as attn_dkdv_sres_body does, and ITS 32 x 32 block of G into a private
+// single-slot LDS tile (refilled right after the step's reads; natural [query][key] rows: the lane's reads are 32 consecutive
+// floats); lse2 / delta of the step's 32 queries sit one per lane and reach the accumulator rows by ds_bpermute.
 //   dP = dO V^T (24 MFMAs)   P = exp2(S - lse2)   dS = P (dP + G/H - delta)   dV += P^T dO (24)   dK += dS^T Q (24)
-// ---------------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, int bid, int nblk, const X3Geom& g, const bf16_t* __restrict__ qp,
-                                                  const bf16_t* __restrict__ vp, const bf16_t* __restrict__ dop,
-                                                  const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                  const float* __restrict__ sres, const float* __restrict__ gm, int64_t gm_sb,
-                                                  int64_t gm_st, float* __restrict__ dk, float* __restrict__ dv) {
-    const int NB = (g.T + 31) >> 5, nkt = (NB + 3) >> 2;
+__device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, float* gsm, float* rcm, int bid, int nblk, const X3Geom& g,
+                                                  const bf16_t* __restrict__ qp, const bf16_t* __restrict__ vp,
+                                                  const bf16_t* __restrict__ dop, const float* __restrict__ lse2,
+                                                  const float* __restrict__ delta, const float* __restrict__ sres,
+                                                  const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st, float* __restrict__ dk,
+                                                  float* __restrict__ dv) {
+    const int NB = (g.T + 31) >> 5, nkt = (NB + X3_BW - 1) / X3_BW;
     int id = acr_xcd_remap(bid, nblk);
     const int ktile = id % nkt; id /= nkt;
     const int hd = id % g.H;
@@ -456,11 +632,12 @@ __device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, int bi
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int key0 = ktile * 128 + wave * 32;
+    const int key0 = (ktile * X3_BW + wave) * 32;
     const bool live = key0 < g.T;
     const int64_t pbase = (int64_t)b * g.T * g.D + (int64_t)hd * 64;
-    const bf16_t* qb = qp + pbase;
-    const bf16_t* dob = dop + pbase;
+    const int op = wave >> 2, pc = wave & 3;               // this wave's share of the tile DMA: operand (Q | dO), 8-row piece
+    const bf16_t* tb = (op ? dop : qp) + pbase;
+    char* tdst = smem + op * X3_TILE_B;
     const float* lrow = lse2 + ((int64_t)b * g.H + hd) * g.T;
     const float* drow = delta + ((int64_t)b * g.H + hd) * g.T;
     // score blocks of this wave: (qb = step, kb = key0 / 32); lane c of DMA piece gq fetches global chunk c ^ (2 gq + (c >> 5))
@@ -476,74 +653,95 @@ __device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, int bi
         for (int gq = 0; gq < 4; ++gq)
             __builtin_amdgcn_global_load_lds((x3_glb_vp)(src + soff[gq]), (x3_lds_vp)(sw + slot * X3_SB_FLOATS + gq * 256), 16, 0, 0);
     };
-    x3_dma_tile(smem, qb, g.plane, g.D, 0, g.T, wave, lane);
-    x3_dma_tile(smem + X3_TILE_B, dob, g.plane, g.D, 0, g.T, wave, lane);
-    if (live) dma_scores(0, 0);
+    // G block of the step: rows = the 32 queries, 128 bytes = this wave's 32 keys.  Columns are clamped into the row (the last
+    // key block reaches beyond T: those lanes' P is exactly 0 and whatever they compute never leaves their own accumulator row).
+    const float* gb0 = gm ? gm + (int64_t)b * gm_sb : nullptr;          // uniform
+    float* gw = gsm + wave * X3_SB_FLOATS;
+    const int gcol = min(key0 + 4 * (lane & 7), (int)gm_st - 4);
+    auto dma_g = [&](int q0) {
+        if (gb0 == nullptr) return;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float* src = gb0 + (int64_t)min(q0 + 8 * p + (lane >> 3), g.T - 1) * gm_st + gcol;
+            __builtin_amdgcn_global_load_lds((x3_glb_vp)src, (x3_lds_vp)(gw + p * 256), 16, 0, 0);
+        }
+    };
+    // lse2 (lanes 0-31) and delta (lanes 32-63) of the step's 32 queries: one 256-byte DMA into a private LDS row
+    float* rcw = rcm + wave * 64;
+    auto dma_rc = [&](int q0) {
+        const float* src = (lane < 32 ? lrow : drow) + min(q0 + (lane & 31), g.T - 1);
+        __builtin_amdgcn_global_load_lds((x3_glb_vp)src, (x3_lds_vp)rcw, 4, 0, 0);
+    };
+    x3_dma_tile(tdst, tb, g.plane, g.D, 0, g.T, pc, lane);
+    if (live) {
+        dma_rc(0);
+        dma_g(0);
+        dma_scores(0, 0);
+        if (32 < g.T) dma_scores(1, 1);
+    }
     bf16x8 vf[3][4];
     x3_rows_from_global(vf, vp + pbase, g.plane, g.D, key0, g.T, r, h);
-    const int key = key0 + r;
-    const float invH = 1.f / (float)g.H;
-    const float* gb0 = gm ? gm + (int64_t)b * gm_sb : nullptr;          // uniform
-    const int glane = min(key, g.T - 1) + 4 * h * (int)gm_st;            // lane part of a G address (krow = c_reg + 4h)
-    const int gcl = min(key, g.T - 1);
+    const float invH = gb0 ? 1.f / (float)g.H : 0.f;
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
-    const X3Lane lb = x3_lane(lane);
-    const int doff = x3_dma_off(g.D, wave, lane);
-    // transposed score reads: lane (kappa = r, h): byte address = tb[reg & 3] + slot*4096 + 128*(reg >> 2)
-    int tb[4];
+    const X3Lane lb = x3_lane(lane, smem);
+    const int doff = x3_dma_off(g.D, pc, lane);
+    // transposed score reads: lane (kappa = r, h): LDS byte address = tb4[reg & 3] + slot*4096 + 128*(reg >> 2)
+    uint32_t tb4[4];
     {
         const int gk = r >> 3, hk = (r >> 2) & 1, ek = r & 3, mm = 2 * gk + hk;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tb[j] = ((wave * 2 * X3_SB_FLOATS) + gk * 256 + 128 * hk + ek + 4 * ((j + 4 * h) ^ mm)) * 4;
+        for (int j = 0; j < 4; ++j)
+            tb4[j] = x3_lds_addr(ssm) + ((wave * 2 * X3_SB_FLOATS) + gk * 256 + 128 * hk + ek + 4 * ((j + 4 * h) ^ mm)) * 4;
     }
-    const char* ssb = reinterpret_cast<const char*>(ssm);
-    float gbuf[2][16];                                      // [ring slot][register]: raw G[b][q0 + krow][key]
-    float lbuf[2], dbuf[2];                                 // [ring slot]: lse2 / delta of query q0 + (lane & 31)
-    auto load_g = [&](int q0, float (&gv)[16]) {
-        if (gb0 == nullptr) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) gv[reg] = 0.f;
-        } else if (q0 + 32 <= g.T) {                       // uniform row pointer + lane offset (saddr form loads)
-            const float* gq0 = gb0 + (int64_t)q0 * gm_st;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int c_reg = (reg & 3) + 8 * (reg >> 2);
-                gv[reg] = (gq0 + (int64_t)c_reg * gm_st)[glane];
-            }
-        } else {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) gv[reg] = gb0[(int64_t)min(q0 + acr_krow(reg, h), g.T - 1) * gm_st + gcl];
-        }
-    };
-    auto load_ld = [&](int q0, float& lv, float& dv_) {
-        const int qi = min(q0 + r, g.T - 1);
-        lv = lrow[qi];
-        dv_ = drow[qi];
-    };
-    if (live) { load_g(0, gbuf[0]); load_ld(0, lbuf[0], dbuf[0]); }
+    const uint32_t gaddr = x3_lds_addr(gsm) + (wave * X3_SB_FLOATS + 4 * h * 32 + r) * 4;      // + 128 * c_reg per register
+    const uint32_t rcaddr = x3_lds_addr(rcw) + 16 * h;                                          // l4[gq] at + 32 gq, d4[gq] at + 128 + 32 gq
+    X3L_DECL;
     auto step = [&](int q0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int QOFF = SLOT * X3_SLOT_B, DOOFF = QOFF + X3_TILE_B;
-        acr_dma_barrier();
-        if (q0 + 32 < g.T) {
-            if (q0 + 64 <= g.T) {                          // next tile fully inside: precomputed lane offset, uniform base
-                x3_dma_tile_i(smem + (SLOT ^ 1) * X3_SLOT_B, qb + (int64_t)(q0 + 32) * g.D, g.plane, doff, wave);
-                x3_dma_tile_i(smem + (SLOT ^ 1) * X3_SLOT_B + X3_TILE_B, dob + (int64_t)(q0 + 32) * g.D, g.plane, doff, wave);
-            } else {
-                x3_dma_tile(smem + (SLOT ^ 1) * X3_SLOT_B, qb, g.plane, g.D, q0 + 32, g.T, wave, lane);
-                x3_dma_tile(smem + (SLOT ^ 1) * X3_SLOT_B + X3_TILE_B, dob, g.plane, g.D, q0 + 32, g.T, wave, lane);
-            }
-            if (live) dma_scores((q0 >> 5) + 1, SLOT ^ 1);
-        }
-        if (!live) return;
-        // G, lse2 and delta of the NEXT query block go in flight now and are consumed a whole step later
-        if (q0 + 32 < g.T) { load_g(q0 + 32, gbuf[SLOT ^ 1]); load_ld(q0 + 32, lbuf[SLOT ^ 1], dbuf[SLOT ^ 1]); }
+        X3L_MARK();
+        // Issue order of a live wave's step (younger to the right):  tile(t+1) [3] | lse2-delta(t+1) [1]  G(t+1) [4]  scores(t+2) [4],
+        // all of them LDS-DMA.  At this barrier tile(t) must have landed; behind it the previous step issued lse2-delta(t), G(t)
+        // and scores(t+1).
+        x3_barrier((q0 > 0 && live) ? 1 + (gb0 ? 4 : 0) + (q0 + 32 < g.T ? 4 : 0) : 0);
+        X3L_ADD(0);
+        auto dma_next = [&] {                              // this wave's three pieces of tile(t+1)
+            if (q0 + 64 <= g.T) x3_dma_tile_i(tdst + (SLOT ^ 1) * X3_SLOT_B, tb + (int64_t)(q0 + 32) * g.D, g.plane, doff, pc);
+            else if (q0 + 32 < g.T) x3_dma_tile(tdst + (SLOT ^ 1) * X3_SLOT_B, tb, g.plane, g.D, q0 + 32, g.T, pc, lane);
+            X3_FENCE();
+        };
+        if (!live) { dma_next(); return; }
+        X3L_ADD(1);
         f32x16 dp = {0};
-        x3_rowop<DOOFF>(dp, smem, lb, vf);                 // dP[query = krow][key = r]
-        f32x16 s;
+        x3_rowop<DOOFF>(dp, lb, vf, dma_next);             // dP[query = krow][key = r]; tile(t+1) issued after the first MFMA group
+        X3L_USE(dp[15]);
+        X3L_ADD(2);
+        // lse2-delta(t) and G(t) (issued in the previous step) must have landed in this wave's private tiles: behind them are
+        // scores(t+1) [4] and this step's tile(t+1) [3].  The score block (t) is older than both: it has landed with them.
+        if (q0 > 0) x3_wait_vm(q0 + 32 < g.T ? 7 : 0);
+        // this wave's private tiles, read by inline asm (see X3_RD128): score block transposed, G block, lse2 | delta
+        float s[16], gv[16];
+        f32x4 l4[4], d4[4];
+#define X3_RDS(REG) X3_RD32(s[REG], tb4[(REG) & 3], SLOT * X3_SB_FLOATS * 4 + 128 * ((REG) >> 2))
+#define X3_RDG(REG) X3_RD32(gv[REG], gaddr, 128 * (((REG) & 3) + 8 * ((REG) >> 2)))
+        X3_RDS(0); X3_RDS(1); X3_RDS(2); X3_RDS(3); X3_RDS(4); X3_RDS(5); X3_RDS(6); X3_RDS(7);
+        X3_RDS(8); X3_RDS(9); X3_RDS(10); X3_RDS(11); X3_RDS(12); X3_RDS(13); X3_RDS(14); X3_RDS(15);
+        X3_RD128(l4[0], rcaddr, 0); X3_RD128(l4[1], rcaddr, 32); X3_RD128(l4[2], rcaddr, 64); X3_RD128(l4[3], rcaddr, 96);
+        X3_RD128(d4[0], rcaddr, 128); X3_RD128(d4[1], rcaddr, 160); X3_RD128(d4[2], rcaddr, 192); X3_RD128(d4[3], rcaddr, 224);
+        if (gb0 != nullptr) {
+            X3_RDG(0); X3_RDG(1); X3_RDG(2); X3_RDG(3); X3_RDG(4); X3_RDG(5); X3_RDG(6); X3_RDG(7);
+            X3_RDG(8); X3_RDG(9); X3_RDG(10); X3_RDG(11); X3_RDG(12); X3_RDG(13); X3_RDG(14); X3_RDG(15);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]), "+v"(gv[4]), "+v"(gv[5]), "+v"(gv[6]),
+                         "+v"(gv[7]), "+v"(gv[8]), "+v"(gv[9]), "+v"(gv[10]), "+v"(gv[11]), "+v"(gv[12]), "+v"(gv[13]), "+v"(gv[14]), "+v"(gv[15]));
+        } else {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            s[reg] = *reinterpret_cast<const float*>(ssb + tb[reg & 3] + (SLOT * X3_SB_FLOATS * 4 + 128 * (reg >> 2)));
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = 0.f;
+        }
+#undef X3_RDS
+#undef X3_RDG
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]),
+                     "+v"(s[8]), "+v"(s[9]), "+v"(s[10]), "+v"(s[11]), "+v"(s[12]), "+v"(s[13]), "+v"(s[14]), "+v"(s[15]), "+v"(l4[0]),
+                     "+v"(l4[1]), "+v"(l4[2]), "+v"(l4[3]), "+v"(d4[0]), "+v"(d4[1]), "+v"(d4[2]), "+v"(d4[3]));
         if (q0 + 32 > g.T) {                               // last query block: rows beyond T are junk, P = 0 there
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
@@ -551,32 +749,38 @@ __device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, int bi
         }
         f32x16 p, ds;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int src = acr_krow(reg, h);              // lane that holds this accumulator row's query
-            const float lq = __shfl(lbuf[SLOT], src), dq_ = __shfl(dbuf[SLOT], src);
-            const float pv = __builtin_amdgcn_exp2f(s[reg] - lq);
-            p[reg] = pv;
-            ds[reg] = pv * (dp[reg] + gbuf[SLOT][reg] * invH - dq_);
+        for (int gq = 0; gq < 4; ++gq) {                   // krow(4 gq + e, h) = 8 gq + 4 h + e: four consecutive queries
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int reg = 4 * gq + e;
+                const float pv = __builtin_amdgcn_exp2f(s[reg] - l4[gq][e]);
+                p[reg] = pv;
+                ds[reg] = pv * (dp[reg] + gv[reg] * invH - d4[gq][e]);
+            }
         }
-        {
-            bf16x8 z0[3], z1[3];
-            x3_split_acc<0>(p, z0);
-            x3_split_acc<1>(p, z1);
-            x3_accop_a<DOOFF, 0>(dv0, z0, z1, smem, lb);   // dV[key = krow][d = 32*blk + r]
-            x3_accop_a<DOOFF, 1>(dv1, z0, z1, smem, lb);
-        }
-        {
-            bf16x8 z0[3], z1[3];
-            x3_split_acc<0>(ds, z0);
-            x3_split_acc<1>(ds, z1);
-            x3_accop_a<QOFF, 0>(dk0, z0, z1, smem, lb);
-            x3_accop_a<QOFF, 1>(dk1, z0, z1, smem, lb);
-        }
+        X3L_USE(p[15]); X3L_USE(ds[15]);
+        // the private tiles have been read (their values are in p / ds): they are refilled between the MFMA groups below, like
+        // the splits of P's second half and of dS; the DMAs land under the rest of the step and the next step's counted waits
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every read of the private tiles has returned
+        bf16x8 z0[3], z1[3];
+        x3_split_acc<0>(p, z0);
+        X3L_ADD(3);
+        x3_accop<DOOFF, true>(dv0, dv1, z0, z1, lb,
+                              [&] { x3_split_acc<1>(p, z1); },
+                              [&] { if (q0 + 32 < g.T) dma_rc(q0 + 32); X3_FENCE(); },
+                              [&] { if (q0 + 32 < g.T) dma_g(q0 + 32); X3_FENCE(); });
+        x3_split_acc<0>(ds, z0);
+        x3_accop<QOFF, true>(dk0, dk1, z0, z1, lb,
+                             [&] { x3_split_acc<1>(ds, z1); },
+                             [&] { if (q0 + 64 < g.T) dma_scores((q0 >> 5) + 2, SLOT); X3_FENCE(); });
+        X3L_USE(dv0[15]); X3L_USE(dv1[15]); X3L_USE(dk0[15]); X3L_USE(dk1[15]);
+        X3L_ADD(4);
     };
     for (int q0 = 0; q0 < g.T; q0 += 64) {
         step(q0, std::integral_constant<int, 0>{});
         if (q0 + 32 < g.T) step(q0 + 32, std::integral_constant<int, 1>{});
     }
+    X3L_OUT(2, (g.T + 31) >> 5);
     if (!live) return;
     const int64_t base = (int64_t)b * g.sb + (int64_t)hd * g.sh;
 #pragma unroll
@@ -594,20 +798,22 @@ __device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, int bi
 }
 
 // dK/dV and dQ in ONE launch (one partly filled last round instead of two): first half of the grid dK/dV, second half dQ.
-__global__ __launch_bounds__(256, 2) void attn_bwd_x3_kernel(X3Geom g, const bf16_t* __restrict__ qp, const bf16_t* __restrict__ kp,
-                                                             const bf16_t* __restrict__ vp, const bf16_t* __restrict__ dop,
-                                                             const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                             const float* __restrict__ sres, const float* __restrict__ gm, int64_t gm_sb,
-                                                             int64_t gm_st, float* __restrict__ dq, float* __restrict__ dk,
-                                                             float* __restrict__ dv) {
+__global__ __launch_bounds__(64 * X3_BW, 2) void attn_bwd_x3_kernel(X3Geom g, const bf16_t* __restrict__ qp, const bf16_t* __restrict__ kp,
+                                                                   const bf16_t* __restrict__ vp, const bf16_t* __restrict__ dop,
+                                                                   const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                                   const float* __restrict__ sres, const float* __restrict__ gm,
+                                                                   int64_t gm_sb, int64_t gm_st, float* __restrict__ dq,
+                                                                   float* __restrict__ dk, float* __restrict__ dv) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * X3_SLOT_B];                 // [slot][Q | dO planes]  resp.  [slot][K | V planes]
-    __shared__ __attribute__((aligned(1024))) float ssm[4 * 2 * X3_SB_FLOATS];          // dK/dV: [wave][slot] score blocks
+    __shared__ __attribute__((aligned(1024))) float ssm[X3_BW * 2 * X3_SB_FLOATS];      // dK/dV: [wave][slot] score blocks
+    __shared__ __attribute__((aligned(1024))) float gsm[X3_BW * X3_SB_FLOATS];          // dK/dV: [wave] G block
+    __shared__ __attribute__((aligned(256))) float rcm[X3_BW * 64];                     // dK/dV: [wave][lse2 x 32 | delta x 32]
     const int half = (int)gridDim.x >> 1;
     const int bid = (int)blockIdx.x;
     if (bid < half)
-        attn_dkdv_x3_body(smem, ssm, bid, half, g, qp, vp, dop, lse2, delta, sres, gm, gm_sb, gm_st, dk, dv);
+        attn_dkdv_x3_body(smem, ssm, gsm, rcm, bid, half, g, qp, vp, dop, lse2, delta, sres, gm, gm_sb, gm_st, dk, dv);
     else
-        attn_dq_x3_body(smem, bid - half, half, g, kp, vp, dop, lse2, delta, sres, gm, gm_sb, gm_st, dq);
+        attn_dq_x3_body(smem, ssm, gsm, bid - half, half, g, kp, vp, dop, lse2, delta, sres, gm, gm_sb, gm_st, dq);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -659,8 +865,8 @@ void acr_attn_bwd_f32_x3(const AttnGeom& g, const float* o, const float* d_o, co
     hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((n8 + 255) / 256), 1), dim3(256), 0, st, a);
     acr_attn_delta_sres(g, scores, o, d_o, lse2, gm, gm_sb, gm_st, delta_ws, st);
     const int NB = (g.T + 31) / 32;
-    const int nmain = g.B * g.H * ((NB + 3) / 4);
-    hipLaunchKernelGGL(attn_bwd_x3_kernel, dim3(2 * nmain), dim3(256), 0, st, x, planes, planes + 3 * x.plane, planes + 6 * x.plane,
+    const int nmain = g.B * g.H * ((NB + X3_BW - 1) / X3_BW);
+    hipLaunchKernelGGL(attn_bwd_x3_kernel, dim3(2 * nmain), dim3(64 * X3_BW), 0, st, x, planes, planes + 3 * x.plane, planes + 6 * x.plane,
                        (const bf16_t*)dop, lse2, (const float*)delta_ws, scores, gm, gm_sb, gm_st, dq, dk, dv);
 }
 
