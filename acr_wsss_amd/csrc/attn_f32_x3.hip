@@ -406,8 +406,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
                 if (k0 + acr_krow(reg, h) >= g.T) s[reg] = -INFINITY;
         }
         float* sp = sblk + (int64_t)(k0 >> 5) * X3_SB_FLOATS;
-        const f32x4 st0 = {s[0], s[1], s[2], s[3]}, st1 = {s[4], s[5], s[6], s[7]}, st2 = {s[8], s[9], s[10], s[11]},
-                    st3 = {s[12], s[13], s[14], s[15]};                     // stored between the MFMA groups of the second product
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {                   // (kept out of the second product's fillers: 16 more live registers
+            const f32x4 t = {s[4 * gq], s[4 * gq + 1], s[4 * gq + 2], s[4 * gq + 3]};      //  cost the third wave per SIMD)
+            X3_STORE_NT(sp + gq * 256, t);
+        }
         float mx = s[0];
 #pragma unroll
         for (int reg = 1; reg < 16; ++reg) mx = fmaxf(mx, s[reg]);
@@ -429,10 +432,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
         x3_split_acc<0>(p, p0);
         X3L_USE(p0[2][7]);
         X3L_ADD(3);
-        x3_accop<VOFF, false>(o0, o1, p0, p1, lb,           // o[reg] = O^T[d = 32*blk + krow][query = r]
-                              [&] { x3_split_acc<1>(p, p1); },
-                              [&] { X3_STORE_NT(sp, st0); X3_STORE_NT(sp + 256, st1); },
-                              [&] { X3_STORE_NT(sp + 512, st2); X3_STORE_NT(sp + 768, st3); });
+        x3_accop<VOFF, false>(o0, o1, p0, p1, lb, [&] { x3_split_acc<1>(p, p1); });      // o[reg] = O^T[d = 32*blk + krow][query = r]
         X3L_USE(o0[15]); X3L_USE(o1[15]);
         X3L_ADD(4);
     };

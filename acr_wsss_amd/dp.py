@@ -36,8 +36,12 @@ class GradSync:
     would average already-averaged values with raw ones when the ranks disagree on who was late).
     ``strict=True`` (or ACR_DP_STRICT=1) turns any disagreement between ranks into an error instead."""
 
-    def __init__(self, params, process_group=None, bucket_mb=64, strict=None, always_reduce=False):
+    def __init__(self, params, process_group=None, bucket_mb=64, strict=None, always_reduce=False, record_timeline=False):
         import os
+        # record_timeline: a device event at prepare() (backward about to start), at every bucket launch and at finish()
+        # (backward fully issued), on the launch stream -> timeline() says when each bucket became launchable inside backward
+        self._tl = [] if (record_timeline and torch.cuda.is_available()) else None
+        self._tl_steps = []
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in params if p.requires_grad]
@@ -108,6 +112,8 @@ class GradSync:
         a bucket has arrived they are copied into the bucket with ONE multi-tensor launch and ``.grad`` is re-pointed at
         the bucket views.  Slots of parameters without a gradient are zeroed when the bucket leaves."""
         self._late = []
+        if self._tl is not None:
+            self._tl = [("start", -1, 0, self._event())]
         for b in self.buckets:
             b.pending, b.work = sum(1 for p in b.params if p not in self._unused), None
             for p in b.params:
@@ -116,9 +122,34 @@ class GradSync:
         self._next = 0
         self._armed = True
 
+    def _event(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def timeline(self):
+        """Per recorded step (record_timeline=True): backward's duration on the device and, per bucket, its size and when its
+        launch was issued relative to the END of backward (ms, negative = that long before the last gradient kernel finished;
+        synchronises).  What one GPU can say about overlap: a bucket's all-reduce can hide under whatever backward work is
+        still to come after its launch."""
+        if self._tl is None:
+            return []
+        torch.cuda.synchronize()
+        out = []
+        for tl in self._tl_steps:
+            start = next(e for k, _, _, e in tl if k == "start")
+            end = next(e for k, _, _, e in tl if k == "end")
+            out.append({"backward_ms": round(start.elapsed_time(end), 3),
+                        "buckets": [{"bucket": i, "mb": round(nb / 2 ** 20, 2), "where": k,
+                                     "ms_before_backward_end": round(e.elapsed_time(end), 3)} for k, i, nb, e in tl
+                                    if k in ("backward", "finish")]})
+        return out
+
     def _launch(self, b, where="backward"):
         self.launch_log.append((b.index, where))
         self.stats["bucket_launches_in_" + where] += 1
+        if self._tl is not None:
+            self._tl.append((where, b.index, b.flat.numel() * b.flat.element_size(), self._event()))
         live = [(v, p.grad) for p, v in zip(b.params, b.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if live:
             torch._foreach_copy_([v for v, _ in live], [g for _, g in live])
@@ -162,6 +193,10 @@ class GradSync:
         """Call after backward: exchange the buckets backward could not complete (in index order), agree with the other
         ranks on late parameters and on the parameters nobody produced a gradient for, wait for every collective, turn
         sums into means and exchange the late gradients."""
+        if self._tl is not None:
+            self._tl.append(("end", -1, 0, self._event()))
+            self._tl_steps.append(self._tl)
+            self._tl_steps = self._tl_steps[-8:]
         while self._next < len(self.buckets):
             self._launch(self.buckets[self._next], "finish")
             self._next += 1

@@ -1,0 +1,72 @@
+"""GPU (one is enough): when does each gradient bucket become launchable inside backward?  Runs the bench's training step
+(BASELINE configs[1], 16 images per rank) at world size 1 with GradSync's bookkeeping on (what ACR_FORCE_GRADSYNC=1 does in
+bench.py) and device events at the start of backward, at every bucket launch and at its end; prints one JSON with, per mode
+(f32_split, f32, bf16), bucket sizes, launch times relative to the end of backward, and the all-reduce time that stays EXPOSED
+at 8 ranks under a stated link model.  usage: python scripts/gradsync_timeline.py > profiles/r04_gradsync_timeline.json"""
+import json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from acr_wsss_amd.DPT.ACR import ACR
+from acr_wsss_amd.dp import GradSync
+from acr_wsss_amd.train import MasterWeights, PolyOptimizer, train_step
+from acr_wsss_amd.tuning import use_shipped_miopen_db
+
+# Link model (SURVEY 5 / MI355X platform: 7 xGMI links x ~153 GB/s per GPU, fully connected 8-GPU node).  A ring all-reduce of S
+# bytes over N ranks moves 2 (N-1)/N * S per rank through ONE link direction at a time: per-link bound.  RCCL on a fully
+# connected node can run several rings / direct exchange over all 7 links; both ends are given.
+LINK_GBS, LINKS, RANKS, LAT_US = 153.0, 7, 8, 30.0
+
+
+def allreduce_ms(nbytes, links):
+    return 2.0 * (RANKS - 1) / RANKS * nbytes / (LINK_GBS * 1e9 * links) * 1e3 + LAT_US * 1e-3
+
+
+def exposed_ms(buckets, links):
+    """Buckets go out in order on one communication stream; bucket i can start at max(its launch, previous bucket's end);
+    what is left after backward's end is exposed."""
+    t = -1e9
+    for b in buckets:                                         # times relative to the end of backward (negative = before)
+        start = max(-b["ms_before_backward_end"], t)
+        t = start + allreduce_ms(b["mb"] * 2 ** 20, links)
+    return max(0.0, t)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    use_shipped_miopen_db()
+    out = {"workload": "BASELINE configs[1]: hybrid-base 448x448, 16 images per rank, world size 1 with the bucket bookkeeping on",
+           "link_model": {"gb_s_per_link": LINK_GBS, "links_per_gpu": LINKS, "ranks": RANKS, "latency_us_per_collective": LAT_US,
+                          "formula": "ring all-reduce: 2 (N-1)/N * bytes / (links_used * link rate) + latency"}}
+    for mode in ("f32_split", "f32", "bf16"):
+        torch.manual_seed(0)
+        model = ACR(num_classes=20, backbone_name="vitb_hybrid", use_pretrain=False, math="f32_split" if mode == "f32_split" else "f32").to(dev).train()
+        g = torch.Generator().manual_seed(1)
+        img = torch.randn(16, 3, 448, 448, generator=g).to(dev)
+        label = (torch.rand(16, 20, generator=g) > 0.85).float().to(dev)
+        if mode == "bf16":
+            opt = MasterWeights(model, lambda ps: PolyOptimizer(ps, lr=0.05, weight_decay=5e-4, max_step=100000))
+            img = img.to(torch.bfloat16)
+        else:
+            opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=100000)
+        sync = GradSync(model.parameters(), record_timeline=True)
+        for _ in range(6):
+            train_step(model, opt, img, label, 125, grad_sync=sync)
+        steps = sync.timeline()[-3:]
+        last = steps[-1]
+        rec = {"buckets_mb": [b["mb"] for b in last["buckets"]], "backward_ms": [s["backward_ms"] for s in steps],
+               "launch_ms_before_backward_end": [[b["ms_before_backward_end"] for b in s["buckets"]] for s in steps],
+               "launched_from": [b["where"] for b in last["buckets"]],
+               "projected_exposed_allreduce_ms_at_8_ranks": {"one_link_ring": round(exposed_ms(last["buckets"], 1), 3),
+                                                             "all_7_links": round(exposed_ms(last["buckets"], LINKS), 3)},
+               "allreduce_ms_per_bucket_one_link": [round(allreduce_ms(b["mb"] * 2 ** 20, 1), 3) for b in last["buckets"]]}
+        out[mode] = rec
+        print("[gradsync] %s: backward %.1f ms, buckets %s MB, launched %s ms before its end" % (
+            mode, last["backward_ms"], rec["buckets_mb"], rec["launch_ms_before_backward_end"][-1]), file=sys.stderr, flush=True)
+        del model, opt, sync
+        torch.cuda.empty_cache()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
