@@ -182,3 +182,24 @@ class ACR(DPT):
         cams = torch.stack(rows).sum(dim=0)
         skip = 2 if self.cur_backbone == "deitb16_distil_384" else 1
         return torch.relu(cams[:, skip:]), attn_list, rows
+
+    def getam_all(self, start_layer=0, func="grad"):
+        """``getam`` for EVERY sample of the last forward_cam / backward pair at once: (B, N) class CAM rows, row b equal to
+        ``getam(b, start_layer, func)[0]`` up to the order of the fp32 layer sum (one launch per layer for the whole batch,
+        accumulated in the kernel, instead of one launch per sample and layer plus a stack + sum: CAM generation batches the
+        flipped and the plain pass and several images)."""
+        vit = self.pretrained.model
+        rows = None
+        for i, blk in enumerate(vit.blocks):
+            if i < start_layer:
+                continue
+            saved = blk.attn.saved_for_getam()
+            if saved is None:
+                raise RuntimeError("getam_all(): block %d has no saved forward/backward: call forward_cam + backward first, in eval() "
+                                   "mode (a train()-mode forward keeps no attention state unless Attention.keep_state_in_training is set)" % i)
+            qkv, d_o, lse2, heads = saved
+            if rows is None:
+                rows = torch.zeros((qkv.shape[0], qkv.shape[1]), dtype=torch.float32, device=qkv.device)
+            ops.getam_rows_accum(qkv, d_o, lse2, heads, func, rows)
+        skip = 2 if self.cur_backbone == "deitb16_distil_384" else 1
+        return torch.relu(rows[:, skip:])

@@ -128,6 +128,8 @@ SIGNATURES = {
     "acr_getam_row_accum": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       c_void_p, c_void_p]),
     "acr_aff_refine": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "acr_aff_refine_batch": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "acr_getam_rows_accum": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "acr_patch_cam": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                 c_void_p, c_void_p]),
     "acr_bilinear_resize": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int32,

@@ -466,9 +466,11 @@ template <typename T>
 __global__ __launch_bounds__(64) void getam_row_kernel(AttnGeom g, const T* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v, const T* __restrict__ d_o,
                                                        const float* __restrict__ lse2, int batch, int func,
-                                                       float* __restrict__ cam_row) {
+                                                       float* __restrict__ cam_row, int64_t row_stride) {
     __shared__ float q0s[64], do0s[64];
     const int j = blockIdx.x * 64 + threadIdx.x;
+    batch += blockIdx.y;                                   // acr_getam_rows_accum: one grid row per sample
+    cam_row += (int64_t)blockIdx.y * row_stride;
     float sum_g = 0.f, sum_cg = 0.f;
     for (int h = 0; h < g.H; ++h) {
         const int64_t base = (int64_t)batch * g.sb + (int64_t)h * g.sh;
@@ -758,9 +760,29 @@ extern "C" int acr_getam_row_accum(const acr_attn_desc* d, const void* q, const 
     const dim3 grid((d->T + 63) / 64);
     if (d->dtype == ACR_F32)
         hipLaunchKernelGGL((getam_row_kernel<float>), grid, dim3(64), 0, (hipStream_t)stream, g, (const float*)q,
-                           (const float*)k, (const float*)v, (const float*)d_o, lse2, batch, func, cam_row);
+                           (const float*)k, (const float*)v, (const float*)d_o, lse2, batch, func, cam_row, (int64_t)0);
     else
         hipLaunchKernelGGL((getam_row_kernel<__bf16>), grid, dim3(64), 0, (hipStream_t)stream, g, (const __bf16*)q,
-                           (const __bf16*)k, (const __bf16*)v, (const __bf16*)d_o, lse2, batch, func, cam_row);
+                           (const __bf16*)k, (const __bf16*)v, (const __bf16*)d_o, lse2, batch, func, cam_row, (int64_t)0);
     return acr_check_launch("acr_getam_row_accum");
+}
+
+// the same for EVERY sample of the batch in one launch: cam_rows[b] (row pitch row_stride >= T) += f(...) of sample b
+extern "C" int acr_getam_rows_accum(const acr_attn_desc* d, const void* q, const void* k, const void* v, const void* d_o,
+                                    const float* lse2, int32_t func, float* cam_rows, int64_t row_stride, void* stream) {
+    int rc = check_desc(d, "acr_getam_rows_accum");
+    if (rc) return rc;
+    ACR_CHECK_ARG(q && k && v && d_o && lse2 && cam_rows, "acr_getam_rows_accum: null pointer");
+    ACR_CHECK_ARG(func >= 0 && func <= 3, "acr_getam_rows_accum: unknown func %d", func);
+    ACR_CHECK_ARG(row_stride >= d->T && d->B < 65536, "acr_getam_rows_accum: row pitch < T or batch too large");
+    ACR_CHECK_ARG(d->dtype != ACR_F32_BF16X3, "acr_getam_rows_accum: exact kernels only (pass ACR_F32)");
+    AttnGeom g = geom(d);
+    const dim3 grid((d->T + 63) / 64, d->B);
+    if (d->dtype == ACR_F32)
+        hipLaunchKernelGGL((getam_row_kernel<float>), grid, dim3(64), 0, (hipStream_t)stream, g, (const float*)q,
+                           (const float*)k, (const float*)v, (const float*)d_o, lse2, 0, func, cam_rows, row_stride);
+    else
+        hipLaunchKernelGGL((getam_row_kernel<__bf16>), grid, dim3(64), 0, (hipStream_t)stream, g, (const __bf16*)q,
+                           (const __bf16*)k, (const __bf16*)v, (const __bf16*)d_o, lse2, 0, func, cam_rows, row_stride);
+    return acr_check_launch("acr_getam_rows_accum");
 }

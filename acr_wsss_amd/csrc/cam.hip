@@ -55,25 +55,53 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
     }
 }
 
-// out[c][r] = sum_l sum_k a[l][1+r][1+k] * cam[c][k]; one wave per row r, up to 8 cams per pass.
-__global__ __launch_bounds__(256) void aff_refine_kernel(const float* __restrict__ a, int L, int T,
+// out[s][c][r] = sum_k (sum_l a[s][l][1+r][1+k]) * cam[s][c][k] for sample s = blockIdx.y; one wave per row r, up to 8 cams per
+// pass.  HBM-bound: every element of the (L, T, T) stack is read once.  The layers are summed FIRST, in layer order, into one
+// value per k (the reference sums the 12 maps before the product too, infer_cam.py:164-165), with 4 x 4 independent loads in
+// flight per lane (the first version's single dependent load per iteration ran at 1.07 TB/s).
+__global__ __launch_bounds__(256) void aff_refine_kernel(const float* __restrict__ a, int64_t a_sb, int L, int T,
                                                          const float* __restrict__ cam, int n_cam, int c0,
                                                          float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int N = T - 1;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= N) return;
+    a += (int64_t)blockIdx.y * a_sb;
+    cam += (int64_t)blockIdx.y * n_cam * N;
+    out += (int64_t)blockIdx.y * n_cam * N;
     float acc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = 0.f;
     const int nc = min(8, n_cam - c0);
-    for (int l = 0; l < L; ++l) {
-        const float* row = a + ((int64_t)l * T + 1 + r) * T + 1;
-        for (int k = lane; k < N; k += 64) {
-            const float av = row[k];
+    const float* row0 = a + (int64_t)(1 + r) * T + 1;
+    const int64_t lst = (int64_t)T * T;
+    for (int k0 = 0; k0 < N; k0 += 256) {
+        float av[4] = {0.f, 0.f, 0.f, 0.f};
+        int kk[4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (c < nc) acc[c] = fmaf(av, cam[(int64_t)(c0 + c) * N + k], acc[c]);
+        for (int u = 0; u < 4; ++u) kk[u] = min(k0 + 64 * u + lane, N - 1);          // clamped: loads stay unconditional
+        int l = 0;
+        for (; l + 4 <= L; l += 4) {
+            float t[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[j][u] = __builtin_nontemporal_load(row0 + (l + j) * lst + kk[u]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) av[u] += t[j][u];
+        }
+        for (; l < L; ++l)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) av[u] += __builtin_nontemporal_load(row0 + l * lst + kk[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + 64 * u + lane < N) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (c < nc) acc[c] = fmaf(av[u], cam[(int64_t)(c0 + c) * N + kk[u]], acc[c]);
+            }
         }
     }
 #pragma unroll
@@ -124,12 +152,18 @@ extern "C" int acr_bilinear_resize(const float* src, int64_t src_sc, int64_t src
     return acr_check_launch("acr_bilinear_resize");
 }
 
+extern "C" int acr_aff_refine_batch(const float* a, int64_t a_sb, int32_t L, int32_t T, const float* cam, int32_t n_cam,
+                                    int32_t nbatch, float* out, void* stream) {
+    ACR_CHECK_ARG(a && cam && out, "acr_aff_refine: null pointer");
+    ACR_CHECK_ARG(L > 0 && T > 1 && n_cam > 0 && nbatch > 0 && nbatch < 65536, "acr_aff_refine: bad geometry L=%d T=%d n=%d batch=%d", L, T, n_cam, nbatch);
+    ACR_CHECK_ARG(nbatch == 1 || a_sb >= (int64_t)L * T * T, "acr_aff_refine: batch stride smaller than one (L, T, T) stack");
+    const dim3 grid((T - 1 + 3) / 4, nbatch);
+    for (int c0 = 0; c0 < n_cam; c0 += 8)
+        hipLaunchKernelGGL(aff_refine_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, a_sb, L, T, cam, n_cam, c0, out);
+    return acr_check_launch("acr_aff_refine");
+}
+
 extern "C" int acr_aff_refine(const float* a, int32_t L, int32_t T, const float* cam, int32_t n_cam, float* out,
                               void* stream) {
-    ACR_CHECK_ARG(a && cam && out, "acr_aff_refine: null pointer");
-    ACR_CHECK_ARG(L > 0 && T > 1 && n_cam > 0, "acr_aff_refine: bad geometry L=%d T=%d n=%d", L, T, n_cam);
-    const dim3 grid((T - 1 + 3) / 4);
-    for (int c0 = 0; c0 < n_cam; c0 += 8)
-        hipLaunchKernelGGL(aff_refine_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, L, T, cam, n_cam, c0, out);
-    return acr_check_launch("acr_aff_refine");
+    return acr_aff_refine_batch(a, 0, L, T, cam, n_cam, 1, out, stream);
 }

@@ -31,9 +31,19 @@ def _scale_streams(dev, n):
 CONCURRENT_SCALES = os.environ.get("ACR_INFER_STREAMS", "1") != "0"        # A/B: one stream per scale
 
 
-def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", aff=True, scales=(1,), truncate=True,
-                     batch_flips=True, concurrent_scales=None):
-    """CAMs of a batch of same-sized network inputs.  imgs (B,3,h,w) normalised, on the GPU; labels (B,C) multi-hot;
+def infer_cam_images(model, imgs, labels, out_hws, **kw):
+    """CAMs of a batch of same-sized network inputs: ``launch_cam_images`` (every kernel and the device-to-host copies are
+    enqueued) followed at once by its ``collect()``; see there for arguments and results."""
+    return launch_cam_images(model, imgs, labels, out_hws, **kw)()
+
+
+def launch_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", aff=True, scales=(1,), truncate=True,
+                      batch_flips=True, concurrent_scales=None):
+    """Enqueue the CAM generation of a batch of same-sized network inputs and return ``collect``, a callable that waits for
+    THIS batch's results only and returns them -- so a caller walking a list (infer_cam_list) can enqueue the next images
+    before collecting the previous ones and the GPU never waits for the host between images.
+
+    CAMs of a batch of same-sized network inputs.  imgs (B,3,h,w) normalised, on the GPU; labels (B,C) multi-hot;
     out_hws: B pairs (W,H) = (image height, image width) as infer_cam.py:138 names them (each image keeps its own output
     size).  Returns a list of B (cam_dict, patch_cam_dict): {class index: float32 (W,H) numpy array}, min-max
     normalised over the summed passes (:201-215).
@@ -46,8 +56,8 @@ def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", 
         concurrent_scales = CONCURRENT_SCALES
     B, _, h, w = imgs.shape
     C = labels.shape[1]
-    labels = labels.to(dev).float()
-    lab_cpu = labels.cpu()
+    lab_cpu = labels.detach().float().cpu()                # host copy first: no device round trip when the labels arrive on the host
+    labels = lab_cpu.to(dev, non_blocking=True) if not labels.is_cuda else labels.float()
     classes = [[c for c in range(C) if float(lab_cpu[i, c]) > 1e-5] for i in range(B)]
     kmax = max((len(c) for c in classes), default=0)
     vit = model.pretrained.model
@@ -73,7 +83,16 @@ def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", 
     if side is not None and hasattr(vit.patch_embed, "backbone"):
         vit.patch_embed.backbone.refresh_frozen(imgs.dtype)     # the shared standardised conv weights: before the fork
     by_shape, done = {}, []
-
+    # 0/1 masks of the class logits each backward differentiates: rank k -> (samples, C), for a pass of B samples and for the
+    # batched flip pair (2 B samples: sample index = fi * B + i).  tgt = (logits * mask).sum(): its backward is one multiply
+    # (an advanced-indexing gather would come back as a sorting index_put)
+    m1 = torch.zeros((max(kmax, 1), B, C), dtype=torch.float32)
+    for k in range(kmax):
+        for i in range(B):
+            if k < len(classes[i]):
+                m1[k, i, classes[i][k]] = 1.0
+    mask1 = m1.to(dev, non_blocking=True)
+    mask2 = torch.cat([mask1, mask1], dim=1)
     def flush(rec):
         patch_items, cam_items, ev = rec
         if ev is not None:
@@ -115,27 +134,27 @@ def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", 
                         for fi, flipped in enumerate(flips):
                             for i in range(B):
                                 patch_items.append((pc[fi * B + i], i, flipped, ph, pw))
-                        rows = [[[] for _ in range(B)] for _ in flips]
+                        # one backward per class rank k serves the k-th positive class of every sample of the pass; the GETAM
+                        # rows of ALL samples come from one launch per layer (ACR.getam_all) and the affinity product of all
+                        # samples and classes from one more
+                        nf = len(flips)
+                        rows = []
                         for k in range(kmax):
-                            live = [i for i in range(B) if k < len(classes[i])]
-                            tgt = sum(cls_pred[fi * B + i, classes[i][k]] for fi in range(len(flips)) for i in live)
+                            tgt = (cls_pred.float() * (mask2[k] if nf == 2 else mask1[k])).sum()
                             if truncate:
                                 torch.autograd.grad(tgt, vit.trunc_input, retain_graph=True)
                             else:
                                 model.zero_grad()
                                 tgt.backward(retain_graph=True)
-                            for fi in range(len(flips)):
-                                for i in live:
-                                    cam, _, _ = model.getam(fi * B + i, start_layer=start_layer, func=func)
-                                    rows[fi][i].append(cam)
-                    for fi, flipped in enumerate(flips):
-                        for i in range(B):
-                            if not classes[i]:
-                                continue
-                            cams = torch.cat(rows[fi][i], dim=0).contiguous()                # (n_cls, N)
-                            if aff:
-                                cams = ops.aff_refine(attn[fi * B + i].detach().contiguous(), cams)   # patch_aff @ cam (:164-165,183-184)
-                            cam_items.append((cams, i, flipped, ph, pw))
+                            rows.append(model.getam_all(start_layer=start_layer, func=func))       # (nf * B, N)
+                    if kmax:
+                        cams_all = torch.stack(rows, dim=1)                                          # (nf * B, kmax, N)
+                        if aff:                                                                      # patch_aff @ cam (:164-165,183-184)
+                            cams_all = ops.aff_refine_batch(attn.detach(), cams_all)
+                        for fi, flipped in enumerate(flips):
+                            for i in range(B):
+                                if classes[i]:
+                                    cam_items.append((cams_all[fi * B + i, :len(classes[i])], i, flipped, ph, pw))
                     rec = (patch_items, cam_items, st.record_event() if side is not None else None)
                     if side is None:
                         flush(rec)
@@ -149,15 +168,32 @@ def infer_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad", 
             p.requires_grad_(True)
         for a in attns:
             del a.keep_state_in_training                  # back to the class default
-    out = []
+    # min-max normalisation (:201-215) and the device-to-host copies are enqueued behind this batch's last kernel on the caller's
+    # stream -- into pinned buffers, asynchronously -- and an event marks their end: collect() waits for that event only
+    host = []
     for i in range(B):
         ca, pa = cam_acc[i], patch_acc[i]
         cmin, cmax = ca.amin((1, 2), keepdim=True), ca.amax((1, 2), keepdim=True)
-        norm_cam = ((ca - cmin) / (cmax - cmin + 1e-6)).cpu().numpy()
+        norm_cam = (ca - cmin) / (cmax - cmin + 1e-6)
+        pa = pa[classes[i]] if classes[i] else pa[:0]      # only the positive classes' planes are returned (and copied)
         pmin, pmax = pa.amin((1, 2), keepdim=True), pa.amax((1, 2), keepdim=True)
-        patch_norm = ((pa - pmin) / (pmax - pmin + 1e-5)).cpu().numpy()
-        out.append(({c: norm_cam[j] for j, c in enumerate(classes[i])}, {c: patch_norm[c] for c in classes[i]}))
-    return out
+        patch_norm = (pa - pmin) / (pmax - pmin + 1e-5)
+        hc = torch.empty(norm_cam.shape, dtype=torch.float32, pin_memory=True)
+        hp = torch.empty(patch_norm.shape, dtype=torch.float32, pin_memory=True)
+        hc.copy_(norm_cam, non_blocking=True)
+        hp.copy_(patch_norm, non_blocking=True)
+        host.append((hc, hp))
+    done_ev = torch.cuda.Event()
+    done_ev.record(main)
+
+    def collect():
+        done_ev.synchronize()
+        out = []
+        for i in range(B):
+            norm_cam, patch_norm = host[i][0].numpy().copy(), host[i][1].numpy().copy()
+            out.append(({c: norm_cam[j] for j, c in enumerate(classes[i])}, {c: patch_norm[j] for j, c in enumerate(classes[i])}))
+        return out
+    return collect
 
 
 def infer_cam_image(model, img, label, out_hw, start_layer=10, func="grad", aff=True, scales=(1,), truncate=True,
@@ -199,17 +235,9 @@ def infer_cam_list(model, items, out_cam=None, rank=0, world=1, batch_size=1, ou
     model.eval()
     results = {}
     mine = shard_indices(len(items), rank, world)
-    pos = 0
-    while pos < len(mine):
-        grp = [mine[pos]]
-        shape = items[mine[pos]][1].shape
-        while len(grp) < batch_size and pos + len(grp) < len(mine) and items[mine[pos + len(grp)]][1].shape == shape:
-            grp.append(mine[pos + len(grp)])
-        pos += len(grp)
-        imgs = torch.cat([items[i][1] for i in grp], dim=0).to(dev)
-        labels = torch.cat([items[i][2] for i in grp], dim=0)
-        outs = infer_cam_images(model, imgs, labels, [items[i][3] for i in grp], **kw)
-        for i, (cam_dict, _) in zip(grp, outs):
+
+    def finish(grp, collect):
+        for i, (cam_dict, _) in zip(grp, collect()):
             name = items[i][0]
             if out_cam is not None:
                 os.makedirs(out_cam, exist_ok=True)
@@ -223,4 +251,22 @@ def infer_cam_list(model, items, out_cam=None, rank=0, world=1, batch_size=1, ou
                     os.makedirs(folder, exist_ok=True)
                     np.save(os.path.join(folder, name + ".npy"), crf_with_alpha(cam_dict, alpha, np.asarray(items[i][4]), device=dev))
             results[name] = cam_dict
+
+    # one batch in flight behind the one being collected: the kernels of images i+1 are enqueued BEFORE the host blocks on the
+    # results of images i (each batch's copies land in its own pinned buffers behind its own event)
+    pending, pos = None, 0
+    while pos < len(mine):
+        grp = [mine[pos]]
+        shape = items[mine[pos]][1].shape
+        while len(grp) < batch_size and pos + len(grp) < len(mine) and items[mine[pos + len(grp)]][1].shape == shape:
+            grp.append(mine[pos + len(grp)])
+        pos += len(grp)
+        imgs = torch.cat([items[i][1] for i in grp], dim=0).to(dev)
+        labels = torch.cat([items[i][2] for i in grp], dim=0)
+        collect = launch_cam_images(model, imgs, labels, [items[i][3] for i in grp], **kw)
+        if pending is not None:
+            finish(*pending)
+        pending = (grp, collect)
+    if pending is not None:
+        finish(*pending)
     return results

@@ -252,6 +252,16 @@ def getam_row_accum(qkv, d_o, lse2, heads, batch, func, cam_row):
                                     L.GETAM_FUNCS[func], L.ptr(cam_row), L.stream_ptr()), "acr_getam_row_accum")
 
 
+def getam_rows_accum(qkv, d_o, lse2, heads, func, cam_rows):
+    """cam_rows (B, T) fp32 += one layer's GETAM row of EVERY sample of the batch, one launch (acr_getam_rows_accum)."""
+    B, T, _ = qkv.shape
+    lib = L.load()
+    qp, kp, vp = _qkv_ptrs(qkv, heads)
+    assert cam_rows.shape == (B, T) and cam_rows.stride(1) == 1
+    L.check(lib.acr_getam_rows_accum(_desc(B, heads, T, qkv.dtype), qp, kp, vp, L.ptr(d_o), L.ptr(lse2), L.GETAM_FUNCS[func],
+                                     L.ptr(cam_rows), cam_rows.stride(0), L.stream_ptr()), "acr_getam_rows_accum")
+
+
 def linear_bf16(x, weight, bias=None, resid=None, out=None):
     """y = x @ weight.T (+ bias) (+ resid) on the hand-written bf16 MFMA GEMM (acr_linear_bf16).
     x (M,K), weight (N,K), bias (N,), resid (M,N), all bf16 with unit inner stride."""
@@ -1048,6 +1058,19 @@ def bilinear_resize(src, out_hw, align_corners, chan_mul=None, hflip=False, out=
         chan_mul = chan_mul.to(device=src.device, dtype=torch.float32).contiguous()
     L.check(L.load().acr_bilinear_resize(L.ptr(src), sc, sp, C, ih, iw, L.ptr(out), oh, ow, int(align_corners),
                                          L.ptr(chan_mul), int(hflip), int(acc), L.stream_ptr()), "acr_bilinear_resize")
+    return out
+
+
+def aff_refine_batch(stack, cams):
+    """patch_aff @ cam for every sample in one launch: stack (S,L,T,T) fp32 head-mean maps (dense per sample), cams (S,n,T-1)
+    -> (S,n,T-1)."""
+    L.require_gpu(stack, cams)
+    S, Ly, T, _ = stack.shape
+    assert stack.stride(3) == 1 and stack.stride(2) == T and stack.stride(1) == T * T and cams.is_contiguous()
+    assert cams.shape[0] == S and cams.shape[2] == T - 1
+    out = torch.empty_like(cams)
+    L.check(L.load().acr_aff_refine_batch(L.ptr(stack), stack.stride(0), Ly, T, L.ptr(cams), cams.shape[1], S, L.ptr(out),
+                                          L.stream_ptr()), "acr_aff_refine_batch")
     return out
 
 

@@ -305,7 +305,8 @@ def infer_record(args, dev, with_cpu):
     """The CAM half of the path (infer_cam.py:141-215) as BASELINE configs[3] names it: one 384x384 network input with 2
     positive classes, flipped + plain pass at scales {0.5, 1, 1.5, 2} (T = 145 ... 2305), GETAM `grad` from layer 10 with
     affinity refinement, CAMs resized to 375x500; fp32 (the precision the argmax seeds are pinned in).  `value` = images/s
-    through acr_wsss_amd.infer_cam.infer_cam_image (host loop included: this path is launch-bound at batch 1);
+    walking a list one image at a time the way acr_wsss_amd.infer_cam.infer_cam_list does (host loop included; one image in
+    flight behind the one being collected; `single_image_latency_ms` = one call of infer_cam_image alone);
     `batch8_scale1` = 8 images per call at scale 1.  Kernel records: the attention pair at the largest scale through the
     C ABI (MFMA-bound), the GETAM row accumulation and the affinity product (HBM-bound, SURVEY 8d bytes).  CPU baseline:
     the oracle's infer_image on the same image at scale 1 only (bounded sample)."""
@@ -331,21 +332,43 @@ def infer_record(args, dev, with_cpu):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
 
-    t_ms = timed(lambda: infer_cam_image(model, img, lab, out_hw, scales=scales), 3)
-    log("infer: 4 scales %.1f ms/image" % (t_ms * 1e3))
-    t_s1 = timed(lambda: infer_cam_image(model, img, lab, out_hw), 5)
+    # a LIST of images walked one image at a time, as infer_cam.py:119-123 does: infer_cam_list keeps one image in flight behind
+    # the one whose results it collects (launch_cam_images / collect), so the host's launch work overlaps the GPU's
+    from acr_wsss_amd.infer_cam import launch_cam_images
+
+    def walk(n, **kw):
+        pending = None
+        for _ in range(n):
+            c = launch_cam_images(model, img, lab, [out_hw], **kw)
+            if pending is not None:
+                pending()
+            pending = c
+        pending()
     imgs8, labs8 = img.repeat(8, 1, 1, 1), lab.repeat(8, 1)
-    t_b8 = timed(lambda: infer_cam_images(model, imgs8, labs8, [out_hw] * 8), 2)
-    # a list of same-sized images (what infer_cam.py walks: every VOC image is resized to the crop first) can go through in
-    # batches -- results per image are those of the one-image call (tests/test_model_gpu.py::test_infer_cam_images_batch_...)
-    t_b8ms = timed(lambda: infer_cam_images(model, imgs8, labs8, [out_hw] * 8, scales=scales), 2)
-    log("infer: scale 1 %.1f ms/image, batch 8 %.1f ms; 4 scales in batches of 8: %.1f ms/batch" % (t_s1 * 1e3, t_b8 * 1e3, t_b8ms * 1e3))
+    # both arithmetics of the model's fp32 products: the split-product one carries `value` (every CAM / seed fixture of the
+    # reference passes under it at unchanged tolerances: tests/test_model_gpu.py::test_infer_cam_*[f32_split]); the exact-fp32
+    # numbers ride along as `f32_exact`
+    per_math = {}
+    for math in ("f32_split", "f32"):
+        model.set_math(math)
+        t_one = timed(lambda: infer_cam_image(model, img, lab, out_hw, scales=scales), 3)
+        t_ms = timed(lambda: walk(6, scales=scales), 2) / 6
+        t_s1 = timed(lambda: infer_cam_image(model, img, lab, out_hw), 5)
+        t_b8 = timed(lambda: infer_cam_images(model, imgs8, labs8, [out_hw] * 8), 2)
+        # a list of same-sized images (what infer_cam.py walks: every VOC image is resized to the crop first) can go through
+        # in batches -- results per image are those of the one-image call (test_infer_cam_images_batch_matches_single_images)
+        t_b8ms = timed(lambda: infer_cam_images(model, imgs8, labs8, [out_hw] * 8, scales=scales), 2)
+        log("infer[%s]: 4 scales %.1f ms/image in a list walk (%.1f ms for one image alone); scale 1 %.1f ms/image, batch 8 %.1f ms; "
+            "4 scales in batches of 8: %.1f ms/batch" % (math, t_ms * 1e3, t_one * 1e3, t_s1 * 1e3, t_b8 * 1e3, t_b8ms * 1e3))
+        per_math[math] = {"value": round(1.0 / t_ms, 3), "ms_per_image": round(t_ms * 1e3, 2),
+                          "single_image_latency_ms": round(t_one * 1e3, 2), "scale1_img_s": round(1.0 / t_s1, 2),
+                          "batch8_scale1": round(8.0 / t_b8, 2), "batch8_4scales": round(8.0 / t_b8ms, 2)}
     rec = {"workload": "BASELINE configs[3]: 384x384 base, scales {0.5,1,1.5,2}, 2 classes, flipped + plain pass, GETAM grad "
                        "start_layer 10 + affinity, CAMs at 375x500 (infer_cam.py:141-215); synthetic image, seeded init",
-           "metric": "img/s CAM generation, 1 GPU", "value": round(1.0 / t_ms, 3), "unit": "img/s", "dtype": "f32",
-           "ms_per_image": round(t_ms * 1e3, 2), "scale1_img_s": round(1.0 / t_s1, 2), "batch8_scale1": round(8.0 / t_b8, 2),
-           "batch8_4scales": round(8.0 / t_b8ms, 2),
-           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+           "metric": "img/s CAM generation, 1 GPU", "unit": "img/s", "dtype": "f32_split", "precision": PRECISION["f32_split"]}
+    rec.update(per_math["f32_split"])
+    rec["f32_exact"] = per_math["f32"]
+    rec["peak_mem_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
     del model, imgs8
     gc.collect()
     torch.cuda.empty_cache()
@@ -372,6 +395,18 @@ def infer_record(args, dev, with_cpu):
                                                             dvp, L.ptr(delta), st), "bwd"))
     kernels["acr_attn_bwd"] = _mfma_rec("acr_attn_bwd_scores (no head-mean gradient: the class logit's backward), B=2 H=12 T=2305",
                                         4 * unit, 5 * unit, t, peak)
+    # the same pair under the split-product arithmetic (what `value` runs): fp32-equivalent FLOP against the bf16 peak / 6
+    dx = ops._desc(B, H, T, torch.float32, math=1)
+    sres3 = torch.empty(lib.acr_attn_scores_floats(dx), device=dev)
+    delta3 = torch.empty(lib.acr_attn_bwd_ws_floats(dx), device=dev)
+    t = time_kernel(lambda: L.check(lib.acr_attn_fwd_scores(dx, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(sres3), L.ptr(pm), T * T, T, st), "fwd"))
+    kernels["acr_attn_fwd_x3"] = _mfma_rec("acr_attn_fwd_scores [ACR_F32_BF16X3] (+ split + head-mean stream), B=2 H=12 T=2305", 2 * unit, 2 * unit, t,
+                                           PEAK_MFMA["f32_split"])
+    t = time_kernel(lambda: L.check(lib.acr_attn_bwd_scores(dx, qp, kp, vp, L.ptr(o), L.ptr(d_o), L.ptr(lse2), L.ptr(sres3), None, 0, 0, dqp, dkp,
+                                                            dvp, L.ptr(delta3), st), "bwd"))
+    kernels["acr_attn_bwd_x3"] = _mfma_rec("acr_attn_bwd_scores [ACR_F32_BF16X3] (no head-mean gradient), B=2 H=12 T=2305", 4 * unit, 5 * unit, t,
+                                           PEAK_MFMA["f32_split"])
+    del sres3, delta3
     cam_row = torch.zeros(T - 1, device=dev)
     t = time_kernel(lambda: ops.getam_row_accum(qkv, d_o, lse2, H, 0, "grad", cam_row))
     row_bytes = 4.0 * (3 * H * 64 * T + H * 64 + H * T + (T - 1))     # k, v of one sample once, q/dO row 0, lse2 row, the output row

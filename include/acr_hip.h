@@ -350,11 +350,18 @@ int acr_consistency_bwd(const float* a1, const float* a2, int64_t a_sb, int32_t 
 int acr_getam_row_accum(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
                         const void* d_o, const float* lse2, int32_t batch, int32_t func,
                         float* cam_row, void* stream);
+/* The same for every sample of the batch in ONE launch (CAM generation batches the flipped and the plain pass and several
+ * images: infer_cam.py:147-153 runs them one by one): cam_rows[b*row_stride + j] += f_h(...) of sample b, b = 0 .. desc->B-1. */
+int acr_getam_rows_accum(const acr_attn_desc* desc, const void* q, const void* k, const void* v, const void* d_o,
+                         const float* lse2, int32_t func, float* cam_rows, int64_t row_stride, void* stream);
 
 /* Affinity refinement (infer_cam.py:164-165,183-184): out[c][r] = sum_l sum_k a[l][1+r][1+k] cam[c][k]
  * for one sample's (L,T,T) head-mean stack `a`, n_cam row vectors cam (n_cam, T-1) -> out (n_cam, T-1). */
 int acr_aff_refine(const float* a, int32_t L, int32_t T, const float* cam, int32_t n_cam,
                    float* out, void* stream);
+/* nbatch samples in one launch: a[s] = a + s * a_sb, cam / out (nbatch, n_cam, T-1) contiguous. */
+int acr_aff_refine_batch(const float* a, int64_t a_sb, int32_t L, int32_t T, const float* cam, int32_t n_cam,
+                         int32_t nbatch, float* out, void* stream);
 
 /* ---- input pipeline (myTool.py:1158-1199 get_data_from_chunk_v2, :1364-1403 get_data_from_chunk_val) ----
  * One launch turns a batch of decoded uint8 HWC RGB images into the (B,3,S,S) network input: bilinear resize with
