@@ -203,10 +203,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_sres_kernel
     rows_from_global(qreg, q + base, g.st, q0, g.T, r, h, g.scale * ACR_LOG2E);
     float m = -INFINITY, l = 0.f;
     f32x16 o0 = {0}, o1 = {0};
-    const LaneBases lb = lane_bases(r, h);
+    const LaneBasesA lb = lane_bases_a(r, h, smem);
     int doff[(8 + NW - 1) / NW];
     dma_offsets32_nw<NW>(doff, g.st, wave, lane);
-    const char* sm = reinterpret_cast<const char*>(smem);
     float* sblk = sres + sres_block(g, NB, b, hd, min(q0 >> 5, NB - 1), 0) + lane * 4;
     auto step = [&](int k0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_sres_kernel
         __builtin_amdgcn_s_setprio(0);
         if (!live) return;
         f32x16 s = {0};
-        rowop_i<KOFF>(s, sm, lb, qreg);                    // s[reg] = S2[key = k0 + krow][query = q0 + r]
+        rowop_x<KOFF>(s, lb, qreg);                        // s[reg] = S2[key = k0 + krow][query = q0 + r]
         __builtin_amdgcn_s_setprio(2);
         if (k0 + 32 > g.T) {                               // only the last key tile has keys beyond T (uniform branch)
 #pragma unroll
@@ -254,8 +253,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_sres_kernel
         rs += __shfl_xor(rs, 32);
         l += rs;
         __builtin_amdgcn_s_setprio(0);
-        accop_b_i<VOFF, 0>(o0, p, sm, lb);                 // o[reg] = O^T[d = 32*blk + krow][query = r]
-        accop_b_i<VOFF, 1>(o1, p, sm, lb);
+        accop_x<VOFF, 0, false>(o0, p, lb);                // o[reg] = O^T[d = 32*blk + krow][query = r]
+        accop_x<VOFF, 1, false>(o1, p, lb);
     };
     for (int k0 = 0; k0 < g.T; k0 += 64) {
         step(k0, std::integral_constant<int, 0>{});
@@ -439,10 +438,9 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk
     const float* grow = gm ? gm + (int64_t)b * gm_sb + (int64_t)min(q0 + r, g.T - 1) * gm_st : nullptr;
     const float* sblk = sres + sres_block(g, NB, b, hd, min(q0 >> 5, NB - 1), 0) + lane * 4;
     f32x16 dq0 = {0}, dq1 = {0};
-    const LaneBases lb = lane_bases(r, h);
+    const LaneBasesA lb = lane_bases_a(r, h, smem);
     int doff[2];
     dma_offsets32(doff, g.st, wave, lane);
-    const char* sm = reinterpret_cast<const char*>(smem);
     f32x4 sbuf[2][4], gbuf[2][4];                          // [ring slot][register quad]
     auto load_sg = [&](int k0, f32x4 (&s4)[4], f32x4 (&g4)[4]) {
         const float* sp = sblk + (int64_t)(k0 >> 5) * SB_FLOATS;
@@ -482,7 +480,7 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk
         __builtin_amdgcn_s_setprio(0);
         LAB_ADD(1);
         f32x16 dp = {0};
-        rowop_i<VOFF>(dp, sm, lb, doreg);                  // dP^T[key = krow][query = r]
+        rowop_x<VOFF>(dp, lb, doreg);                      // dP^T[key = krow][query = r]
 #ifdef LAB_TL
         asm volatile("" :: "v"(dp[15]));
 #endif
@@ -496,8 +494,8 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk
         }
         __builtin_amdgcn_s_setprio(0);
         LAB_ADD(3);
-        accop_a_i<KOFF, 0>(dq0, ds, sm, lb);               // dQ[query = krow][d = 32*blk + r]
-        accop_a_i<KOFF, 1>(dq1, ds, sm, lb);
+        accop_x<KOFF, 0, true>(dq0, ds, lb);               // dQ[query = krow][d = 32*blk + r]
+        accop_x<KOFF, 1, true>(dq1, ds, lb);
 #ifdef LAB_TL
         asm volatile("" :: "v"(dq0[15]), "v"(dq1[15]));
 #endif
@@ -573,19 +571,19 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
     const int glane = min(key, g.T - 1) + 4 * h * (int)gm_st;            // lane part of a G address (krow = c_reg + 4h)
     const int gcl = min(key, g.T - 1);
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
-    const LaneBases lb = lane_bases(r, h);
-    const char* sm = reinterpret_cast<const char*>(smem);
+    const LaneBasesA lb = lane_bases_a(r, h, smem);
     int qoff[2], dooff[2];                                   // lane parts of the Q / dO tile DMA source addresses (interior tiles)
     dma_offsets32(qoff, g.st, wave, lane);
     dma_offsets32(dooff, g.ost, wave, lane);
     // transposed score reads: lane (kappa = r, h): byte address = tb[reg & 3] + slot*4096 + 128*(reg >> 2)
-    int tb[4];
+    uint32_t tb[4];
     {
         const int gk = r >> 3, hk = (r >> 2) & 1, ek = r & 3, mm = 2 * gk + hk;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tb[j] = ((wave * 2 * SB_FLOATS) + gk * 256 + 128 * hk + ek + 4 * ((j + 4 * h) ^ mm)) * 4;
+        for (int j = 0; j < 4; ++j)
+            tb[j] = lds_addr_of(ssm) + ((wave * 2 * SB_FLOATS) + gk * 256 + 128 * hk + ek + 4 * ((j + 4 * h) ^ mm)) * 4;
     }
-    const char* ssb = reinterpret_cast<const char*>(ssm);
+    const uint32_t rca = lds_addr_of(rc) + 16 * h;           // l4[gq] at + slot*256 + 32 gq, d4[gq] at + slot*256 + 128 + 32 gq
     float gbuf[2][16];                                      // [ring slot][register]: raw G[b][q0 + krow][key]
     auto load_g = [&](int q0, float (&gv)[16]) {
         if (gb0 == nullptr) {
@@ -632,15 +630,24 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         if (q0 + 32 < g.T) load_g(q0 + 32, gbuf[SLOT ^ 1]);
         LAB_ADD(1);
         f32x16 dp = {0};
-        rowop_i<DOOFF>(dp, sm, lb, vreg);                  // dP[query = krow][key = r]
+        rowop_x<DOOFF>(dp, lb, vreg);                      // dP[query = krow][key = r]
 #ifdef LAB_TL
         asm volatile("" :: "v"(dp[15]));
 #endif
         LAB_ADD(2);
-        f32x16 s;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            s[reg] = *reinterpret_cast<const float*>(ssb + tb[reg & 3] + (SLOT * SB_FLOATS * 4 + 128 * (reg >> 2)));
+        float s[16];
+        f32x4 l4[4], d4[4];
+#define SRES_RDS(REG) ACR_LDS_RD32(s[REG], tb[(REG) & 3], SLOT * SB_FLOATS * 4 + 128 * ((REG) >> 2))
+        SRES_RDS(0); SRES_RDS(1); SRES_RDS(2); SRES_RDS(3); SRES_RDS(4); SRES_RDS(5); SRES_RDS(6); SRES_RDS(7);
+        SRES_RDS(8); SRES_RDS(9); SRES_RDS(10); SRES_RDS(11); SRES_RDS(12); SRES_RDS(13); SRES_RDS(14); SRES_RDS(15);
+#undef SRES_RDS
+        ACR_LDS_RD128(l4[0], rca, SLOT * 256); ACR_LDS_RD128(l4[1], rca, SLOT * 256 + 32);
+        ACR_LDS_RD128(l4[2], rca, SLOT * 256 + 64); ACR_LDS_RD128(l4[3], rca, SLOT * 256 + 96);
+        ACR_LDS_RD128(d4[0], rca, SLOT * 256 + 128); ACR_LDS_RD128(d4[1], rca, SLOT * 256 + 160);
+        ACR_LDS_RD128(d4[2], rca, SLOT * 256 + 192); ACR_LDS_RD128(d4[3], rca, SLOT * 256 + 224);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]),
+                     "+v"(s[8]), "+v"(s[9]), "+v"(s[10]), "+v"(s[11]), "+v"(s[12]), "+v"(s[13]), "+v"(s[14]), "+v"(s[15]), "+v"(l4[0]),
+                     "+v"(l4[1]), "+v"(l4[2]), "+v"(l4[3]), "+v"(d4[0]), "+v"(d4[1]), "+v"(d4[2]), "+v"(d4[3]));
         if (q0 + 32 > g.T) {                               // last query block: rows beyond T are junk, P = 0 there
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
@@ -650,22 +657,20 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {                   // krow(4 gq + e, h) = 8 gq + 4 h + e: four consecutive queries
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(rcs + 8 * gq + 4 * h);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(rcs + 32 + 8 * gq + 4 * h);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int reg = 4 * gq + e;
-                const float pv = __builtin_amdgcn_exp2f(s[reg] - l4[e]);
+                const float pv = __builtin_amdgcn_exp2f(s[reg] - l4[gq][e]);
                 p[reg] = pv;
-                ds[reg] = pv * (dp[reg] + gbuf[SLOT][reg] * invH - d4[e]);
+                ds[reg] = pv * (dp[reg] + gbuf[SLOT][reg] * invH - d4[gq][e]);
             }
         }
         __builtin_amdgcn_s_setprio(0);
         LAB_ADD(3);
-        accop_a_i<DOOFF, 0>(dv0, p, sm, lb);               // dV[key = krow][d = 32*blk + r]
-        accop_a_i<DOOFF, 1>(dv1, p, sm, lb);
-        accop_a_i<QOFF, 0>(dk0, ds, sm, lb);
-        accop_a_i<QOFF, 1>(dk1, ds, sm, lb);
+        accop_x<DOOFF, 0, true>(dv0, p, lb);               // dV[key = krow][d = 32*blk + r]
+        accop_x<DOOFF, 1, true>(dv1, p, lb);
+        accop_x<QOFF, 0, true>(dk0, ds, lb);
+        accop_x<QOFF, 1, true>(dk1, ds, lb);
 #ifdef LAB_TL
         asm volatile("" :: "v"(dv0[15]), "v"(dv1[15]), "v"(dk0[15]), "v"(dk1[15]));
 #endif

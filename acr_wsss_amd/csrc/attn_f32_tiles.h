@@ -203,3 +203,81 @@ __device__ __forceinline__ LaneBases lane_bases_at(int r, int h, int byte_off) {
     for (int c = 0; c < 4; ++c) lb.colb[c] += byte_off;
     return lb;
 }
+
+// ---- the same walks with INLINE-ASM LDS reads (round 4) ---------------------------------------------------------------------------
+// hipcc cannot tell an LDS-DMA's LDS write from an LDS load of another slot: behind a global_load_lds it puts s_waitcnt vmcnt(0)
+// in front of the next LDS load builtin -- in every step of the sweeps the wave then waited for the tile it had just sent for
+// (found in the ISA while building attn_f32_x3.hip; the resident-score sweeps had carried it since round 3: their "DMA issue +
+// loads" phase, profiles/r03_attn_bwd_phases.txt).  Reads written as inline asm are invisible to that pass; each carries its own
+// counted lgkmcnt wait (LDS operations of a wave return in order: "at most n outstanding" = "all but my n newest have landed";
+// operations the compiler adds only make a wait stricter).  Addresses are LDS byte addresses (tile base included).
+struct LaneBasesA { uint32_t rowb[8]; uint32_t colb[4]; };
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ LaneBasesA lane_bases_a(int r, int h, const void* sm) {
+    const LaneBases lb = lane_bases(r, h);
+    LaneBasesA la;
+    const uint32_t b = lds_addr_of(sm);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) la.rowb[i] = b + lb.rowb[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) la.colb[c] = b + lb.colb[c];
+    return la;
+}
+#define ACR_LDS_RD128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
+#define ACR_LDS_RD32(dst, addr, OFF) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
+#define ACR_LDS_WAIT4(cnt, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define ACR_LDS_WAIT1(cnt, a) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(a))
+
+// acc[reg] += sum_d tile[krow(reg,h)][d] * Y[l&31][d]: four 16-byte reads in flight ahead of the MFMAs that consume them
+template <int TILE_OFF>
+__device__ __forceinline__ void rowop_x(f32x16& acc, const LaneBasesA& lb, const float (&y)[32]) {
+    f32x4 a[8];
+    ACR_LDS_RD128(a[0], lb.rowb[0], TILE_OFF); ACR_LDS_RD128(a[1], lb.rowb[1], TILE_OFF);
+    ACR_LDS_RD128(a[2], lb.rowb[2], TILE_OFF); ACR_LDS_RD128(a[3], lb.rowb[3], TILE_OFF);
+#define ACR_ROWSTEP(I, CNT, NEXT)                                                                   \
+    ACR_LDS_WAIT1(CNT, a[I]);                                                                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[I][0], y[4 * (I) + 0], acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[I][1], y[4 * (I) + 1], acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[I][2], y[4 * (I) + 2], acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[I][3], y[4 * (I) + 3], acc, 0, 0, 0);              \
+    NEXT
+    ACR_ROWSTEP(0, 3, ACR_LDS_RD128(a[4], lb.rowb[4], TILE_OFF);)
+    ACR_ROWSTEP(1, 3, ACR_LDS_RD128(a[5], lb.rowb[5], TILE_OFF);)
+    ACR_ROWSTEP(2, 3, ACR_LDS_RD128(a[6], lb.rowb[6], TILE_OFF);)
+    ACR_ROWSTEP(3, 3, ACR_LDS_RD128(a[7], lb.rowb[7], TILE_OFF);)
+    ACR_ROWSTEP(4, 3, )
+    ACR_ROWSTEP(5, 2, )
+    ACR_ROWSTEP(6, 1, )
+    ACR_ROWSTEP(7, 0, )
+#undef ACR_ROWSTEP
+}
+// the 16 column elements of accop (col_elem) of one 32-column block, read 8 ahead
+template <int TILE_OFF, int BLK, int REG>
+__device__ __forceinline__ void col_read_x(float& dst, const LaneBasesA& lb) {
+    constexpr int c_reg = (REG & 3) + 8 * (REG >> 2);
+    constexpr int C = (8 * BLK) ^ (c_reg & 15);
+    ACR_LDS_RD32(dst, lb.colb[C & 3], TILE_OFF + c_reg * 256 + (C & 8) * 16);
+}
+template <int TILE_OFF, int BLK, bool ZA>
+__device__ __forceinline__ void accop_x(f32x16& acc, const f32x16& z, const LaneBasesA& lb) {
+    float t[16];
+#define ACR_CR(R) col_read_x<TILE_OFF, BLK, R>(t[R], lb)
+#define ACR_MM(R)                                                                                   \
+    acc = ZA ? __builtin_amdgcn_mfma_f32_32x32x2f32(z[R], t[R], acc, 0, 0, 0)                       \
+             : __builtin_amdgcn_mfma_f32_32x32x2f32(t[R], z[R], acc, 0, 0, 0)
+    ACR_CR(0); ACR_CR(1); ACR_CR(2); ACR_CR(3); ACR_CR(4); ACR_CR(5); ACR_CR(6); ACR_CR(7);
+    ACR_LDS_WAIT4(4, t[0], t[1], t[2], t[3]);
+    ACR_MM(0); ACR_MM(1); ACR_MM(2); ACR_MM(3);
+    ACR_CR(8); ACR_CR(9); ACR_CR(10); ACR_CR(11);
+    ACR_LDS_WAIT4(4, t[4], t[5], t[6], t[7]);
+    ACR_MM(4); ACR_MM(5); ACR_MM(6); ACR_MM(7);
+    ACR_CR(12); ACR_CR(13); ACR_CR(14); ACR_CR(15);
+    ACR_LDS_WAIT4(4, t[8], t[9], t[10], t[11]);
+    ACR_MM(8); ACR_MM(9); ACR_MM(10); ACR_MM(11);
+    ACR_LDS_WAIT4(0, t[12], t[13], t[14], t[15]);
+    ACR_MM(12); ACR_MM(13); ACR_MM(14); ACR_MM(15);
+#undef ACR_CR
+#undef ACR_MM
+}
