@@ -404,15 +404,30 @@ __global__ __launch_bounds__(256) void attn_delta_sres_kernel(AttnGeom g, int NB
 }
 
 // ---------------------------------------------------------------------------------------------
+// Counted waits (round 4).  A step's tile DMA must have landed at the step's barrier, but the private streams of a wave -- its
+// score blocks (two steps ahead) and its G block (one step) -- are YOUNGER vector-memory operations and may stay in flight:
+// vmcnt retires in issue order, so "at most n outstanding" with n = the number of younger operations is exactly "the tile has
+// landed".  n is wave-uniform; every stream is LDS-DMA (register prefetch rings turn into loop-carried copies that hipcc
+// waits for right behind the loads -- found in this file's round-3 ISA).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sres_wait_vm(int n) {
+    if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#define SRES_FENCE() asm volatile("" ::: "memory")
+
+// ---------------------------------------------------------------------------------------------
 // dQ: workgroup = (b, h, 128 queries); dO rows of the wave's 32 queries in registers; K/V tiles stream through the LDS ring;
-// the wave's score block and its G rows for the NEXT step are in flight (registers) while this step's MFMAs run.
+// the wave's score blocks (as stored: query on the lane) go through a private two-slot LDS ring two steps ahead, its 32 x 32
+// block of G through a private single-slot tile one step ahead, both by LDS-DMA.
 //   dP^T = V dO^T (32 MFMAs)   dS^T = exp2(S - lse2) (dP^T + G/H - delta)   dQ += dS K (32 MFMAs)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk, bool tails, const AttnGeom& g, const float* __restrict__ k,
-                                                  const float* __restrict__ v, const float* __restrict__ d_o,
-                                                  const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                  const float* __restrict__ sres, const float* __restrict__ gm, int64_t gm_sb,
-                                                  int64_t gm_st, float* __restrict__ dq) {
+__device__ __forceinline__ void attn_dq_sres_body(float* smem, float* ssm, float* gsm, int bid, int nblk, bool tails, const AttnGeom& g,
+                                                  const float* __restrict__ k, const float* __restrict__ v,
+                                                  const float* __restrict__ d_o, const float* __restrict__ lse2,
+                                                  const float* __restrict__ delta, const float* __restrict__ sres,
+                                                  const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st, float* __restrict__ dq) {
     const int NB = (g.T + 31) >> 5, nqt = tails ? NB >> 2 : (NB + 3) >> 2;      // tails: the last block has its own workgroup
     int id = acr_xcd_remap(bid, nblk);
     const int qt = id % nqt; id /= nqt;
@@ -427,47 +442,63 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk
     const int64_t obase = (int64_t)b * g.osb + (int64_t)hd * g.osh;
     const float* kb = k + base;
     const float* vb = v + base;
+    // private streams of this wave: score blocks (qb = q0 / 32, kb = step) copied as stored, G block rows = its queries with
+    // 16-byte chunk c of row q in slot c ^ ((q >> 1) & 7) (the lane's row reads are then bank-conflict free)
+    const float* srow = sres + sres_block(g, NB, b, hd, min(q0 >> 5, NB - 1), 0) + lane * 4;
+    float* sw = ssm + wave * 2 * SB_FLOATS;
+    auto dma_scores = [&](int kblk, int slot) {
+        const float* src = srow + (int64_t)kblk * SB_FLOATS;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            __builtin_amdgcn_global_load_lds((glb_vp)(src + gq * 256), (lds_vp)(sw + slot * SB_FLOATS + gq * 256), 16, 0, SRES_DMA_AUX);
+    };
+    const float* gb0 = gm ? gm + (int64_t)b * gm_sb : nullptr;          // uniform
+    float* gw = gsm + wave * SB_FLOATS;
+    const float* grow[4];
+    int gchunk[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = 8 * p + (lane >> 3);
+        grow[p] = gb0 ? gb0 + (int64_t)min(q0 + row, g.T - 1) * gm_st : nullptr;
+        gchunk[p] = 4 * ((lane & 7) ^ ((row >> 1) & 7));
+    }
+    auto dma_g = [&](int k0) {
+        if (gb0 == nullptr) return;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_global_load_lds((glb_vp)(grow[p] + min(k0 + gchunk[p], (int)gm_st - 4)), (lds_vp)(gw + p * 256), 16, 0, 0);
+    };
     dma_tile32(smem, kb, g.st, 0, g.T, wave, lane);
     dma_tile32(smem + DT_FLOATS, vb, g.st, 0, g.T, wave, lane);
+    if (live) {
+        dma_g(0);
+        dma_scores(0, 0);
+        if (32 < g.T) dma_scores(1, 1);
+    }
     float doreg[32];
     rows_from_global(doreg, d_o + obase, g.ost, q0, g.T, r, h, 1.f);
     const bool qok = q0 + r < g.T;
     const float l2q = qok ? lse2[((int64_t)b * g.H + hd) * g.T + q0 + r] : INFINITY;    // queries beyond T: p = exp2(-inf) = 0
     const float dl = qok ? delta[((int64_t)b * g.H + hd) * g.T + q0 + r] : 0.f;
-    const float invH = 1.f / (float)g.H;
-    const float* grow = gm ? gm + (int64_t)b * gm_sb + (int64_t)min(q0 + r, g.T - 1) * gm_st : nullptr;
-    const float* sblk = sres + sres_block(g, NB, b, hd, min(q0 >> 5, NB - 1), 0) + lane * 4;
+    const float invH = gb0 ? 1.f / (float)g.H : 0.f;
     f32x16 dq0 = {0}, dq1 = {0};
     const LaneBasesA lb = lane_bases_a(r, h, smem);
     int doff[2];
     dma_offsets32(doff, g.st, wave, lane);
-    f32x4 sbuf[2][4], gbuf[2][4];                          // [ring slot][register quad]
-    auto load_sg = [&](int k0, f32x4 (&s4)[4], f32x4 (&g4)[4]) {
-        const float* sp = sblk + (int64_t)(k0 >> 5) * SB_FLOATS;
+    const uint32_t saddr = lds_addr_of(sw) + lane * 16;                                 // + slot * 4096 + gq * 1024
+    uint32_t gaddr[4];                                                                  // quad gq = keys 8 gq + 4 h .. + 3 of row r
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) s4[gq] = SRES_LOAD_DQ(sp + gq * 256);
-        if (grow == nullptr) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) g4[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else if (k0 + 32 <= g.T) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) g4[gq] = *reinterpret_cast<const f32x4*>(grow + k0 + 8 * gq + 4 * h);
-        } else {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g4[gq][e] = grow[min(k0 + 8 * gq + 4 * h + e, g.T - 1)];
-        }
-    };
-    if (live) load_sg(0, sbuf[0], gbuf[0]);
+    for (int gq = 0; gq < 4; ++gq) gaddr[gq] = lds_addr_of(gw) + r * 128 + (((2 * gq + h) ^ ((r >> 1) & 7)) << 4);
     LAB_DECL;
     auto step = [&](int k0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int KOFF = SLOT * 2 * DT_FLOATS * 4, VOFF = KOFF + DT_FLOATS * 4;
         LAB_MARK();
-        acr_dma_barrier();
+        // issue order of a live wave's step:  tile(t+1) [4] | G(t+1) [4]  scores(t+2) [4].  At this barrier tile(t) must have
+        // landed; behind it the previous step issued G(t) and scores(t+1).
+        sres_wait_vm((k0 > 0 && live) ? (gb0 ? 4 : 0) + (k0 + 32 < g.T ? 4 : 0) : 0);
+        __syncthreads();
         LAB_ADD(0);
-        __builtin_amdgcn_s_setprio(2);
         if (k0 + 64 <= g.T) {
             dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb + (int64_t)(k0 + 32) * g.st, doff, wave);
             dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb + (int64_t)(k0 + 32) * g.st, doff, wave);
@@ -475,9 +506,8 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk
             dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb, g.st, k0 + 32, g.T, wave, lane);
             dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb, g.st, k0 + 32, g.T, wave, lane);
         }
-        if (!live) { __builtin_amdgcn_s_setprio(0); return; }
-        if (k0 + 32 < g.T) load_sg(k0 + 32, sbuf[SLOT ^ 1], gbuf[SLOT ^ 1]);
-        __builtin_amdgcn_s_setprio(0);
+        SRES_FENCE();
+        if (!live) return;
         LAB_ADD(1);
         f32x16 dp = {0};
         rowop_x<VOFF>(dp, lb, doreg);                      // dP^T[key = krow][query = r]
@@ -485,14 +515,37 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk
         asm volatile("" :: "v"(dp[15]));
 #endif
         LAB_ADD(2);
+        // G(t) must have landed in this wave's tile: behind it are scores(t+1) [4] and this step's tile(t+1) [4]
+        if (k0 > 0) sres_wait_vm(k0 + 32 < g.T ? 8 : 0);
+        f32x4 s4[4], g4[4];
+        ACR_LDS_RD128(s4[0], saddr, SLOT * 4096); ACR_LDS_RD128(s4[1], saddr, SLOT * 4096 + 1024);
+        ACR_LDS_RD128(s4[2], saddr, SLOT * 4096 + 2048); ACR_LDS_RD128(s4[3], saddr, SLOT * 4096 + 3072);
+        if (gb0 != nullptr) {
+            ACR_LDS_RD128(g4[0], gaddr[0], 0); ACR_LDS_RD128(g4[1], gaddr[1], 0);
+            ACR_LDS_RD128(g4[2], gaddr[2], 0); ACR_LDS_RD128(g4[3], gaddr[3], 0);
+            ACR_LDS_WAIT4(0, g4[0], g4[1], g4[2], g4[3]);
+            if (k0 + 32 > g.T) {                           // keys beyond T: their columns hold whatever the row pitch holds
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k0 + 8 * gq + 4 * h + e >= g.T) g4[gq][e] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) g4[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        ACR_LDS_WAIT4(0, s4[0], s4[1], s4[2], s4[3]);
         f32x16 ds;
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float gv = gbuf[SLOT][reg >> 2][reg & 3] * invH;
-            ds[reg] = __builtin_amdgcn_exp2f(sbuf[SLOT][reg >> 2][reg & 3] - l2q) * (dp[reg] + gv - dl);
-        }
+        for (int reg = 0; reg < 16; ++reg)
+            ds[reg] = __builtin_amdgcn_exp2f(s4[reg >> 2][reg & 3] - l2q) * (dp[reg] + g4[reg >> 2][reg & 3] * invH - dl);
         __builtin_amdgcn_s_setprio(0);
+        // the private tiles have been read: refill G for the next step and the score slot for the step AFTER next
+        if (k0 + 32 < g.T) dma_g(k0 + 32);
+        if (k0 + 64 < g.T) dma_scores((k0 >> 5) + 2, SLOT);
+        SRES_FENCE();
         LAB_ADD(3);
         accop_x<KOFF, 0, true>(dq0, ds, lb);               // dQ[query = krow][d = 32*blk + r]
         accop_x<KOFF, 1, true>(dq1, ds, lb);
@@ -519,12 +572,14 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, int bid, int nblk
 }
 
 // ---------------------------------------------------------------------------------------------
-// dK, dV: workgroup = (b, h, 128 keys); V rows of the wave's 32 keys in registers; Q / dO tiles (and the 32 queries' lse2 /
-// delta, one 256-byte DMA) stream through the shared ring; every wave also streams ITS score blocks (q-block j x its key
-// block) by LDS-DMA into a private two-slot ring and reads them transposed (key on the lane).
+// dK, dV: workgroup = (b, h, 128 keys); V rows of the wave's 32 keys in registers; Q / dO tiles stream through the shared ring;
+// every wave streams ITS score blocks (q-block j x its key block) by LDS-DMA into a private two-slot ring two steps ahead and
+// reads them transposed (key on the lane), and ITS 32 x 32 block of G into a private single-slot tile (natural [query][key]
+// rows: the lane's reads are 32 consecutive floats); lse2 / delta of the step's 32 queries are loaded one per lane at the top
+// of the step (consumed behind the 32 MFMAs of dP) and reach the accumulator rows by ds_bpermute.
 //   dP = dO V^T (32 MFMAs)   P = exp2(S - lse2)   dS = P (dP + G/H - delta)   dV += P^T dO (32)   dK += dS^T Q (32)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, float* rc, int bid, int nblk, bool tails, const AttnGeom& g,
+__device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, float* gsm, int bid, int nblk, bool tails, const AttnGeom& g,
                                                     const float* __restrict__ q, const float* __restrict__ v,
                                                     const float* __restrict__ d_o, const float* __restrict__ lse2,
                                                     const float* __restrict__ delta, const float* __restrict__ sres,
@@ -559,23 +614,35 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         for (int gq = 0; gq < 4; ++gq)
             __builtin_amdgcn_global_load_lds((glb_vp)(src + soff[gq]), (lds_vp)(sw + slot * SB_FLOATS + gq * 256), 16, 0, SRES_DMA_AUX);
     };
+    // G block of the step: rows = the 32 queries, 128 bytes = this wave's 32 keys; columns clamped into the row (the last key
+    // block reaches beyond T: those lanes' P is exactly 0 and whatever they compute never leaves their own accumulator row)
+    const float* gb0 = gm ? gm + (int64_t)b * gm_sb : nullptr;          // uniform
+    float* gw = gsm + wave * SB_FLOATS;
+    const int gcol = min(key0 + 4 * (lane & 7), (int)gm_st - 4);
+    auto dma_g = [&](int q0) {
+        if (gb0 == nullptr) return;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float* src = gb0 + (int64_t)min(q0 + 8 * p + (lane >> 3), g.T - 1) * gm_st + gcol;
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(gw + p * 256), 16, 0, 0);
+        }
+    };
     dma_tile32(smem, qb, g.st, 0, g.T, wave, lane);
     dma_tile32(smem + DT_FLOATS, dob, g.ost, 0, g.T, wave, lane);
-    if (wave == 0) dma_rowconst(rc, lrow, drow, 0, g.T, lane);
-    if (live) dma_scores(0, 0);
+    if (live) {
+        dma_g(0);
+        dma_scores(0, 0);
+        if (32 < g.T) dma_scores(1, 1);
+    }
     float vreg[32];
     rows_from_global(vreg, v + base, g.st, key0, g.T, r, h, 1.f);
-    const int key = key0 + r;
-    const float invH = 1.f / (float)g.H;
-    const float* gb0 = gm ? gm + (int64_t)b * gm_sb : nullptr;          // uniform
-    const int glane = min(key, g.T - 1) + 4 * h * (int)gm_st;            // lane part of a G address (krow = c_reg + 4h)
-    const int gcl = min(key, g.T - 1);
+    const float invH = gb0 ? 1.f / (float)g.H : 0.f;
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
     const LaneBasesA lb = lane_bases_a(r, h, smem);
     int qoff[2], dooff[2];                                   // lane parts of the Q / dO tile DMA source addresses (interior tiles)
     dma_offsets32(qoff, g.st, wave, lane);
     dma_offsets32(dooff, g.ost, wave, lane);
-    // transposed score reads: lane (kappa = r, h): byte address = tb[reg & 3] + slot*4096 + 128*(reg >> 2)
+    // transposed score reads: lane (kappa = r, h): LDS byte address = tb[reg & 3] + slot*4096 + 128*(reg >> 2)
     uint32_t tb[4];
     {
         const int gk = r >> 3, hk = (r >> 2) & 1, ek = r & 3, mm = 2 * gk + hk;
@@ -583,51 +650,28 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         for (int j = 0; j < 4; ++j)
             tb[j] = lds_addr_of(ssm) + ((wave * 2 * SB_FLOATS) + gk * 256 + 128 * hk + ek + 4 * ((j + 4 * h) ^ mm)) * 4;
     }
-    const uint32_t rca = lds_addr_of(rc) + 16 * h;           // l4[gq] at + slot*256 + 32 gq, d4[gq] at + slot*256 + 128 + 32 gq
-    float gbuf[2][16];                                      // [ring slot][register]: raw G[b][q0 + krow][key]
-    auto load_g = [&](int q0, float (&gv)[16]) {
-        if (gb0 == nullptr) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) gv[reg] = 0.f;
-        } else if (q0 + 32 <= g.T) {                       // uniform row pointer + lane offset (saddr form loads)
-            const float* gq0 = gb0 + (int64_t)q0 * gm_st;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int c_reg = (reg & 3) + 8 * (reg >> 2);
-                gv[reg] = (gq0 + (int64_t)c_reg * gm_st)[glane];
-            }
-        } else {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) gv[reg] = gb0[(int64_t)min(q0 + acr_krow(reg, h), g.T - 1) * gm_st + gcl];
-        }
-    };
-    if (live) load_g(0, gbuf[0]);
+    const uint32_t gaddr = lds_addr_of(gsm) + (wave * SB_FLOATS + 4 * h * 32 + r) * 4;      // + 128 * c_reg per register
     LAB_DECL;
     auto step = [&](int q0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int QOFF = SLOT * 2 * DT_FLOATS * 4, DOOFF = QOFF + DT_FLOATS * 4;
         LAB_MARK();
-        acr_dma_barrier();
+        // issue order of a live wave's step:  tile(t+1) [4]  lse2 / delta(t) [2 plain loads, consumed in this step] | G(t+1) [4]
+        // scores(t+2) [4].  At this barrier tile(t) must have landed; behind it the previous step issued G(t) and scores(t+1).
+        sres_wait_vm((q0 > 0 && live) ? (gb0 ? 4 : 0) + (q0 + 32 < g.T ? 4 : 0) : 0);
+        __syncthreads();
         LAB_ADD(0);
-        __builtin_amdgcn_s_setprio(2);
-        if (q0 + 32 < g.T) {
-            if (q0 + 64 <= g.T) {                          // next tile fully inside: precomputed lane offsets, uniform base
-                dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, qb + (int64_t)(q0 + 32) * g.st, qoff, wave);
-                dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, dob + (int64_t)(q0 + 32) * g.ost, dooff, wave);
-            } else {
-                dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS, qb, g.st, q0 + 32, g.T, wave, lane);
-                dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, dob, g.ost, q0 + 32, g.T, wave, lane);
-            }
-            if (wave == 0) dma_rowconst(rc + (SLOT ^ 1) * 64, lrow, drow, q0 + 32, g.T, lane);
-            if (live) dma_scores((q0 >> 5) + 1, SLOT ^ 1);
+        if (q0 + 64 <= g.T) {
+            dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, qb + (int64_t)(q0 + 32) * g.st, qoff, wave);
+            dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, dob + (int64_t)(q0 + 32) * g.ost, dooff, wave);
+        } else if (q0 + 32 < g.T) {
+            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS, qb, g.st, q0 + 32, g.T, wave, lane);
+            dma_tile32(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, dob, g.ost, q0 + 32, g.T, wave, lane);
         }
-        __builtin_amdgcn_s_setprio(0);
+        SRES_FENCE();
         if (!live) return;
-        const float* rcs = rc + SLOT * 64;
-        // G of the NEXT query block goes in flight now and is consumed a whole step later: consumed in the step that issues
-        // it, the 16 loads stall the wave for their full latency under the score stream's HBM load -- 10.4k of a 21.6k-cycle
-        // step (scripts/lab/attn_bwd_phases.py, profiles/r03_attn_bwd_phases.txt)
-        if (q0 + 32 < g.T) load_g(q0 + 32, gbuf[SLOT ^ 1]);
+        const int qi = min(q0 + r, g.T - 1);
+        const float lq_lane = lrow[qi], dq_lane = drow[qi];         // this step's lse2 / delta, one query per lane
         LAB_ADD(1);
         f32x16 dp = {0};
         rowop_x<DOOFF>(dp, lb, vreg);                      // dP[query = krow][key = r]
@@ -635,19 +679,27 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         asm volatile("" :: "v"(dp[15]));
 #endif
         LAB_ADD(2);
-        float s[16];
-        f32x4 l4[4], d4[4];
+        // G(t) must have landed in this wave's tile: behind it are scores(t+1) [4], this step's tile(t+1) [4] (and the two plain
+        // loads above, if they are still in flight: 8 is the stricter count)
+        if (q0 > 0) sres_wait_vm(q0 + 32 < g.T ? 8 : 0);
+        float s[16], gv[16];
 #define SRES_RDS(REG) ACR_LDS_RD32(s[REG], tb[(REG) & 3], SLOT * SB_FLOATS * 4 + 128 * ((REG) >> 2))
+#define SRES_RDG(REG) ACR_LDS_RD32(gv[REG], gaddr, 128 * (((REG) & 3) + 8 * ((REG) >> 2)))
         SRES_RDS(0); SRES_RDS(1); SRES_RDS(2); SRES_RDS(3); SRES_RDS(4); SRES_RDS(5); SRES_RDS(6); SRES_RDS(7);
         SRES_RDS(8); SRES_RDS(9); SRES_RDS(10); SRES_RDS(11); SRES_RDS(12); SRES_RDS(13); SRES_RDS(14); SRES_RDS(15);
+        if (gb0 != nullptr) {
+            SRES_RDG(0); SRES_RDG(1); SRES_RDG(2); SRES_RDG(3); SRES_RDG(4); SRES_RDG(5); SRES_RDG(6); SRES_RDG(7);
+            SRES_RDG(8); SRES_RDG(9); SRES_RDG(10); SRES_RDG(11); SRES_RDG(12); SRES_RDG(13); SRES_RDG(14); SRES_RDG(15);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]), "+v"(gv[4]), "+v"(gv[5]), "+v"(gv[6]),
+                         "+v"(gv[7]), "+v"(gv[8]), "+v"(gv[9]), "+v"(gv[10]), "+v"(gv[11]), "+v"(gv[12]), "+v"(gv[13]), "+v"(gv[14]), "+v"(gv[15]));
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = 0.f;
+        }
 #undef SRES_RDS
-        ACR_LDS_RD128(l4[0], rca, SLOT * 256); ACR_LDS_RD128(l4[1], rca, SLOT * 256 + 32);
-        ACR_LDS_RD128(l4[2], rca, SLOT * 256 + 64); ACR_LDS_RD128(l4[3], rca, SLOT * 256 + 96);
-        ACR_LDS_RD128(d4[0], rca, SLOT * 256 + 128); ACR_LDS_RD128(d4[1], rca, SLOT * 256 + 160);
-        ACR_LDS_RD128(d4[2], rca, SLOT * 256 + 192); ACR_LDS_RD128(d4[3], rca, SLOT * 256 + 224);
+#undef SRES_RDG
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]),
-                     "+v"(s[8]), "+v"(s[9]), "+v"(s[10]), "+v"(s[11]), "+v"(s[12]), "+v"(s[13]), "+v"(s[14]), "+v"(s[15]), "+v"(l4[0]),
-                     "+v"(l4[1]), "+v"(l4[2]), "+v"(l4[3]), "+v"(d4[0]), "+v"(d4[1]), "+v"(d4[2]), "+v"(d4[3]));
+                     "+v"(s[8]), "+v"(s[9]), "+v"(s[10]), "+v"(s[11]), "+v"(s[12]), "+v"(s[13]), "+v"(s[14]), "+v"(s[15]));
         if (q0 + 32 > g.T) {                               // last query block: rows beyond T are junk, P = 0 there
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
@@ -656,16 +708,19 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         f32x16 p, ds;
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {                   // krow(4 gq + e, h) = 8 gq + 4 h + e: four consecutive queries
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int reg = 4 * gq + e;
-                const float pv = __builtin_amdgcn_exp2f(s[reg] - l4[gq][e]);
-                p[reg] = pv;
-                ds[reg] = pv * (dp[reg] + gbuf[SLOT][reg] * invH - d4[gq][e]);
-            }
+        for (int reg = 0; reg < 16; ++reg) {
+            const int src = acr_krow(reg, h);              // lane that holds this accumulator row's query
+            const float lq = __shfl(lq_lane, src), dq_ = __shfl(dq_lane, src);
+            const float pv = __builtin_amdgcn_exp2f(s[reg] - lq);
+            p[reg] = pv;
+            ds[reg] = pv * (dp[reg] + gv[reg] * invH - dq_);
         }
         __builtin_amdgcn_s_setprio(0);
+        // the private tiles have been read: refill G for the next step and the score slot for the step AFTER next
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (q0 + 32 < g.T) dma_g(q0 + 32);
+        if (q0 + 64 < g.T) dma_scores((q0 >> 5) + 2, SLOT);
+        SRES_FENCE();
         LAB_ADD(3);
         accop_x<DOOFF, 0, true>(dv0, p, lb);               // dV[key = krow][d = 32*blk + r]
         accop_x<DOOFF, 1, true>(dv1, p, lb);
@@ -911,15 +966,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_sres_kernel(AttnGeom g, const
                                                                int64_t gm_sb, int64_t gm_st, float* __restrict__ dq,
                                                                float* __restrict__ dk, float* __restrict__ dv, int ntail) {
     __shared__ __attribute__((aligned(1024))) float smem[4 * DT_FLOATS];       // [slot][Q | dO]  resp.  [slot][K | V]
-    __shared__ __attribute__((aligned(1024))) float ssm[4 * 2 * SB_FLOATS];    // dK/dV: [wave][slot] score blocks
-    __shared__ __attribute__((aligned(256))) float rc[2 * 64];                 // dK/dV: [slot][lse2 x 32 | delta x 32]
+    __shared__ __attribute__((aligned(1024))) float ssm[4 * 2 * SB_FLOATS];    // [wave][slot] score blocks (both bodies)
+    __shared__ __attribute__((aligned(1024))) float gsm[4 * SB_FLOATS];        // [wave] G block (both bodies); 80 KB in all: two per CU
     // grid: [dK/dV full | dQ full | dK/dV split tails | dQ split tails]; tails (one per (b, h) and sweep) are dispatched last
     const int half = ((int)gridDim.x - 2 * ntail) >> 1;
     const int bid = (int)blockIdx.x;
     if (bid < half)
-        attn_dkdv_sres_body(smem, ssm, rc, bid, half, ntail != 0, g, q, v, d_o, lse2, delta, sres, gm, gm_sb, gm_st, dk, dv);
+        attn_dkdv_sres_body(smem, ssm, gsm, bid, half, ntail != 0, g, q, v, d_o, lse2, delta, sres, gm, gm_sb, gm_st, dk, dv);
     else if (bid < 2 * half)
-        attn_dq_sres_body(smem, bid - half, half, ntail != 0, g, k, v, d_o, lse2, delta, sres, gm, gm_sb, gm_st, dq);
+        attn_dq_sres_body(smem, ssm, gsm, bid - half, half, ntail != 0, g, k, v, d_o, lse2, delta, sres, gm, gm_sb, gm_st, dq);
     else if (bid < 2 * half + ntail)
         attn_dkdv_tail_body(smem, ssm, g, q, v, d_o, lse2, delta, sres, gm, gm_sb, gm_st, dk, dv, acr_xcd_remap(bid - 2 * half, ntail));
     else

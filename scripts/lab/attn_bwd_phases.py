@@ -4,7 +4,7 @@ import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from acr_wsss_amd import _lib as L
-L.LIB_PATH = os.path.join(ROOT, "scripts", "lab", "_build", "libacr_hip_tl.so")
+L.LIB_PATH = os.path.join(ROOT, "scripts", "lab", "_build", "libacr_srestl.so")
 from acr_wsss_amd import ops
 raw = ctypes.CDLL(L.LIB_PATH)
 dev = torch.device("cuda:0")
