@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
     else tile_coords(tt, g.tiles_m, g.tiles_n, tm, tn);
     const int m0 = tm * F_BM, n0 = tn * F_BN;
     const int zs = split / g.ksplit;
-    const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);      // host: (kend - kbeg) % 32 == 0
+    const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);      // host: (kend - kbeg) % 16 == 0
     const float* __restrict__ pa = g.a + (int64_t)zs * g.a_zs;
     const float* __restrict__ pb = g.b + (int64_t)zs * g.b_zs;
     f32x16 acc[2][2];
@@ -961,7 +961,9 @@ extern "C" int acr_conv1x1_wgrad_f32(int32_t math, const float* dy, const float*
     g.nsplit = nsamp * ks;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.nsplit));
     ACR_CHECK_ARG(math == ACR_MATH_F32 || math == ACR_MATH_BF16X3, "acr_conv1x1_wgrad_f32: bad math %d", math);
-    if ((hw % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && math == ACR_MATH_BF16X3)
+    // the split-product kernel advances in 16-deep stages: pixel counts that are multiples of 16 suffice (28 x 28 = 784 = 49 x 16
+    // took the register-staged exact kernel before: 2.6 ms of the f32_split step)
+    if ((hw % S_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && math == ACR_MATH_BF16X3)
         hipLaunchKernelGGL((gemm_f32_split_kernel<true, true, 3>), grid, dim3(256), 0, st, g);
     else if ((hw % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0)
         hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 3>), grid, dim3(256), 0, st, g);
