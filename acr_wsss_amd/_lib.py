@@ -74,6 +74,10 @@ SIGNATURES = {
     "acr_conv1x1_f32": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "acr_conv1x1_wgrad_f32_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "acr_conv1x1_wgrad_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "acr_conv3x3_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "acr_conv3x3_wgrad_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "acr_conv3x3_wgrad_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                        c_void_p]),
     "acr_maxpool3x3s2_fwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                             c_int32, c_void_p]),
     "acr_maxpool3x3s2_bwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,

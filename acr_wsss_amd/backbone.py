@@ -72,6 +72,8 @@ class StdConv2dSame(nn.Conv2d):
         w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
         if self.hip_1x1 and ops.conv1x1_fusable(x, w_hat, self.stride[0]):
             return ops.conv1x1(x, w_hat, self._w_hat_t, self.acr_math)     # NCHW 1x1 conv = per-sample MFMA GEMM, no layout transposes
+        if self.hip_3x3 and not self.dynamic_pad and ops.conv3x3_fusable(x, w_hat, self.stride[0], self.acr_math):
+            return ops.conv3x3(x, w_hat)                                   # split-product implicit GEMM, no layout transposes
         return F.conv2d(x, w_hat, None, self.stride, self.padding)
 
     def forward_skip(self, x):
@@ -83,6 +85,7 @@ class StdConv2dSame(nn.Conv2d):
         return self.forward(x), x
 
     hip_1x1 = True
+    hip_3x3 = os.environ.get("ACR_CONV3X3_HIP", "1") != "0"      # A/B: the stem's 3x3 convolutions under f32_split on csrc/conv3x3.hip
     acr_math = 0            # _lib.MATH code of the fp32 products (set_math)
 
     _w_hat = None           # set for one forward by ResNetV2 when all weights are standardised in one fused launch

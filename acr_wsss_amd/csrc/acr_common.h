@@ -36,6 +36,15 @@ __device__ __forceinline__ void acr_dma_barrier() {
 }
 
 // ---- XCD-aware block remap --------------------------------------------------------------------
+// Workgroup barrier WITHOUT __syncthreads()'s fences, for loops that keep LDS-DMA (`global_load_lds`) in flight across it.
+// __syncthreads() = release fence + s_barrier + acquire fence, and hipcc implements the workgroup-scope release of LDS as "every
+// outstanding LDS-DMA has landed": it puts `s_waitcnt vmcnt(0)` in front of the barrier whenever a DMA may be pending (found in
+// the ISA of every ring kernel, round 4) -- a ring that is N stages ahead degenerates to "wait for the newest stage every step".
+// Contract of this one: the caller has waited (counted `s_waitcnt vmcnt(n)`) for the DMA pieces the OTHER waves are about to read,
+// and `s_waitcnt lgkmcnt(0)` for its own ds_write / ds_read where another wave overwrites or reads those addresses next.
+// The "memory" clobber keeps the compiler from moving memory accesses across it.
+__device__ __forceinline__ void acr_barrier_nofence() { asm volatile("s_barrier" ::: "memory"); }
+
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap the
 // linear block id so that each XCD walks one contiguous chunk of the work list: neighbouring
 // tiles (same batch/head -> same K/V panels) then hit the same 4 MiB L2.  Bijective for any n.

@@ -1,0 +1,421 @@
+// 3x3 stride-1 SAME convolutions of the ResNetV2 stem (models/resnetv2.py:171-216 conv2 of every bottleneck;
+// models/layers/std_conv.py:40-65) in NCHW fp32 with SPLIT PRODUCTS (acr_math ACR_MATH_BF16X3) as implicit GEMMs on the bf16
+// MFMA -- the last library code on the f32_split step's hot path were MIOpen's Winograd / implicit-GEMM kernels and their
+// NCHW <-> NHWC transposes.  No im2col buffer, no layout change:
+//
+//   forward   y[n][co][p] = sum_t sum_ci Wp[co][t*Cin + ci] * x[n][ci][p + off_t] * valid_t(p)      off_t = (ty-1) W + (tx-1)
+//   input     dx = the same kernel on dy with Wd[ci][t'*Cout + co] = w[co][ci][8 - t']              (taps flipped, roles swapped)
+//   weight    dWp[co][t*Cin + ci] = sum_n sum_p dy[n][co][p] * x[n][ci][p + off_t] * valid_t(p)    (conv3x3_wgrad_split_kernel)
+//
+// GEMM view of the forward, per sample: M = output channels, N = the H*W pixels in flattened order (tiles of 128 consecutive
+// pixels), K = 9 Cin in 16-deep stages that never straddle a tap (Cin % 16 == 0).  The A operand is the packed weight, read
+// exactly like a Linear's (k contiguous: gemm_f32.hip's KC image).  The B operand of a stage is 16 channel rows x 128 pixels
+// SHIFTED by the stage's tap offset: an LDS-DMA whose source address is only 4-byte aligned for the +-1 column taps (measured
+// to work: scripts/lab/micro/dma_unaligned.hip); pixels whose tap falls outside the image are zeroed in registers on the
+// fragment (8 v_cndmask per fragment, a per-lane 9-bit validity mask computed once) right before the three-way split.
+// Shifted reads run up to W + 1 floats before a sample's first channel row and up to 128 + W + 1 floats past its last one:
+// inside the tensor that is the neighbouring channel / sample (values masked), at the tensor's two ends it is the
+// ACR_CONV3X3_PAD floats of readable memory the CALLER guarantees on either side (contents irrelevant; ops.py allocates the
+// producers' outputs with that margin).  Arithmetic, tile structure, ring and counted waits are gemm_f32_split_kernel's.
+#include <type_traits>
+
+#include "acr_common.h"
+
+#define C3_BM 128
+#define C3_BN 128
+#define C3_BK 16
+#define C3_TILE (C3_BM * C3_BK)      // floats per operand per stage (8 KiB)
+#define C3_SLOTS 4
+
+typedef __attribute__((address_space(3))) void* c3_lds_vp;
+typedef const __attribute__((address_space(1))) void* c3_glb_vp;
+
+struct Conv3Args {
+    const float* w;                  // packed weights (M, 9 * C): w[m][t * C + c]
+    const float* x;                  // (nsamp, C, H * W)
+    float* y;                        // (nsamp, M, H * W)
+    int M, C, H, W, HW, nsamp;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void c3_split3(const f32x4& lo4, const f32x4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? lo4[e] : hi4[e - 4];
+        const __bf16 h0 = (__bf16)x;
+        const float r1 = x - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;
+        p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)r2;
+    }
+}
+#define C3_MFMA6(ACC, A, Bv)                                                         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bv[2], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bv[0], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bv[1], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bv[1], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bv[0], ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bv[0], ACC, 0, 0, 0);
+
+// 9-bit validity mask of pixel p: bit t set iff tap t of p lies inside the image
+__device__ __forceinline__ int c3_valid9(int p, int H, int W, int HW) {
+    if (p >= HW) return 0;
+    const int y = p / W, x = p - y * W;
+    int m = 0;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            const int yy = y + ty - 1, xx = x + tx - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) m |= 1 << (ty * 3 + tx);
+        }
+    return m;
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const Conv3Args g) {
+    __shared__ __attribute__((aligned(1024))) float smem[C3_SLOTS * 2 * C3_TILE];      // [slot][A | B], 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int t0 = acr_xcd_remap(blockIdx.x, ntile * g.nsamp);
+    const int sample = t0 / ntile, tt = t0 - sample * ntile;
+    const int tn = tt / g.tiles_m, tm = tt - tn * g.tiles_m;               // the tile rows of one pixel tile are neighbours
+    const int m0 = tm * C3_BM, n0 = tn * C3_BN;
+    const int lda = 9 * g.C;
+    const float* __restrict__ pa = g.w;
+    const float* __restrict__ pb = g.x + (int64_t)sample * g.C * g.HW;
+    const bool compute = m0 + wm * 64 < g.M;                               // Cout = 64: the lower wave row has no outputs
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // A: piece = 16 rows x 64 bytes, lane -> (row = l >> 2, 16-byte chunk l & 3), chunk XOR-swizzled by (row >> 2) & 3 on the source
+    int offa[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + (lane >> 2);
+        offa[i] = min(m0 + row, g.M - 1) * lda + (((lane & 3) ^ ((row >> 2) & 3)) << 2);
+    }
+    // B: piece = 2 channel rows of 128 pixels; lane -> (row = l >> 5, pixels 4 (l & 31) .. + 3)
+    int rowb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rowb[i] = ((wave * 2 + i) * 2 + (lane >> 5)) * g.HW;
+    const int pix = n0 + 4 * (lane & 31);
+    const int valid0 = c3_valid9(n0 + wn * 64 + r, g.H, g.W, g.HW), valid1 = c3_valid9(n0 + wn * 64 + 32 + r, g.H, g.W, g.HW);
+    const int nst = lda / C3_BK;
+    auto issue = [&](int st) {
+        float* d = smem + (st & (C3_SLOTS - 1)) * 2 * C3_TILE;
+        const int k0 = st * C3_BK;
+        const int tap = k0 / g.C, ci0 = k0 - tap * g.C;                    // uniform
+        const int ty = tap / 3, off = (ty - 1) * g.W + (tap - 3 * ty - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((c3_glb_vp)(pa + k0 + offa[i]), (c3_lds_vp)(d + (wave * 2 + i) * 256), 16, 0, 0);
+        const float* xb = pb + (int64_t)ci0 * g.HW + (pix + off);                // may leave the sample at its ends: see the header
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((c3_glb_vp)(xb + rowb[i]), (c3_lds_vp)(d + C3_TILE + (wave * 2 + i) * 256), 16, 0, 0);
+    };
+#pragma unroll
+    for (int st = 0; st < C3_SLOTS - 1; ++st)
+        if (st < nst) issue(st);
+    bf16x8 ap[2][2][3], bp[2][2][3];                        // [register set][block][piece]
+    f32x4 ra[2][2], rb[2][2];
+#define C3_ALL(SET)                                                                                 \
+    C3_MFMA6(acc[0][0], ap[SET][0], bp[SET][0]) C3_MFMA6(acc[0][1], ap[SET][0], bp[SET][1])        \
+    C3_MFMA6(acc[1][0], ap[SET][1], bp[SET][0]) C3_MFMA6(acc[1][1], ap[SET][1], bp[SET][1])
+    // stage st: wait until it has landed (stages st+1, st+2 may stay in flight: 4 DMA instructions each), publish it, refill the
+    // slot stage st-1 was read from, read + mask + split stage st into register set SET while the MFMAs of stage st-1 (set SET^1) run
+    auto step = [&](int st, auto set_tag, auto first_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + C3_SLOTS - 1 < nst) issue(st + C3_SLOTS - 1);
+        if (!compute) return;
+        const float* sa = smem + (st & (C3_SLOTS - 1)) * 2 * C3_TILE;
+        const float* sb = sa + C3_TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + r, sw = (row >> 2) & 3;
+            ra[i][0] = *reinterpret_cast<const f32x4*>(sa + row * C3_BK + (((2 * h) ^ sw) << 2));
+            ra[i][1] = *reinterpret_cast<const f32x4*>(sa + row * C3_BK + (((2 * h + 1) ^ sw) << 2));
+        }
+        const int tap = (st * C3_BK) / g.C;                 // uniform
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* p = sb + (8 * h) * C3_BN + wn * 64 + j * 32 + r;
+            const bool ok = (((j ? valid1 : valid0) >> tap) & 1) != 0;
+            rb[j][0] = f32x4{p[0], p[C3_BN], p[2 * C3_BN], p[3 * C3_BN]};
+            rb[j][1] = f32x4{p[4 * C3_BN], p[5 * C3_BN], p[6 * C3_BN], p[7 * C3_BN]};
+            if (!ok) { rb[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; rb[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) c3_split3(ra[i][0], ra[i][1], ap[SET][i][0], ap[SET][i][1], ap[SET][i][2]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c3_split3(rb[j][0], rb[j][1], bp[SET][j][0], bp[SET][j][1], bp[SET][j][2]);
+        if (!FIRST) {
+            C3_ALL(SET ^ 1)
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA of stage st - 1
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // eight VALU instructions of stage st's split
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    step(0, std::integral_constant<int, 0>{}, std::true_type{});
+    for (int st = 1; st < nst; st += 2) {
+        step(st, std::integral_constant<int, 1>{}, std::false_type{});
+        if (st + 1 < nst) step(st + 1, std::integral_constant<int, 0>{}, std::false_type{});
+    }
+    if (!compute) return;
+    if (nst & 1) { C3_ALL(0) } else { C3_ALL(1) }
+    // ---- epilogue: lane (r, h), register e of a 32x32 accumulator = row krow(e, h), column (pixel) r
+    float* yb = g.y + (int64_t)sample * g.M * g.HW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + acr_krow(e, h);
+                if (row < g.M && col < g.HW) yb[(int64_t)row * g.HW + col] = acc[i][j][e];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// weight gradient: c[co][t*C + ci] = sum_p dy[co][p] * x[ci][p + off_t] * valid_t(p) per (sample, pixel part) into fp32 slabs,
+// summed in a fixed order afterwards.  Both operands are contiguous in the contraction index p (gemm_f32.hip's KC images): A rows
+// = dy's channels, B rows = the 9 C (tap, channel) pairs, each an x channel row SHIFTED by its tap's offset (per-lane source
+// pointers, 4-byte aligned).  The validity of a tap varies ALONG the contraction here: every lane's fragment is 8 consecutive
+// pixels of one (tap, channel) row, handled as two halves of 4 -- image rows are multiples of 4 pixels long, so a half never
+// straddles an image row: one row test per half, and only its first (tx = 0) or last (tx = 2) element can touch the column border.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct Conv3WgArgs {
+    const float* dy;                 // (nsamp, M, HW)
+    const float* x;                  // (nsamp, C, HW)
+    float* ws;                       // slabs (nsamp * ksplit, M, 9 C)
+    int M, C, H, W, HW, nsamp, ksplit, kps;
+    int tiles_m, tiles_n;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const Conv3WgArgs g) {
+    __shared__ __attribute__((aligned(1024))) float smem[C3_SLOTS * 2 * C3_TILE];      // [slot][A | B], 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int ntile = g.tiles_m * g.tiles_n, nsplit = g.nsamp * g.ksplit;
+    const int t0 = acr_xcd_remap(blockIdx.x, ntile * nsplit);
+    const int split = t0 / ntile, tt = t0 - split * ntile;
+    const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
+    const int m0 = tm * C3_BM, n0 = tn * C3_BN;
+    const int sample = split / g.ksplit;
+    const int kbeg = (split - sample * g.ksplit) * g.kps, kend = min(g.HW, kbeg + g.kps);        // host: (kend - kbeg) % 16 == 0
+    const int N9 = 9 * g.C;
+    const float* __restrict__ pa = g.dy + (int64_t)sample * g.M * g.HW;
+    const float* __restrict__ pb = g.x + (int64_t)sample * g.C * g.HW;
+    const bool compute = m0 + wm * 64 < g.M && n0 + wn * 64 < N9;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // DMA pieces: 16 rows x 64 bytes, lane -> (row = l >> 2, 16-byte chunk l & 3), chunk XOR-swizzled by (row >> 2) & 3 on the source
+    int offa[2], offb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + (lane >> 2);
+        const int lc4 = ((lane & 3) ^ ((row >> 2) & 3)) << 2;
+        offa[i] = min(m0 + row, g.M - 1) * g.HW + lc4;
+        const int nr = min(n0 + row, N9 - 1);               // (tap, channel) row of B
+        const int tap = nr / g.C, ci = nr - tap * g.C;
+        const int ty = tap / 3;
+        offb[i] = ci * g.HW + (ty - 1) * g.W + (tap - 3 * ty - 1) + lc4;
+    }
+    // the lane's two B fragments: rows n0 + wn*64 + j*32 + r -> their taps
+    int tyj[2], txj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nr = min(n0 + wn * 64 + j * 32 + r, N9 - 1);
+        const int tap = nr / g.C;
+        tyj[j] = tap / 3;
+        txj[j] = tap - 3 * tyj[j];
+    }
+    int xh0 = (kbeg + 8 * h) % g.W, xh1 = (kbeg + 8 * h + 4) % g.W;      // column of the first pixel of the lane's two halves
+    const int nst = (kend - kbeg) / C3_BK;
+    auto issue = [&](int st) {
+        float* d = smem + (st & (C3_SLOTS - 1)) * 2 * C3_TILE;
+        const int k0 = kbeg + st * C3_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((c3_glb_vp)(pa + k0 + offa[i]), (c3_lds_vp)(d + (wave * 2 + i) * 256), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((c3_glb_vp)(pb + k0 + offb[i]), (c3_lds_vp)(d + C3_TILE + (wave * 2 + i) * 256), 16, 0, 0);
+    };
+#pragma unroll
+    for (int st = 0; st < C3_SLOTS - 1; ++st)
+        if (st < nst) issue(st);
+    bf16x8 ap[2][2][3], bp[2][2][3];
+    f32x4 ra[2][2], rb[2][2];
+    auto step = [&](int st, auto set_tag, auto first_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + C3_SLOTS - 1 < nst) issue(st + C3_SLOTS - 1);
+        if (!compute) return;
+        const float* sa = smem + (st & (C3_SLOTS - 1)) * 2 * C3_TILE;
+        const float* sb = sa + C3_TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + r, sw = (row >> 2) & 3;
+            ra[i][0] = *reinterpret_cast<const f32x4*>(sa + row * C3_BK + (((2 * h) ^ sw) << 2));
+            ra[i][1] = *reinterpret_cast<const f32x4*>(sa + row * C3_BK + (((2 * h + 1) ^ sw) << 2));
+        }
+        const int p0 = kbeg + st * C3_BK + 8 * h;           // first pixel of the lane's fragment
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wn * 64 + j * 32 + r, sw = (row >> 2) & 3;
+            rb[j][0] = *reinterpret_cast<const f32x4*>(sb + row * C3_BK + (((2 * h) ^ sw) << 2));
+            rb[j][1] = *reinterpret_cast<const f32x4*>(sb + row * C3_BK + (((2 * h + 1) ^ sw) << 2));
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int p = p0 + 4 * hf, xc = hf ? xh1 : xh0;
+                const bool yok = tyj[j] == 1 || (tyj[j] == 0 ? p >= g.W : p < g.HW - g.W);
+                const bool kf = txj[j] == 0 && xc == 0, kl = txj[j] == 2 && xc + 4 == g.W;
+                f32x4 v = rb[j][hf];
+                if (!yok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kf) v[0] = 0.f;
+                if (kl) v[3] = 0.f;
+                rb[j][hf] = v;
+            }
+        }
+        xh0 += C3_BK; if (xh0 >= g.W) xh0 -= g.W;
+        xh1 += C3_BK; if (xh1 >= g.W) xh1 -= g.W;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) c3_split3(ra[i][0], ra[i][1], ap[SET][i][0], ap[SET][i][1], ap[SET][i][2]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c3_split3(rb[j][0], rb[j][1], bp[SET][j][0], bp[SET][j][1], bp[SET][j][2]);
+        if (!FIRST) {
+            C3_ALL(SET ^ 1)
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    step(0, std::integral_constant<int, 0>{}, std::true_type{});
+    for (int st = 1; st < nst; st += 2) {
+        step(st, std::integral_constant<int, 1>{}, std::false_type{});
+        if (st + 1 < nst) step(st + 1, std::integral_constant<int, 0>{}, std::false_type{});
+    }
+    if (!compute) return;
+    if (nst & 1) { C3_ALL(0) } else { C3_ALL(1) }
+    float* slab = g.ws + (int64_t)split * g.M * N9;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + acr_krow(e, h);
+                if (row < g.M && col < N9) slab[(int64_t)row * N9 + col] = acc[i][j][e];
+            }
+        }
+}
+
+// out[i] = sum_s slab[s][i] in slab order (deterministic), float4 per thread
+__global__ __launch_bounds__(256) void conv3x3_reduce_kernel(const float* __restrict__ ws, int nslab, int64_t n4, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = reinterpret_cast<const f32x4*>(ws)[i];
+    for (int k = 1; k < nslab; ++k) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(ws)[(int64_t)k * n4 + i];
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+static int c3_wgrad_ksplit(int nsamp, int cout, int cin, int HW) {
+    const int tiles = ((cout + C3_BM - 1) / C3_BM) * ((9 * cin + C3_BN - 1) / C3_BN) * nsamp;
+    int ks = 512 / tiles;
+    const int maxs = HW / 1024;
+    if (ks > maxs) ks = maxs;
+    if (ks < 1) ks = 1;
+    const int kps = ((HW + ks - 1) / ks + 31) / 32 * 32;
+    return (HW + kps - 1) / kps;
+}
+extern "C" size_t acr_conv3x3_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W) {
+    return (size_t)nsamp * c3_wgrad_ksplit(nsamp, cout, cin, H * W) * cout * 9 * cin;
+}
+
+extern "C" int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t H,
+                                     int32_t W, float* ws, float* dw_packed, void* stream) {
+    ACR_CHECK_ARG(dy && x && ws && dw_packed, "acr_conv3x3_wgrad_f32: null pointer");
+    if (math != ACR_MATH_BF16X3) {
+        acr_set_error("acr_conv3x3_wgrad_f32: built for ACR_MATH_BF16X3 only");
+        return ACR_ERR_UNSUPPORTED;
+    }
+    const int HW = H * W;
+    ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && (cout % 4) == 0 && (cin % 4) == 0 && H > 0 && W > 0 && (W % 4) == 0 && W >= C3_BK &&
+                      (HW % C3_BK) == 0,
+                  "acr_conv3x3_wgrad_f32: need cout, cin %% 4 == 0, W %% 4 == 0, W >= 16, H*W %% 16 == 0 (n=%d co=%d ci=%d %dx%d)", nsamp, cout, cin, H, W);
+    ACR_CHECK_ARG(W + C3_BN + 1 <= ACR_CONV3X3_PAD, "acr_conv3x3_wgrad_f32: W = %d exceeds the margin ACR_CONV3X3_PAD covers", W);
+    ACR_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)dw_packed & 15) == 0,
+                  "acr_conv3x3_wgrad_f32: 16-byte alignment");
+    ACR_CHECK_ARG((int64_t)cout * HW < (1ll << 30) && (int64_t)cin * HW < (1ll << 30), "acr_conv3x3_wgrad_f32: operand too large for 32-bit offsets");
+    Conv3WgArgs g;
+    g.dy = dy; g.x = x; g.ws = ws; g.M = cout; g.C = cin; g.H = H; g.W = W; g.HW = HW; g.nsamp = nsamp;
+    g.ksplit = c3_wgrad_ksplit(nsamp, cout, cin, HW);
+    g.kps = ((HW + g.ksplit - 1) / g.ksplit + 31) / 32 * 32;
+    g.tiles_m = (cout + C3_BM - 1) / C3_BM; g.tiles_n = (9 * cin + C3_BN - 1) / C3_BN;
+    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp * g.ksplit;
+    ACR_CHECK_ARG(nwg < (1ll << 31), "acr_conv3x3_wgrad_f32: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv3x3_wgrad_split_kernel, dim3((unsigned)nwg), dim3(256), 0, st, g);
+    const int64_t n4 = (int64_t)cout * 9 * cin / 4;
+    hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsamp * g.ksplit, n4,
+                       dw_packed);
+    return acr_check_launch("acr_conv3x3_wgrad_f32");
+}
+
+extern "C" int acr_conv3x3_f32(int32_t math, const float* w_packed, const float* x, float* y, int32_t nsamp, int32_t cout, int32_t cin,
+                               int32_t H, int32_t W, void* stream) {
+    ACR_CHECK_ARG(w_packed && x && y, "acr_conv3x3_f32: null pointer");
+    if (math != ACR_MATH_BF16X3) {
+        acr_set_error("acr_conv3x3_f32: built for ACR_MATH_BF16X3 only (the exact-fp32 arithmetic keeps the library's Winograd kernels: "
+                      "F(2,3) does 2.25x fewer multiplies than an implicit GEMM on the fp32 MFMA)");
+        return ACR_ERR_UNSUPPORTED;
+    }
+    ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && (cin % C3_BK) == 0 && H > 0 && W > 0 && ((int64_t)H * W) % 4 == 0 && (int64_t)H * W >= 4,
+                  "acr_conv3x3_f32: need cin %% 16 == 0 and H*W %% 4 == 0 (n=%d co=%d ci=%d %dx%d)", nsamp, cout, cin, H, W);
+    ACR_CHECK_ARG(W + C3_BN + 1 <= ACR_CONV3X3_PAD, "acr_conv3x3_f32: W = %d exceeds the margin ACR_CONV3X3_PAD covers", W);
+    ACR_CHECK_ARG(((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "acr_conv3x3_f32: 16-byte alignment");
+    ACR_CHECK_ARG((int64_t)cout * 9 * cin < (1ll << 30) && (int64_t)cin * H * W < (1ll << 30), "acr_conv3x3_f32: operand too large for 32-bit offsets");
+    Conv3Args g;
+    g.w = w_packed; g.x = x; g.y = y; g.M = cout; g.C = cin; g.H = H; g.W = W; g.HW = H * W; g.nsamp = nsamp;
+    g.tiles_m = (cout + C3_BM - 1) / C3_BM; g.tiles_n = (g.HW + C3_BN - 1) / C3_BN;
+    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp;
+    ACR_CHECK_ARG(nwg < (1ll << 31), "acr_conv3x3_f32: grid too large");
+    hipLaunchKernelGGL(conv3x3_split_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
+    return acr_check_launch("acr_conv3x3_f32");
+}

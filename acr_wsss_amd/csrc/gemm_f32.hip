@@ -552,6 +552,40 @@ __device__ __forceinline__ void split_frag8(const float* __restrict__ s, int bas
     }
 }
 
+// The same fragment through inline-asm LDS reads.  hipcc cannot tell an LDS-DMA's LDS write from a read of another ring slot:
+// in front of the first compiler-visible LDS load behind a DMA it waits for ALL outstanding vector-memory operations
+// (`s_waitcnt vmcnt(0)`, found in the ISA right before the stage barrier) -- which turned the three-stages-ahead ring into a
+// one-stage-ahead one: every stage waited for the DMAs issued one stage earlier.  asm reads are invisible to that analysis; the
+// counted vmcnt wait + barrier in front of them and the lgkmcnt wait behind them (SPLIT_LDS_WAIT8) are the synchronisation.
+// Lane bases (LDS byte addresses inside slot 0's A resp. B tile): KC two per fragment (the two swizzled 16-byte chunks), KS one.
+template <bool KC>
+__device__ __forceinline__ void split_frag_bases(uint32_t (&b)[2], const float* tile0, int base, int r, int h) {
+    typedef const __attribute__((address_space(3))) char* lds_cp;
+    const uint32_t t = (uint32_t)(uintptr_t)(lds_cp)tile0;
+    if (KC) {
+        const int row = base + r, sw = (row >> 2) & 3;
+        b[0] = t + row * (S_BK * 4) + (((2 * h) ^ sw) << 4);
+        b[1] = t + row * (S_BK * 4) + (((2 * h + 1) ^ sw) << 4);
+    } else {
+        b[0] = b[1] = t + ((8 * h) * F_BM + base + r) * 4;
+    }
+}
+#define SPLIT_RD128(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=&v"(dst) : "v"(addr))
+#define SPLIT_RD32(dst, addr, OFF) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
+template <bool KC>
+__device__ __forceinline__ void split_frag8_x(const uint32_t (&b)[2], uint32_t slot_off, f32x4& lo4, f32x4& hi4) {
+    if (KC) {
+        SPLIT_RD128(lo4, b[0] + slot_off);
+        SPLIT_RD128(hi4, b[1] + slot_off);
+    } else {
+        const uint32_t a = b[0] + slot_off;
+        SPLIT_RD32(lo4[0], a, 0); SPLIT_RD32(lo4[1], a, F_BM * 4); SPLIT_RD32(lo4[2], a, 2 * F_BM * 4); SPLIT_RD32(lo4[3], a, 3 * F_BM * 4);
+        SPLIT_RD32(hi4[0], a, 4 * F_BM * 4); SPLIT_RD32(hi4[1], a, 5 * F_BM * 4); SPLIT_RD32(hi4[2], a, 6 * F_BM * 4); SPLIT_RD32(hi4[3], a, 7 * F_BM * 4);
+    }
+}
+#define SPLIT_LDS_WAIT8(a0, a1, a2, a3, a4, a5, a6, a7) \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7))
+
 template <bool A_KC, bool B_KC, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Args g) {
     __shared__ __attribute__((aligned(1024))) float smem[S_SLOTS * 2 * S_TILE];      // [slot][A | B], 64 KiB
@@ -583,6 +617,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
     split_dma_offsets<B_KC>(offb, g.ldb, n0, g.N, wave, lane);
     const int64_t ka = A_KC ? 1 : g.lda, kb = B_KC ? 1 : g.ldb;      // operand advance per contraction index
     const int nst = (kend - kbeg) / S_BK;
+    uint32_t fa[2][2], fb[2][2];                             // fragment lane bases in slot 0
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        split_frag_bases<A_KC>(fa[i], smem, wm * 64 + i * 32, r, h);
+        split_frag_bases<B_KC>(fb[i], smem + S_TILE, wn * 64 + i * 32, r, h);
+    }
+    const uint32_t cs_base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem + ((tid >> 7) * F_BM + (tid & 127)) * 4;
     auto issue = [&](int st) {
         float* d = smem + (st & (S_SLOTS - 1)) * 2 * S_TILE;
         split_dma_stage(d, pa + (int64_t)(kbeg + st * S_BK) * ka, offa, wave);
@@ -610,21 +651,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
     auto step = [&](int st, auto set_tag, auto first_tag) {
         constexpr int SET = decltype(set_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
+#ifdef SPLIT_SPREAD
+        if (nst >= S_SLOTS) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#endif
+        acr_barrier_nofence();                              // stage st landed for every wave; all reads of stage st - 1 were waited for (SPLIT_LDS_WAIT8)
+#ifndef SPLIT_SPREAD
         if (st + S_SLOTS - 1 < nst) issue(st + S_SLOTS - 1);
-        const float* sa = smem + (st & (S_SLOTS - 1)) * 2 * S_TILE;
-        const float* sb = sa + S_TILE;
+#else
+        if (FIRST && st + S_SLOTS - 1 < nst) issue(st + S_SLOTS - 1);
+#endif
+        const uint32_t so = (uint32_t)(st & (S_SLOTS - 1)) * (2 * S_TILE * 4);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) split_frag8<A_KC>(sa, wm * 64 + i * 32, r, h, ra[i][0], ra[i][1]);
+        for (int i = 0; i < 2; ++i) split_frag8_x<A_KC>(fa[i], so, ra[i][0], ra[i][1]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) split_frag8<B_KC>(sb, wn * 64 + j * 32, r, h, rb[j][0], rb[j][1]);
+        for (int j = 0; j < 2; ++j) split_frag8_x<B_KC>(fb[j], so, rb[j][0], rb[j][1]);
         if (want_cs) {                                      // [k][i] image: 8 of the stage's 16 k rows per thread
+            float c8[8];
+            const uint32_t ca = cs_base + so;
+            SPLIT_RD32(c8[0], ca, 0); SPLIT_RD32(c8[1], ca, 2 * F_BM * 4); SPLIT_RD32(c8[2], ca, 4 * F_BM * 4); SPLIT_RD32(c8[3], ca, 6 * F_BM * 4);
+            SPLIT_RD32(c8[4], ca, 8 * F_BM * 4); SPLIT_RD32(c8[5], ca, 10 * F_BM * 4); SPLIT_RD32(c8[6], ca, 12 * F_BM * 4); SPLIT_RD32(c8[7], ca, 14 * F_BM * 4);
+            SPLIT_LDS_WAIT8(c8[0], c8[1], c8[2], c8[3], c8[4], c8[5], c8[6], c8[7]);
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) csum += sa[(2 * kk + (tid >> 7)) * F_BM + (tid & 127)];
+            for (int kk = 0; kk < 8; ++kk) csum += c8[kk];
         }
+        SPLIT_LDS_WAIT8(ra[0][0], ra[0][1], ra[1][0], ra[1][1], rb[0][0], rb[0][1], rb[1][0], rb[1][1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) split3_bf16(ra[i][0], ra[i][1], ap[SET][i][0], ap[SET][i][1], ap[SET][i][2]);
@@ -632,10 +687,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
         for (int j = 0; j < 2; ++j) split3_bf16(rb[j][0], rb[j][1], bp[SET][j][0], bp[SET][j][1], bp[SET][j][2]);
         if (!FIRST) {
             ACR_SPLIT_MFMA6(SET ^ 1, 0, 0) ACR_SPLIT_MFMA6(SET ^ 1, 0, 1) ACR_SPLIT_MFMA6(SET ^ 1, 1, 0) ACR_SPLIT_MFMA6(SET ^ 1, 1, 1)
+#ifdef SPLIT_SPREAD
+            issue(min(st + S_SLOTS - 1, nst - 1));          // unconditional (no branch inside the interleaved region): past the end it re-reads the last stage into a free slot
+#endif
 #pragma unroll
             for (int it = 0; it < 24; ++it) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA of stage st - 1
                 __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // eight VALU instructions of stage st's split
+#ifdef SPLIT_SPREAD
+                if (it % 6 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one of the refill's four LDS-DMA instructions
+#endif
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -648,6 +709,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
     if (nst & 1) { ACR_SPLIT_MFMA6(0, 0, 0) ACR_SPLIT_MFMA6(0, 0, 1) ACR_SPLIT_MFMA6(0, 1, 0) ACR_SPLIT_MFMA6(0, 1, 1) }
     else { ACR_SPLIT_MFMA6(1, 0, 0) ACR_SPLIT_MFMA6(1, 0, 1) ACR_SPLIT_MFMA6(1, 1, 0) ACR_SPLIT_MFMA6(1, 1, 1) }
 #undef ACR_SPLIT_MFMA6
+#ifdef SPLIT_SPREAD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end
+#endif
     __syncthreads();                                        // every wave is done with the ring: the finish may reuse it
     gemm_f32_finish<A_KC, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, csum, want_cs);
 }

@@ -232,6 +232,23 @@ size_t acr_conv1x1_wgrad_f32_ws_floats(int32_t nsamp, int32_t cout, int32_t cin,
 int acr_conv1x1_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw, float* ws,
                           float* dw, void* stream);
 
+/* ---- 3x3 stride-1 SAME convolutions of the stem's bottlenecks (models/resnetv2.py:171-216 `conv2`; std_conv.py:40-65) in NCHW fp32
+ * as implicit GEMMs with split products on the bf16 MFMA (math = ACR_MATH_BF16X3 only: ACR_ERR_UNSUPPORTED otherwise -- the
+ * exact-fp32 arithmetic keeps the library's Winograd kernels).  No im2col buffer, no layout change.
+ * acr_conv3x3_f32: y[n][co][p] = sum_t sum_ci w_packed[co][t*cin + ci] * x[n][ci][p + off_t] (zero outside the image), with
+ * w_packed (cout, 9*cin) = w.permute(0,2,3,1) of the (cout, cin, 3, 3) weight.  The input gradient is the same call on dy with
+ * w_packed = w.flip(2,3).permute(1,2,3,0) as (cin, 9*cout).  cin %% 16 == 0, H*W %% 4 == 0, 16-byte aligned pointers.
+ * The shifted tap reads leave x at its two ends (values masked, addresses dereferenced): the caller guarantees
+ * ACR_CONV3X3_PAD floats of readable device memory before x and behind its last element (contents irrelevant).
+ * acr_conv3x3_wgrad_f32: dw_packed (cout, 9*cin) = sum_n sum_p dy[n][co][p] * x[n][ci][p + off_t]; ws: fp32 slabs of
+ * acr_conv3x3_wgrad_ws_floats(...) floats, summed in a fixed order (deterministic). */
+#define ACR_CONV3X3_PAD 512
+int acr_conv3x3_f32(int32_t math, const float* w_packed, const float* x, float* y, int32_t nsamp, int32_t cout, int32_t cin,
+                    int32_t H, int32_t W, void* stream);
+size_t acr_conv3x3_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W);
+int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W,
+                          float* ws, float* dw_packed, void* stream);
+
 /* ---- 3x3 stride-2 max-pool of the stem with TF-SAME -inf padding folded in (models/resnetv2.py:322-328) ----
  * x (nc, h, w) -> y (nc, ho, wo); amax = 1-byte window argmax (i*3+j, first maximum like ATen) kept for the backward,
  * which gathers (no atomics).  Window (ho, wo) starts at (2 ho - pad_top, 2 wo - pad_left). */

@@ -877,6 +877,60 @@ def test_conv1x1_f32(N, cin, cout, H, W, math):
         assert err <= 1e-5, (n, float(err))
 
 
+@pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 64, 16, 16), (1, 16, 48, 12, 20), (2, 128, 128, 28, 28), (1, 64, 64, 112, 112),
+                                             (3, 32, 160, 20, 36), (2, 256, 256, 28, 28)])
+def test_conv3x3_split(N, cin, cout, H, W):
+    """3x3 stride-1 SAME convolution with split products as an implicit GEMM (csrc/conv3x3.hip): forward, input gradient (same
+    kernel, flipped taps) and weight gradient vs fp64 conv2d at the fp32 GEMM tests' tolerance.  Covers cout = 64 (half a tile
+    row), pixel tiles that run past H*W and whose rows straddle image rows (W = 20, 28, 36), H != W, 9 cin not a multiple of the
+    tile (cin = 16, 32, 64), several pixel parts in the weight gradient (112 x 112) -- and inputs WITHOUT the margin the entry
+    point asks for (ops copies them into a buffer that has it)."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).to(dev).requires_grad_(True)
+    assert ops.conv3x3_fusable(x, w, 1, 1) and not ops.conv3x3_fusable(x, w, 1, 0) and not ops.conv3x3_fusable(x, w, 2, 1)
+    y = ops.conv3x3(x, w)
+    dy = torch.randn(N, cout, H, W, generator=g).to(dev)
+    (y * dy).sum().backward()
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    ref = F.conv2d(xd, wd, padding=1)
+    (ref * dy.double()).sum().backward()
+    for n, a, b in (("y", y, ref), ("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad)):
+        err = (a.double() - b).abs().max() / b.abs().max()
+        assert err <= 1e-5, (n, float(err))
+    # the border is exact zero padding, not a neighbouring row / channel / sample: a one-hot input's response is the flipped kernel
+    x1 = torch.zeros(1, cin, H, W, device=dev)
+    x1[0, 3, 0, 0] = 1.0
+    x1[0, 5, H - 1, W - 1] = 1.0
+    y1 = ops.conv3x3(x1, w.detach())
+    r1 = F.conv2d(x1.double(), w.detach().double(), padding=1)
+    assert (y1.double() - r1).abs().max() <= 1e-6 * r1.abs().max()
+    assert torch.equal(y1 == 0, r1 == 0)
+    # bitwise reproducible (fixed slab order in the weight gradient)
+    x2 = x.detach().clone().requires_grad_(True)
+    w2 = w.detach().clone().requires_grad_(True)
+    y2 = ops.conv3x3(x2, w2)
+    (y2 * dy).sum().backward()
+    assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad) and torch.equal(w2.grad, w.grad)
+
+
+def test_conv3x3_margin_contract():
+    """acr_conv3x3_* read up to ACR_CONV3X3_PAD floats outside x (masked): ops hands them tensors whose storage has that slack --
+    the GroupNorm outputs are allocated with it, anything else is copied."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    x = torch.randn(2, 32, 16, 16, device=dev)
+    assert ops._with_margin(x) is not x and torch.equal(ops._with_margin(x), x)
+    m = ops.empty_with_margin(x)
+    assert ops._with_margin(m) is m and m.is_contiguous() and m.data_ptr() % 16 == 0
+    assert m.storage_offset() == ops.CONV3X3_PAD and m.untyped_storage().nbytes() == (x.numel() + 2 * ops.CONV3X3_PAD) * 4
+    y = ops.groupnorm_act(x, torch.ones(32, device=dev), torch.zeros(32, device=dev), "relu")
+    assert ops._with_margin(y) is y
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_stem_kernels_full_size_are_per_sample(dtype):
     """GroupNorm (+ residual + ReLU) and the NCHW 1x1 convolution at the largest launches of the BASELINE step (32 views, 256 channels
