@@ -26,6 +26,8 @@
 
 #include "acr_common.h"
 
+typedef __bf16 bf16_t;
+
 #define F_BM 128
 #define F_BN 128
 #define F_BK 32
@@ -716,6 +718,224 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
     gemm_f32_finish<A_KC, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, csum, want_cs);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Split products on PRE-SPLIT, PRE-TILED operands (round 4).  gemm_f32_split_kernel splits its operand tiles in registers:
+// ~200 VALU instructions per 24 MFMAs per wave, and every operand element is split again by every workgroup that reads it
+// (N / 128 resp. M / 128 times); its counters (profiles/r04_pmc_split_gemm.txt) show the VALU port -- which also issues the
+// MFMAs -- busy 66 % of the time and the matrix pipe 57 %.  Here every operand is split ONCE per product by a streaming pass
+// (planes_tile_kernel / planes_tile_t_kernel: HBM-bound, 10 bytes per element) into three bf16 planes in the workspace,
+// transposed on the way where the product needs it, so that ONE kernel flavour (both operands [row][k]) serves NT, NN and TN
+// and its loop is DMA + ds_read_b128 + MFMA only.
+// The planes are stored TILED, in exactly the image the kernel wants in LDS: for row block rb (128 rows) and stage kb (16
+// contraction elements) the three 4 KiB planes [128 rows][32 bytes] follow each other,
+//     byte offset = ((rb * nkb + kb) * 3 + p) * 4096 + row * 32 + 16 * (khalf ^ bit 3 of row) + 2 * (k & 7),
+// so a stage of an operand is 12 KiB of CONTIGUOUS memory and every LDS-DMA instruction copies one contiguous KiB.  The first
+// version kept dense row-major planes: 32 bytes per row and stage made every DMA instruction touch 32 cache lines, the
+// texture-address units were busy 95 % of the kernel and the matrix pipe 37 % (profiles/r04_pmc_planes_gemm_first_version.txt).
+// The half swap (bit 3 of the row) makes the 16 lanes a ds_read_b128 serves per cycle hit 16 different 16-byte bank groups.
+// Rows past the operand's end and contraction indices past K are zero in the image (no clamps, no K % 16 condition).
+// Ring of 3 slots x [A p0 p1 p2 | B p0 p1 p2], DMA two stages ahead (6 pieces per wave and stage; waves 0-1 fetch A, 2-3 B).
+// The reads of stage st and the refill of the ring are interleaved with the 24 MFMAs of stage st - 1 in program order
+// (sched_barrier between the groups: inline-asm reads are invisible to sched_group_barrier).
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define P_BK 16
+#define P_SLOTS 3
+#define P_TILE_B 4096                 // bytes per plane per operand per stage (128 rows x 32 B)
+#define P_STAGE_B (6 * P_TILE_B)
+#define PL_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Args g) {
+    __shared__ __attribute__((aligned(1024))) float smem[P_SLOTS * P_STAGE_B / 4];      // 72 KiB
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int ntile = g.tiles_launch;
+    const int t0 = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
+    const int split = t0 / ntile, tt = g.tile0 + (t0 - split * ntile);
+    int tm, tn;
+    if (ACT == 3) { tm = tt / g.tiles_n; tn = tt - tm * g.tiles_n; }
+    else tile_coords(tt, g.tiles_m, g.tiles_n, tm, tn);
+    const int m0 = tm * F_BM, n0 = tn * F_BN;
+    const int zs = split / g.ksplit;
+    const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);      // host: K, kps multiples of 16
+    const int nkb = g.K / P_BK;                             // stages per row block in the tiled image
+    // this wave's six KiB of every stage: waves 0, 1 the two halves of A's 12 KiB, waves 2, 3 of B's
+    const char* __restrict__ pw = (wave < 2 ? reinterpret_cast<const char*>(g.a) + ((int64_t)tm * nkb + kbeg / P_BK) * (3 * P_TILE_B)
+                                            : reinterpret_cast<const char*>(g.b) + ((int64_t)tn * nkb + kbeg / P_BK) * (3 * P_TILE_B)) +
+                                  (wave & 1) * (6 * 1024) + lane * 16;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nst = (kend - kbeg) / P_BK;
+    char* sm = reinterpret_cast<char*>(smem);
+    auto dma1 = [&](int st, int slot, int i) {
+        __builtin_amdgcn_global_load_lds((glb_vp)(pw + (int64_t)st * (3 * P_TILE_B) + i * 1024), (lds_vp)(sm + slot * P_STAGE_B + (wave * 6 + i) * 1024), 16, 0, 0);
+    };
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)sm;
+    const uint32_t hx = (h ^ ((r >> 3) & 1)) * 16;
+    const uint32_t fa = lbase + (wm * 64 + r) * 32 + hx, fb = lbase + 3 * P_TILE_B + (wn * 64 + r) * 32 + hx;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma1(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma1(min(1, nst - 1), 1, i);
+    bf16x8 ap[2][2][3], bp[2][2][3];                        // [register set][block][plane]
+#define PL_MFMA(SET, I, J, PA, PB) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][PA], bp[SET][J][PB], acc[I][J], 0, 0, 0);
+#define PL_PAIR(SET, I, J, T)                                                       \
+    if (T == 0) { PL_MFMA(SET, I, J, 0, 2) PL_MFMA(SET, I, J, 2, 0) }              \
+    else if (T == 1) { PL_MFMA(SET, I, J, 1, 1) PL_MFMA(SET, I, J, 0, 1) }         \
+    else { PL_MFMA(SET, I, J, 1, 0) PL_MFMA(SET, I, J, 0, 0) }
+    // step st (slot = st % 3): stage st has landed for everyone -> refill the slot stage st - 1 was read from with stage st + 2
+    // (past the end: the last stage again, into a slot nobody reads -- keeps the DMA count per step, hence the vmcnt, constant),
+    // read stage st into register set SET while the MFMAs of stage st - 1 (set SET ^ 1) run
+    auto step = [&](int st, int slot, auto set_tag, auto first_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // younger: the 6 pieces of stage st + 1
+        acr_barrier_nofence();
+        const int rslot = slot == 0 ? 2 : slot - 1;         // (st + 2) % 3
+        const int rst = min(st + 2, nst - 1);
+        const uint32_t fas = fa + slot * P_STAGE_B, fbs = fb + slot * P_STAGE_B;
+#define PL_GROUP(K12)                                                                                                   \
+        if (!FIRST) { PL_PAIR(SET ^ 1, ((K12) / 6), (((K12) / 3) & 1), ((K12) % 3)) }                                   \
+        if ((K12) < 6) PL_RD(ap[SET][(K12) / 3][(K12) % 3], fas, ((K12) % 3) * P_TILE_B + ((K12) / 3) * 1024);          \
+        else PL_RD(bp[SET][((K12) - 6) / 3][(K12) % 3], fbs, ((K12) % 3) * P_TILE_B + (((K12) - 6) / 3) * 1024);        \
+        if ((K12) & 1) dma1(rst, rslot, (K12) >> 1);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);
+        PL_GROUP(0) PL_GROUP(1) PL_GROUP(2) PL_GROUP(3) PL_GROUP(4) PL_GROUP(5)
+        PL_GROUP(6) PL_GROUP(7) PL_GROUP(8) PL_GROUP(9) PL_GROUP(10) PL_GROUP(11)
+#undef PL_GROUP
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ap[SET][0][0]), "+v"(ap[SET][0][1]), "+v"(ap[SET][0][2]), "+v"(ap[SET][1][0]), "+v"(ap[SET][1][1]), "+v"(ap[SET][1][2]),
+                       "+v"(bp[SET][0][0]), "+v"(bp[SET][0][1]), "+v"(bp[SET][0][2]), "+v"(bp[SET][1][0]), "+v"(bp[SET][1][1]), "+v"(bp[SET][1][2]));
+    };
+    step(0, 0, std::integral_constant<int, 0>{}, std::true_type{});
+    int slot = 1;
+    for (int st = 1; st < nst; st += 2) {
+        step(st, slot, std::integral_constant<int, 1>{}, std::false_type{});
+        slot = slot == 2 ? 0 : slot + 1;
+        if (st + 1 < nst) {
+            step(st + 1, slot, std::integral_constant<int, 0>{}, std::false_type{});
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+#define PL_ALL(SET)                                                                                      \
+    PL_PAIR(SET, 0, 0, 0) PL_PAIR(SET, 0, 0, 1) PL_PAIR(SET, 0, 0, 2) PL_PAIR(SET, 0, 1, 0) PL_PAIR(SET, 0, 1, 1) PL_PAIR(SET, 0, 1, 2) \
+    PL_PAIR(SET, 1, 0, 0) PL_PAIR(SET, 1, 0, 1) PL_PAIR(SET, 1, 0, 2) PL_PAIR(SET, 1, 1, 0) PL_PAIR(SET, 1, 1, 1) PL_PAIR(SET, 1, 1, 2)
+    if (nst & 1) { PL_ALL(0) } else { PL_ALL(1) }
+#undef PL_ALL
+#undef PL_PAIR
+#undef PL_MFMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end
+    __syncthreads();                                        // every wave is done with the ring: the finish may reuse it
+    gemm_f32_finish<true, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, 0.f, false);
+}
+
+// ---- the split passes (HBM-bound: 4 bytes read, 6 written per element) ----------------------------------------------------------
+__device__ __forceinline__ void planes_split8(const float (&x)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h0 = (__bf16)x[e];
+        const float r1 = x[e] - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;
+        p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)r2;
+    }
+}
+// byte offset of the 16-byte chunk (row rr of the tile, contraction half kh) inside a plane of the tiled image
+__device__ __forceinline__ int planes_chunk_off(int rr, int kh) { return rr * 32 + ((kh ^ ((rr >> 3) & 1)) << 4); }
+
+// tiled image of x[row][k] (pitch ld floats; the operand's rows are x's rows).  Workgroup = row block rb x 4 stages (64 k);
+// thread -> 4 chunks of 8 k: a row's 256 bytes are read by 8 neighbouring threads, a stage's 8 rows x 32 bytes written by 16.
+__global__ __launch_bounds__(256) void planes_tile_kernel(const float* __restrict__ x, int64_t ld, int rows, int K, int nkb, char* __restrict__ img) {
+    const int kq = (nkb + 3) >> 2;
+    const int rb = blockIdx.x / kq, k0 = (blockIdx.x - rb * kq) << 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = j * 256 + threadIdx.x, rr = c >> 3, k8 = c & 7;
+        const int row = rb * 128 + rr, k = k0 + k8 * 8;
+        if (k >= nkb * P_BK) continue;
+        float v[8];
+        if (row < rows && k + 8 <= K) {
+            const float* src = x + (int64_t)row * ld + k;
+            const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 4));
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (row < rows && k + e < K) ? x[(int64_t)row * ld + k + e] : 0.f;
+        }
+        bf16x8 p0, p1, p2;
+        planes_split8(v, p0, p1, p2);
+        char* dst = img + ((int64_t)rb * nkb + (k >> 4)) * (3 * P_TILE_B) + planes_chunk_off(rr, k8 & 1);
+        *reinterpret_cast<bf16x8*>(dst) = p0;
+        *reinterpret_cast<bf16x8*>(dst + P_TILE_B) = p1;
+        *reinterpret_cast<bf16x8*>(dst + 2 * P_TILE_B) = p2;
+    }
+}
+// tiled image of the TRANSPOSE of x[rw][c] (pitch ld): operand rows = x's columns, contraction = x's rows (R of them).  64 x 64
+// blocks through an fp32 LDS tile (pitch 65: the column reads are conflict-free); thread (c = tid & 63, q = tid >> 6) then
+// holds the 16 contraction elements 16 q .. 16 q + 15 of operand row c0 + c = one whole stage row (32 bytes per plane).
+// colpart (or null): per 64-row block of x the column sums of the block (bias gradient parts, summed in block order by
+// gemm_f32_reduce1_kernel: deterministic).
+__global__ __launch_bounds__(256) void planes_tile_t_kernel(const float* __restrict__ x, int64_t ld, int R, int C, int nkb, char* __restrict__ img,
+                                                            float* __restrict__ colpart) {
+    __shared__ float tile[64 * 65];
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int cblocks = ((C + 127) >> 7) << 1;             // whole 128-row blocks of the operand (zeros past C)
+    const int rb = blockIdx.x / cblocks, cb = blockIdx.x - rb * cblocks;
+    const int r0 = rb << 6, c0 = cb << 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                            // 64 rows x 16 float4
+        const int e = i * 256 + tid, rr = e >> 4, c4 = (e & 15) << 2;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + rr < R) {
+            const float* src = x + (int64_t)(r0 + rr) * ld + c0 + c4;
+            if (c0 + c4 + 4 <= C) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            else
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (c0 + c4 + q < C) v[q] = src[q];
+        }
+        float* d = tile + rr * 65 + c4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    __syncthreads();
+    const int c = tid & 63, gq = tid >> 6;
+    float v0[8], v1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v0[e] = tile[(gq * 16 + e) * 65 + c]; v1[e] = tile[(gq * 16 + 8 + e) * 65 + c]; }
+    if (colpart) {
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += v0[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += v1[e];
+        red[tid] = sum;
+        __syncthreads();
+        if (tid < 64 && c0 + tid < C) colpart[(int64_t)rb * C + c0 + tid] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+    }
+    const int kb = (r0 >> 4) + gq;                          // stage of these 16 contraction elements
+    if (kb >= nkb) return;
+    const int orow = c0 + c;                                // operand row (rows past C inside the last 128-row block: zeros from the loads above)
+    bf16x8 p0, p1, p2;
+    char* dst = img + ((int64_t)(orow >> 7) * nkb + kb) * (3 * P_TILE_B);
+    const int rr = orow & 127;
+    planes_split8(v0, p0, p1, p2);
+    char* d0 = dst + planes_chunk_off(rr, 0);
+    *reinterpret_cast<bf16x8*>(d0) = p0; *reinterpret_cast<bf16x8*>(d0 + P_TILE_B) = p1; *reinterpret_cast<bf16x8*>(d0 + 2 * P_TILE_B) = p2;
+    planes_split8(v1, p0, p1, p2);
+    char* d1 = dst + planes_chunk_off(rr, 1);
+    *reinterpret_cast<bf16x8*>(d1) = p0; *reinterpret_cast<bf16x8*>(d1 + P_TILE_B) = p1; *reinterpret_cast<bf16x8*>(d1 + 2 * P_TILE_B) = p2;
+}
+
 // out[i] = sum_s slab[s][i] in split order (deterministic), float4 per thread; n4 = elements / 4
 __global__ __launch_bounds__(256) void gemm_f32_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t n4,
                                                               float* __restrict__ out) {
@@ -843,13 +1063,59 @@ static TnPlan tn_plan(int M, int N, int K) {
     return {ns, kps};
 }
 
-extern "C" size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K) {
+static size_t gemm_ws_base_floats(int mode, int M, int N, int K) {
     if (mode != ACR_GEMM_TN) {
         const TailPlan tp = gemm_tail_plan(M, N, K);
         return (size_t)tp.ntail * tp.nsplit * (F_BM * F_BN);
     }
     const TnPlan p = tn_plan(M, N, K);
     return (size_t)p.nsplit * ((size_t)M * N + (size_t)M);
+}
+// Workspace of the pre-split operands (gemm_f32_planes_kernel): behind the slabs, [A planes | B planes | column-sum parts],
+// every region a multiple of 16 bytes.  Off when the plane offsets would not fit 32 bits (the kernel's DMA offsets are ints).
+struct PlanesPlan { bool on; int nkb; size_t a_fl, b_fl, cs_fl; };
+static PlanesPlan planes_plan(int mode, int math, int M, int N, int K) {
+    PlanesPlan p = {false, 0, 0, 0, 0};
+    if (math != ACR_MATH_BF16X3 || acr_opt(ACR_OPT_GEMM_X3_INKERNEL) != 0) return p;
+    p.on = true; p.nkb = (K + P_BK - 1) / P_BK;
+    p.a_fl = (size_t)((M + F_BM - 1) / F_BM) * p.nkb * (3 * P_TILE_B / 4);
+    p.b_fl = (size_t)((N + F_BN - 1) / F_BN) * p.nkb * (3 * P_TILE_B / 4);
+    p.cs_fl = mode == ACR_GEMM_TN ? (size_t)(((int64_t)((K + 63) / 64) * M + 3) / 4 * 4) : 0;
+    return p;
+}
+extern "C" size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t math, int32_t M, int32_t N, int32_t K) {
+    const PlanesPlan pl = planes_plan(mode, math, M, N, K);
+    return (gemm_ws_base_floats(mode, M, N, K) + 3) / 4 * 4 + pl.a_fl + pl.b_fl + pl.cs_fl;
+}
+// out[c] = sum over the nparts row-block parts of planes_tile_t_kernel, 16 columns per workgroup, 16 threads per column each
+// summing every 16th part (independent loads in flight), combined through LDS in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void planes_colsum_kernel(const float* __restrict__ parts, int nparts, int C, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), q = threadIdx.x >> 4;
+    float s = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int k = q; k < nparts; k += 16) s += parts[(int64_t)k * C + c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < C) {
+        float t = red[threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k * 16 + threadIdx.x];
+        out[c] = t;
+    }
+}
+// operand rows = x's rows
+static void launch_planes_tile(const float* x, int64_t ld, int rows, int K, int nkb, float* img, hipStream_t st) {
+    const int64_t nb = (int64_t)((rows + F_BM - 1) / F_BM) * ((nkb + 3) / 4);
+    hipLaunchKernelGGL(planes_tile_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ld, rows, K, nkb, reinterpret_cast<char*>(img));
+}
+// operand rows = x's C columns, contraction = x's R rows; the row blocks of x cover whole stages up to nkb * 16
+static void launch_planes_tile_t(const float* x, int64_t ld, int R, int C, int nkb, float* img, float* colpart, hipStream_t st) {
+    const int cpad = (C + F_BM - 1) / F_BM * F_BM;            // all 128 rows of the last row block are written (zeros past C)
+    const int64_t nb = (int64_t)((nkb * P_BK + 63) / 64) * (cpad / 64);
+    hipLaunchKernelGGL(planes_tile_t_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ld, R, C, nkb, reinterpret_cast<char*>(img), colpart);
 }
 
 extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
@@ -880,6 +1146,23 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float
         g.nsplit = p.nsplit; g.kps = p.kps; g.k_zs = p.kps;
         g.c = ws; g.ldc = N;
         g.cs = colsum ? ws + (size_t)p.nsplit * M * N : nullptr;
+        const PlanesPlan pl = planes_plan(mode, math, M, N, K);
+        if (pl.on) {                                        // operands split (and transposed) once, then the planes kernel
+            float* wp = ws + (gemm_ws_base_floats(mode, M, N, K) + 3) / 4 * 4;
+            float* pa = wp;
+            float* pb = wp + pl.a_fl;
+            float* colpart = colsum ? wp + pl.a_fl + pl.b_fl : nullptr;
+            launch_planes_tile_t(a, lda, K, M, pl.nkb, pa, colpart, st);
+            launch_planes_tile_t(b, ldb, K, N, pl.nkb, pb, nullptr, st);
+            GemmF32Args gp = g;
+            gp.a = pa; gp.b = pb; gp.K = pl.nkb * P_BK; gp.cs = nullptr;
+            hipLaunchKernelGGL((gemm_f32_planes_kernel<3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, gp);
+            const int64_t n4p = (int64_t)M * N / 4;
+            hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((n4p + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit, n4p, c);
+            if (colsum)
+                hipLaunchKernelGGL(planes_colsum_kernel, dim3((M + 15) / 16), dim3(256), 0, st, (const float*)colpart, (K + 63) / 64, M, colsum);
+            return acr_check_launch("acr_gemm_f32(TN, planes)");
+        }
         if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && math == ACR_MATH_BF16X3)
             hipLaunchKernelGGL((gemm_f32_split_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
         else if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0)
@@ -912,7 +1195,23 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float
         g.tiles_launch -= tp.ntail;
         grid = dim3((unsigned)g.tiles_launch);
     }
+    const PlanesPlan pl = planes_plan(mode, math, M, N, K);
+    GemmF32Args gp = g;                                     // the same product on pre-split planes
+    const bool planes = pl.on && ws && al16(ws) && vec_ok;
+    if (planes) {
+        float* wp = ws + (gemm_ws_base_floats(mode, M, N, K) + 3) / 4 * 4;
+        float* pa = wp;
+        float* pb = wp + pl.a_fl;
+        launch_planes_tile(a, lda, M, K, pl.nkb, pa, st);
+        if (mode == ACR_GEMM_NT) launch_planes_tile(b, ldb, N, K, pl.nkb, pb, st);
+        else launch_planes_tile_t(b, ldb, K, N, pl.nkb, pb, nullptr, st);
+        gp.a = pa; gp.b = pb; gp.K = pl.nkb * P_BK;
+    }
     if (g.tiles_launch == 0) {                              // a small product: every tile goes the K-split way
+    } else if (planes) {
+        if (act == 0) hipLaunchKernelGGL((gemm_f32_planes_kernel<0>), grid, dim3(256), 0, st, gp);
+        else if (act == 1) hipLaunchKernelGGL((gemm_f32_planes_kernel<1>), grid, dim3(256), 0, st, gp);
+        else hipLaunchKernelGGL((gemm_f32_planes_kernel<2>), grid, dim3(256), 0, st, gp);
     } else if (mode == ACR_GEMM_NT) {
         if (act == 0) ACR_F32_LAUNCH(true, true, 0);
         else if (act == 1) ACR_F32_LAUNCH(true, true, 1);
@@ -928,7 +1227,11 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float
         gt.tile0 = g.tiles_launch; gt.tiles_launch = tp.ntail; gt.nsplit = tp.nsplit; gt.kps = tp.kps; gt.k_zs = tp.kps;
         gt.c = ws;
         const dim3 tgrid((unsigned)(tp.ntail * tp.nsplit));
-        if (mode == ACR_GEMM_NT && split) hipLaunchKernelGGL((gemm_f32_split_kernel<true, true, 4>), tgrid, dim3(256), 0, st, gt);
+        if (planes) {
+            GemmF32Args gpt = gp;
+            gpt.tile0 = gt.tile0; gpt.tiles_launch = gt.tiles_launch; gpt.nsplit = gt.nsplit; gpt.kps = gt.kps; gpt.k_zs = gt.k_zs; gpt.c = ws;
+            hipLaunchKernelGGL((gemm_f32_planes_kernel<4>), tgrid, dim3(256), 0, st, gpt);
+        } else if (mode == ACR_GEMM_NT && split) hipLaunchKernelGGL((gemm_f32_split_kernel<true, true, 4>), tgrid, dim3(256), 0, st, gt);
         else if (mode == ACR_GEMM_NT) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 4>), tgrid, dim3(256), 0, st, gt);
         else if (split) hipLaunchKernelGGL((gemm_f32_split_kernel<true, false, 4>), tgrid, dim3(256), 0, st, gt);
         else hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4>), tgrid, dim3(256), 0, st, gt);

@@ -535,7 +535,7 @@ def gemm_f32_raw(mode, a, b, c, bias=None, aux=None, act=0, c2=None, colsum=None
     md = GEMM_MODES[mode]
     M, N = c.shape
     K = a.shape[0] if md == 2 else a.shape[1]
-    nws = lib.acr_gemm_f32_ws_floats(md, M, N, K)
+    nws = lib.acr_gemm_f32_ws_floats(md, math, M, N, K)
     ws = torch.empty(nws, dtype=torch.float32, device=a.device) if nws else None
     tok = _t0("gemm_f32_" + mode, M, N, K)
     L.check(lib.acr_gemm_f32(md, math, act, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(bias), L.ptr(aux),

@@ -89,7 +89,7 @@ typedef enum acr_option {
     ACR_OPT_ATTN_F32_NW = 8,    /* acr_attn_fwd_scores: 5 = five 32-query blocks (waves) per forward workgroup instead of four (A/B: slower) */
     ACR_OPT_GEMM_F32_NOTAIL = 9, /* 1: acr_gemm_f32 NT / NN never K-splits the tiles beyond the last whole half-round (A/B) */
     ACR_OPT_ATTN_F32_NOSPLITTAIL = 10, /* 1: resident-score attention keeps the leftover 32-row block as an ordinary (1 live wave) workgroup (A/B) */
-    ACR_OPT_RESERVED_11 = 11,   /* was ACR_OPT_GEMM_F32_SPLIT (ABI 1): the split-product arithmetic is now the per-call `math` argument */
+    ACR_OPT_GEMM_X3_INKERNEL = 11, /* 1: split-product acr_gemm_f32 splits operand tiles inside the GEMM kernel instead of once per product into bf16 planes (A/B) */
     ACR_OPT_COUNT_
 } acr_option;
 int     acr_set_option(int32_t option, int32_t value);
@@ -184,10 +184,12 @@ int acr_linear_dgelu_bf16(const void* a, int64_t lda, const void* w, int64_t ldw
  *   2: c = acc * aux with aux = the saved GELU'(h) (fc2's input gradient taken through the activation).
  * Pitches in elements, multiples of 4; pointers 16-byte aligned; K %% 4 == 0 (NT/NN), M, N %% 4 == 0 and ldc == N (TN).
  * math: acr_math (how the products are evaluated; everything else is identical).
- * ws: caller-owned scratch of acr_gemm_f32_ws_floats(mode, M, N, K) floats (TN: the split slabs; NT / NN: slabs for the K-split
- * tail tiles, 0 when the tile count needs none -- ws may then be NULL; without ws the product runs unsplit). */
+ * ws: caller-owned scratch of acr_gemm_f32_ws_floats(mode, math, M, N, K) floats (TN: the split slabs; NT / NN: slabs for the
+ * K-split tail tiles, 0 when the tile count needs none -- ws may then be NULL; without ws the product runs unsplit.
+ * math = ACR_MATH_BF16X3 adds the bf16 planes both operands are split into once per call (csrc/gemm_f32.hip
+ * gemm_f32_planes_kernel); with ws == NULL the operand tiles are split inside the GEMM kernel instead, same results). */
 typedef enum acr_gemm_mode { ACR_GEMM_NT = 0, ACR_GEMM_NN = 1, ACR_GEMM_TN = 2 } acr_gemm_mode;
-size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K);
+size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t math, int32_t M, int32_t N, int32_t K);
 int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                  const float* aux, int64_t ldaux, float* c, int64_t ldc, float* c2, float* colsum, int32_t M, int32_t N,
                  int32_t K, float* ws, void* stream);

@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     float *a, *b, *c, *bias, *ws, *dy, *dw;
     size_t na = (size_t)M * K, nb = (size_t)N * K, nc = (size_t)M * N;
     hipMalloc(&a, na * 4); hipMalloc(&b, nb * 4); hipMalloc(&c, nc * 4); hipMalloc(&bias, N * 4); hipMalloc(&dy, nc * 4); hipMalloc(&dw, nb * 4);
-    size_t nws = acr_gemm_f32_ws_floats(ACR_GEMM_TN, N, K, M);
+    size_t nws = acr_gemm_f32_ws_floats(ACR_GEMM_TN, ACR_MATH_F32, N, K, M);
     hipMalloc(&ws, nws * 4 + 16);
     std::vector<float> h(std::max(std::max(na, nb), nc));
     srand(1);
