@@ -497,7 +497,7 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, float* ssm, float
         // issue order of a live wave's step:  tile(t+1) [4] | G(t+1) [4]  scores(t+2) [4].  At this barrier tile(t) must have
         // landed; behind it the previous step issued G(t) and scores(t+1).
         sres_wait_vm((k0 > 0 && live) ? (gb0 ? 4 : 0) + (k0 + 32 < g.T ? 4 : 0) : 0);
-        __syncthreads();
+        acr_barrier_nofence();                             // not __syncthreads(): its release fence drains every DMA (acr_common.h)
         LAB_ADD(0);
         if (k0 + 64 <= g.T) {
             dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb + (int64_t)(k0 + 32) * g.st, doff, wave);
@@ -659,7 +659,7 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         // issue order of a live wave's step:  tile(t+1) [4]  lse2 / delta(t) [2 plain loads, consumed in this step] | G(t+1) [4]
         // scores(t+2) [4].  At this barrier tile(t) must have landed; behind it the previous step issued G(t) and scores(t+1).
         sres_wait_vm((q0 > 0 && live) ? (gb0 ? 4 : 0) + (q0 + 32 < g.T ? 4 : 0) : 0);
-        __syncthreads();
+        acr_barrier_nofence();
         LAB_ADD(0);
         if (q0 + 64 <= g.T) {
             dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, qb + (int64_t)(q0 + 32) * g.st, qoff, wave);

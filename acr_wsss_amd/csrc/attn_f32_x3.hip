@@ -81,9 +81,15 @@ __device__ __forceinline__ void x3_wait_vm(int n) {
 #ifdef LAB_TL
 #define x3_barrier(n_younger) do { x3_wait_vm(n_younger); X3L_ADD(5); __syncthreads(); } while (0)      /* lab: the wait on its own */
 #else
+// acr_barrier_nofence (acr_common.h): __syncthreads()'s release fence made hipcc drain every outstanding DMA in front of the
+// barrier of every second step (`s_waitcnt vmcnt(0)`, found in the ISA) -- the counted wait above it is the synchronisation
 __device__ __forceinline__ void x3_barrier(int n_younger) {
     x3_wait_vm(n_younger);
+#ifdef X3_FENCED_BARRIER          /* lab A/B */
     __syncthreads();
+#else
+    acr_barrier_nofence();
+#endif
 }
 #endif
 

@@ -46,6 +46,7 @@ struct GemmF32Args {
     int M, N, K;
     int tiles_m, tiles_n, nsplit, kps;   // kps: contraction elements per split (multiple of F_BK)
     int tile0, tiles_launch;             // this launch covers tiles tile0 .. tile0 + tiles_launch - 1 (each nsplit times)
+    int nkb_a, nkb_b;                    // gemm_f32_planes_tn_kernel: stages (16 features) per token block of the a / b image
     // z-slices: workgroup slice z = split index.  K-split (weight gradient of a Linear): operands shared, k range z*k_zs..;
     // batch (1x1 convolutions per sample): operands / outputs advance by *_zs per slice, k range the whole contraction
     int64_t a_zs, b_zs, c_zs, aux_zs;
@@ -838,6 +839,123 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
     gemm_f32_finish<true, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, 0.f, false);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient on the SAME images the forward / input-gradient products read (no transposed copies of dy or x):
+//   c[m][n] = sum_t a[t][m] b[t][n],   a = dy image, b = x image, both tiled [token block of 128][stage of 16 features].
+// The contraction index is now the image's ROW: a 16-token stage of a 128-feature operand tile is, for each of its 8 feature
+// stages and 3 planes, 16 consecutive 32-byte rows = 512 contiguous bytes (one LDS-DMA instruction copies two of them), and a
+// fragment -- 8 tokens of one feature per lane -- is read TRANSPOSED from those [16 tokens][16 features] chunks by
+// ds_read_b64_tr_b16 (a 16-lane group takes 4 token rows x 16 features = 128 contiguous bytes, conflict-free; lane (r, h)
+// receives tokens 4 h + (0..3) and 8 + 4 h + (0..3) of feature r: the same permutation of the contraction index for both
+// operands).  Slot = [a: plane][feature stage][512 B] | [b: ...]; ring, waits, interleaving as gemm_f32_planes_kernel.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define PL_RDTR(lo, hi, alo, ahi, OFF)                                                                  \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"          \
+                 : "=&v"(lo), "=&v"(hi) : "v"(alo), "v"(ahi), "i"(OFF))
+__global__ __launch_bounds__(256, 2) void gemm_f32_planes_tn_kernel(const GemmF32Args g) {
+    __shared__ __attribute__((aligned(1024))) float smem[P_SLOTS * P_STAGE_B / 4];      // 72 KiB
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int ntile = g.tiles_launch;
+    const int t0 = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
+    const int split = t0 / ntile, tt = g.tile0 + (t0 - split * ntile);
+    const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
+    const int m0 = tm * F_BM, n0 = tn * F_BN;
+    const int kbeg = split * g.k_zs, kend = min(g.K, kbeg + g.kps);      // tokens; host: K, kps multiples of 16
+    const int nkb = wave < 2 ? g.nkb_a : g.nkb_b;          // feature stages per token block of this wave's operand
+    const int f0 = (wave < 2 ? tm : tn) * 8;               // first feature stage of the tile
+    const char* __restrict__ pw = reinterpret_cast<const char*>(wave < 2 ? g.a : g.b);
+    // piece q = 6 (wave & 1) + i of the operand's 12: plane q >> 2, chunk pair q & 3 (feature stages f0 + 2 (q & 3) + (lane >> 5));
+    // feature stages past the operand's end (M or N not a multiple of 128) alias the last one: rows the finish never stores
+    int offd[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int q = (wave & 1) * 6 + i, pl = q >> 2, fs = min(f0 + 2 * (q & 3) + (lane >> 5), nkb - 1);
+        offd[i] = (fs * 3 + pl) * P_TILE_B + (lane & 31) * 16;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nst = (kend - kbeg) / P_BK;
+    char* sm = reinterpret_cast<char*>(smem);
+    auto dma1 = [&](int st, int slot, int i) {
+        const int tk = kbeg + st * P_BK;                    // uniform
+        const char* src = pw + ((int64_t)(tk >> 7) * nkb) * (3 * P_TILE_B) + (tk & 127) * 32;
+        const int q = (wave & 1) * 6 + i;
+        __builtin_amdgcn_global_load_lds((glb_vp)(src + offd[i]), (lds_vp)(sm + slot * P_STAGE_B + (wave >> 1) * (3 * P_TILE_B) + (q >> 2) * P_TILE_B + (q & 3) * 1024),
+                                         16, 0, 0);
+    };
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)sm;
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1, qq = i16 >> 2, pp = i16 & 3;
+    // lo: token row 4 h + qq (< 8: halves as stored), hi: row 8 + 4 h + qq (halves swapped)
+    const uint32_t tlo = (4 * h + qq) * 32 + ((pp >> 1) << 4) + 8 * (pp & 1), thi = (8 + 4 * h + qq) * 32 + (((pp >> 1) ^ 1) << 4) + 8 * (pp & 1);
+    const uint32_t fa_lo = lbase + (wm * 4 + g1) * 512 + tlo, fa_hi = lbase + (wm * 4 + g1) * 512 + thi;
+    const uint32_t fb_lo = lbase + 3 * P_TILE_B + (wn * 4 + g1) * 512 + tlo, fb_hi = lbase + 3 * P_TILE_B + (wn * 4 + g1) * 512 + thi;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma1(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma1(min(1, nst - 1), 1, i);
+    bf16x4 al[2][2][3], ah[2][2][3], bl[2][2][3], bh[2][2][3];      // [register set][block][plane], tokens lo / hi
+#define PT_MFMA(SET, I, J, PA, PB)                                                                                                        \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(al[SET][I][PA], ah[SET][I][PA], 0, 1, 2, 3, 4, 5, 6, 7), \
+                                                        __builtin_shufflevector(bl[SET][J][PB], bh[SET][J][PB], 0, 1, 2, 3, 4, 5, 6, 7), acc[I][J], 0, 0, 0);
+#define PT_PAIR(SET, I, J, T)                                                       \
+    if (T == 0) { PT_MFMA(SET, I, J, 0, 2) PT_MFMA(SET, I, J, 2, 0) }              \
+    else if (T == 1) { PT_MFMA(SET, I, J, 1, 1) PT_MFMA(SET, I, J, 0, 1) }         \
+    else { PT_MFMA(SET, I, J, 1, 0) PT_MFMA(SET, I, J, 0, 0) }
+    auto step = [&](int st, int slot, auto set_tag, auto first_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // younger: the 6 pieces of stage st + 1
+        acr_barrier_nofence();
+        const int rslot = slot == 0 ? 2 : slot - 1;         // (st + 2) % 3
+        const int rst = min(st + 2, nst - 1);
+        const uint32_t so = slot * P_STAGE_B;
+        const uint32_t a_lo = fa_lo + so, a_hi = fa_hi + so, b_lo = fb_lo + so, b_hi = fb_hi + so;
+#define PT_GROUP(K12)                                                                                                                   \
+        if (!FIRST) { PT_PAIR(SET ^ 1, ((K12) / 6), (((K12) / 3) & 1), ((K12) % 3)) }                                                   \
+        if ((K12) < 6) PL_RDTR(al[SET][(K12) / 3][(K12) % 3], ah[SET][(K12) / 3][(K12) % 3], a_lo, a_hi, ((K12) % 3) * P_TILE_B + ((K12) / 3) * 1024); \
+        else PL_RDTR(bl[SET][((K12) - 6) / 3][(K12) % 3], bh[SET][((K12) - 6) / 3][(K12) % 3], b_lo, b_hi, ((K12) % 3) * P_TILE_B + (((K12) - 6) / 3) * 1024); \
+        if ((K12) & 1) dma1(rst, rslot, (K12) >> 1);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);
+        PT_GROUP(0) PT_GROUP(1) PT_GROUP(2) PT_GROUP(3) PT_GROUP(4) PT_GROUP(5)
+        PT_GROUP(6) PT_GROUP(7) PT_GROUP(8) PT_GROUP(9) PT_GROUP(10) PT_GROUP(11)
+#undef PT_GROUP
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(al[SET][0][0]), "+v"(al[SET][0][1]), "+v"(al[SET][0][2]), "+v"(al[SET][1][0]), "+v"(al[SET][1][1]), "+v"(al[SET][1][2]),
+                       "+v"(ah[SET][0][0]), "+v"(ah[SET][0][1]), "+v"(ah[SET][0][2]), "+v"(ah[SET][1][0]), "+v"(ah[SET][1][1]), "+v"(ah[SET][1][2]),
+                       "+v"(bl[SET][0][0]), "+v"(bl[SET][0][1]), "+v"(bl[SET][0][2]), "+v"(bl[SET][1][0]), "+v"(bl[SET][1][1]), "+v"(bl[SET][1][2]),
+                       "+v"(bh[SET][0][0]), "+v"(bh[SET][0][1]), "+v"(bh[SET][0][2]), "+v"(bh[SET][1][0]), "+v"(bh[SET][1][1]), "+v"(bh[SET][1][2]));
+    };
+    step(0, 0, std::integral_constant<int, 0>{}, std::true_type{});
+    int slot = 1;
+    for (int st = 1; st < nst; st += 2) {
+        step(st, slot, std::integral_constant<int, 1>{}, std::false_type{});
+        slot = slot == 2 ? 0 : slot + 1;
+        if (st + 1 < nst) {
+            step(st + 1, slot, std::integral_constant<int, 0>{}, std::false_type{});
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+#define PT_ALL(SET)                                                                                      \
+    PT_PAIR(SET, 0, 0, 0) PT_PAIR(SET, 0, 0, 1) PT_PAIR(SET, 0, 0, 2) PT_PAIR(SET, 0, 1, 0) PT_PAIR(SET, 0, 1, 1) PT_PAIR(SET, 0, 1, 2) \
+    PT_PAIR(SET, 1, 0, 0) PT_PAIR(SET, 1, 0, 1) PT_PAIR(SET, 1, 0, 2) PT_PAIR(SET, 1, 1, 0) PT_PAIR(SET, 1, 1, 1) PT_PAIR(SET, 1, 1, 2)
+    if (nst & 1) { PT_ALL(0) } else { PT_ALL(1) }
+#undef PT_ALL
+#undef PT_PAIR
+#undef PT_MFMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_f32_finish<true, 3>(g, acc, smem, split, tt, tn, m0, n0, 0, wm, wn, r, h, tid, 0.f, false);
+}
+
 // ---- the split passes (HBM-bound: 4 bytes read, 6 written per element) ----------------------------------------------------------
 __device__ __forceinline__ void planes_split8(const float (&x)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
 #pragma unroll
@@ -854,9 +972,12 @@ __device__ __forceinline__ int planes_chunk_off(int rr, int kh) { return rr * 32
 
 // tiled image of x[row][k] (pitch ld floats; the operand's rows are x's rows).  Workgroup = row block rb x 4 stages (64 k);
 // thread -> 4 chunks of 8 k: a row's 256 bytes are read by 8 neighbouring threads, a stage's 8 rows x 32 bytes written by 16.
-__global__ __launch_bounds__(256) void planes_tile_kernel(const float* __restrict__ x, int64_t ld, int rows, int K, int nkb, char* __restrict__ img) {
+__global__ __launch_bounds__(256) void planes_tile_kernel(const float* __restrict__ x, int64_t ld, int rows, int K, int nkb, char* __restrict__ img,
+                                                          float* __restrict__ colpart) {
+    __shared__ float red[32 * 64];
     const int kq = (nkb + 3) >> 2;
     const int rb = blockIdx.x / kq, k0 = (blockIdx.x - rb * kq) << 6;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = j * 256 + threadIdx.x, rr = c >> 3, k8 = c & 7;
@@ -872,12 +993,25 @@ __global__ __launch_bounds__(256) void planes_tile_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (row < rows && k + e < K) ? x[(int64_t)row * ld + k + e] : 0.f;
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += v[e];
         bf16x8 p0, p1, p2;
         planes_split8(v, p0, p1, p2);
         char* dst = img + ((int64_t)rb * nkb + (k >> 4)) * (3 * P_TILE_B) + planes_chunk_off(rr, k8 & 1);
         *reinterpret_cast<bf16x8*>(dst) = p0;
         *reinterpret_cast<bf16x8*>(dst + P_TILE_B) = p1;
         *reinterpret_cast<bf16x8*>(dst + 2 * P_TILE_B) = p2;
+    }
+    if (colpart) {                                          // column sums of this row block (bias gradient part): thread = rows
+        const int tid = threadIdx.x;                        // (tid >> 3) + 32 j of the 8 columns 8 (tid & 7) ..; fixed summation order
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 3) * 64 + (tid & 7) * 8 + e] = cs[e];
+        __syncthreads();
+        if (tid < 64 && k0 + tid < K) {
+            float t = red[tid];
+            for (int q = 1; q < 32; ++q) t += red[q * 64 + tid];
+            colpart[(int64_t)rb * K + k0 + tid] = t;
+        }
     }
 }
 // tiled image of the TRANSPOSE of x[rw][c] (pitch ld): operand rows = x's columns, contraction = x's rows (R of them).  64 x 64
@@ -1078,9 +1212,15 @@ static PlanesPlan planes_plan(int mode, int math, int M, int N, int K) {
     PlanesPlan p = {false, 0, 0, 0, 0};
     if (math != ACR_MATH_BF16X3 || acr_opt(ACR_OPT_GEMM_X3_INKERNEL) != 0) return p;
     p.on = true; p.nkb = (K + P_BK - 1) / P_BK;
+    if (mode == ACR_GEMM_TN) {                              // images of a[K][M] and b[K][N] as stored: rows = the K tokens
+        const size_t nrb = (size_t)(K + 127) / 128;
+        p.a_fl = nrb * ((M + P_BK - 1) / P_BK) * (3 * P_TILE_B / 4);
+        p.b_fl = nrb * ((N + P_BK - 1) / P_BK) * (3 * P_TILE_B / 4);
+        p.cs_fl = (nrb * M + 3) / 4 * 4;
+        return p;
+    }
     p.a_fl = (size_t)((M + F_BM - 1) / F_BM) * p.nkb * (3 * P_TILE_B / 4);
     p.b_fl = (size_t)((N + F_BN - 1) / F_BN) * p.nkb * (3 * P_TILE_B / 4);
-    p.cs_fl = mode == ACR_GEMM_TN ? (size_t)(((int64_t)((K + 63) / 64) * M + 3) / 4 * 4) : 0;
     return p;
 }
 extern "C" size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t math, int32_t M, int32_t N, int32_t K) {
@@ -1107,15 +1247,102 @@ __global__ __launch_bounds__(256) void planes_colsum_kernel(const float* __restr
     }
 }
 // operand rows = x's rows
-static void launch_planes_tile(const float* x, int64_t ld, int rows, int K, int nkb, float* img, hipStream_t st) {
+static void launch_planes_tile(const float* x, int64_t ld, int rows, int K, int nkb, float* img, float* colpart, hipStream_t st) {
     const int64_t nb = (int64_t)((rows + F_BM - 1) / F_BM) * ((nkb + 3) / 4);
-    hipLaunchKernelGGL(planes_tile_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ld, rows, K, nkb, reinterpret_cast<char*>(img));
+    hipLaunchKernelGGL(planes_tile_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ld, rows, K, nkb, reinterpret_cast<char*>(img), colpart);
 }
 // operand rows = x's C columns, contraction = x's R rows; the row blocks of x cover whole stages up to nkb * 16
 static void launch_planes_tile_t(const float* x, int64_t ld, int R, int C, int nkb, float* img, float* colpart, hipStream_t st) {
     const int cpad = (C + F_BM - 1) / F_BM * F_BM;            // all 128 rows of the last row block are written (zeros past C)
     const int64_t nb = (int64_t)((nkb * P_BK + 63) / 64) * (cpad / 64);
     hipLaunchKernelGGL(planes_tile_t_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ld, R, C, nkb, reinterpret_cast<char*>(img), colpart);
+}
+
+// ---- the image API: split-product operands made once, used by several products (include/acr_hip.h "split-product images") ------
+extern "C" size_t acr_x3_image_floats(int32_t rows, int32_t cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (size_t)((rows + F_BM - 1) / F_BM) * ((cols + P_BK - 1) / P_BK) * (3 * P_TILE_B / 4);
+}
+extern "C" size_t acr_x3_colsum_ws_floats(int32_t rows, int32_t cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (size_t)((rows + F_BM - 1) / F_BM) * cols;
+}
+extern "C" int acr_x3_image(const float* x, int64_t ld, int32_t rows, int32_t cols, float* image, float* colsum, float* colsum_ws, void* stream) {
+    ACR_CHECK_ARG(x && image, "acr_x3_image: null pointer");
+    ACR_CHECK_ARG(rows > 0 && cols > 0 && ld >= cols, "acr_x3_image: bad shape (rows=%d cols=%d ld=%lld)", rows, cols, (long long)ld);
+    ACR_CHECK_ARG(al16(x) && al16(image) && (ld % 4) == 0, "acr_x3_image: x and image must be 16-byte aligned, ld %% 4 == 0");
+    ACR_CHECK_ARG(!colsum || colsum_ws, "acr_x3_image: colsum needs colsum_ws (acr_x3_colsum_ws_floats)");
+    hipStream_t st = (hipStream_t)stream;
+    launch_planes_tile(x, ld, rows, cols, (cols + P_BK - 1) / P_BK, image, colsum ? colsum_ws : nullptr, st);
+    if (colsum)
+        hipLaunchKernelGGL(planes_colsum_kernel, dim3((cols + 15) / 16), dim3(256), 0, st, (const float*)colsum_ws, (rows + F_BM - 1) / F_BM, cols, colsum);
+    return acr_check_launch("acr_x3_image");
+}
+extern "C" int acr_x3_image_t(const float* x, int64_t ld, int32_t rows, int32_t cols, float* image, void* stream) {
+    ACR_CHECK_ARG(x && image, "acr_x3_image_t: null pointer");
+    ACR_CHECK_ARG(rows > 0 && cols > 0 && ld >= cols, "acr_x3_image_t: bad shape (rows=%d cols=%d ld=%lld)", rows, cols, (long long)ld);
+    ACR_CHECK_ARG(al16(x) && al16(image) && (ld % 4) == 0, "acr_x3_image_t: x and image must be 16-byte aligned, ld %% 4 == 0");
+    launch_planes_tile_t(x, ld, rows, cols, (rows + P_BK - 1) / P_BK, image, nullptr, (hipStream_t)stream);
+    return acr_check_launch("acr_x3_image_t");
+}
+extern "C" size_t acr_gemm_x3_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K) {
+    return mode == ACR_GEMM_NN ? 0 : (gemm_ws_base_floats(mode, M, N, K) + 3) / 4 * 4;
+}
+extern "C" int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const float* b_img, const float* bias, const float* aux, int64_t ldaux,
+                           float* c, int64_t ldc, float* c2, int32_t M, int32_t N, int32_t K, float* ws, void* stream) {
+    ACR_CHECK_ARG(a_img && b_img && c, "acr_gemm_x3: null pointer");
+    ACR_CHECK_ARG(M > 0 && N > 0 && K > 0, "acr_gemm_x3: empty problem (M=%d N=%d K=%d)", M, N, K);
+    ACR_CHECK_ARG((mode == ACR_GEMM_NT || mode == ACR_GEMM_TN) && act >= 0 && act <= 2, "acr_gemm_x3: mode must be ACR_GEMM_NT or ACR_GEMM_TN (got %d), act 0..2 (got %d)", mode, act);
+    ACR_CHECK_ARG(al16(a_img) && al16(b_img) && al16(c) && (ldc % 4) == 0 && (!bias || al16(bias)) && (!aux || (al16(aux) && (ldaux % 4) == 0)) && (!c2 || al16(c2)),
+                  "acr_gemm_x3: pointers must be 16-byte aligned, pitches %% 4 == 0");
+    ACR_CHECK_ARG(!ws || al16(ws), "acr_gemm_x3: ws must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    GemmF32Args g;
+    g.a = a_img; g.lda = 0; g.b = b_img; g.ldb = 0; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.c = c; g.ldc = ldc; g.c2 = c2;
+    g.cs = nullptr; g.M = M; g.N = N;
+#ifdef LAB_STAMP
+    g.stamp = g_lab_stamp;
+#endif
+    g.K = (K + P_BK - 1) / P_BK * P_BK;                     // the images are zero past K
+    g.tiles_m = (M + F_BM - 1) / F_BM; g.tiles_n = (N + F_BN - 1) / F_BN; g.nsplit = 1; g.kps = g.K;
+    g.a_zs = g.b_zs = g.c_zs = g.aux_zs = 0; g.k_zs = g.kps; g.ksplit = 1 << 30;
+    g.tile0 = 0; g.tiles_launch = g.tiles_m * g.tiles_n;
+    g.nkb_a = (M + P_BK - 1) / P_BK; g.nkb_b = (N + P_BK - 1) / P_BK;
+    if (mode == ACR_GEMM_TN) {                              // a_img = image of a[K][M], b_img = image of b[K][N] (rows = the K tokens)
+        ACR_CHECK_ARG(act == 0 && !bias && !aux, "acr_gemm_x3: TN takes no epilogue");
+        ACR_CHECK_ARG(ws, "acr_gemm_x3: TN needs the acr_gemm_x3_ws_floats workspace");
+        ACR_CHECK_ARG((M % 4) == 0 && (N % 4) == 0 && ldc == N, "acr_gemm_x3: TN needs M, N %% 4 == 0 and a dense output (ldc == N)");
+        const TnPlan p = tn_plan(M, N, K);
+        g.nsplit = p.nsplit; g.kps = p.kps; g.k_zs = p.kps;
+        g.c = ws; g.ldc = N;
+        hipLaunchKernelGGL(gemm_f32_planes_tn_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
+        const int64_t n4 = (int64_t)M * N / 4;
+        hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit, n4, c);
+        return acr_check_launch("acr_gemm_x3(TN)");
+    }
+    ACR_CHECK_ARG(act != 1 || c2, "acr_gemm_x3: act 1 (GELU) needs c2");
+    ACR_CHECK_ARG(act != 2 || aux, "acr_gemm_x3: act 2 (GELU') needs the saved derivative in aux");
+    TailPlan tp = gemm_tail_plan(M, N, K);
+    if (!ws) tp.ntail = 0;
+    g.tiles_launch -= tp.ntail;
+    if (g.tiles_launch > 0) {
+        const dim3 grid((unsigned)g.tiles_launch);
+        if (act == 0) hipLaunchKernelGGL((gemm_f32_planes_kernel<0>), grid, dim3(256), 0, st, g);
+        else if (act == 1) hipLaunchKernelGGL((gemm_f32_planes_kernel<1>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_f32_planes_kernel<2>), grid, dim3(256), 0, st, g);
+    }
+    if (tp.ntail) {                                         // the tail tiles, K-split into slabs, and their epilogue (gemm_tail_plan)
+        GemmF32Args gt = g;
+        gt.tile0 = g.tiles_launch; gt.tiles_launch = tp.ntail; gt.nsplit = tp.nsplit; gt.kps = tp.kps; gt.k_zs = tp.kps; gt.c = ws;
+        hipLaunchKernelGGL((gemm_f32_planes_kernel<4>), dim3((unsigned)(tp.ntail * tp.nsplit)), dim3(256), 0, st, gt);
+        GemmF32Args ge = g;
+        ge.tile0 = gt.tile0;
+        const dim3 egrid((unsigned)(tp.ntail * 16));
+        if (act == 0) hipLaunchKernelGGL((gemm_f32_tail_epilogue_kernel<0>), egrid, dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
+        else if (act == 1) hipLaunchKernelGGL((gemm_f32_tail_epilogue_kernel<1>), egrid, dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
+        else hipLaunchKernelGGL((gemm_f32_tail_epilogue_kernel<2>), egrid, dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
+    }
+    return acr_check_launch("acr_gemm_x3");
 }
 
 extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
@@ -1147,21 +1374,14 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float
         g.c = ws; g.ldc = N;
         g.cs = colsum ? ws + (size_t)p.nsplit * M * N : nullptr;
         const PlanesPlan pl = planes_plan(mode, math, M, N, K);
-        if (pl.on) {                                        // operands split (and transposed) once, then the planes kernel
+        if (pl.on) {                                        // both operands split once into images, then the product on the images
             float* wp = ws + (gemm_ws_base_floats(mode, M, N, K) + 3) / 4 * 4;
             float* pa = wp;
             float* pb = wp + pl.a_fl;
-            float* colpart = colsum ? wp + pl.a_fl + pl.b_fl : nullptr;
-            launch_planes_tile_t(a, lda, K, M, pl.nkb, pa, colpart, st);
-            launch_planes_tile_t(b, ldb, K, N, pl.nkb, pb, nullptr, st);
-            GemmF32Args gp = g;
-            gp.a = pa; gp.b = pb; gp.K = pl.nkb * P_BK; gp.cs = nullptr;
-            hipLaunchKernelGGL((gemm_f32_planes_kernel<3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, gp);
-            const int64_t n4p = (int64_t)M * N / 4;
-            hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((n4p + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit, n4p, c);
-            if (colsum)
-                hipLaunchKernelGGL(planes_colsum_kernel, dim3((M + 15) / 16), dim3(256), 0, st, (const float*)colpart, (K + 63) / 64, M, colsum);
-            return acr_check_launch("acr_gemm_f32(TN, planes)");
+            int rc = acr_x3_image(a, lda, K, M, pa, colsum, colsum ? wp + pl.a_fl + pl.b_fl : nullptr, stream);
+            if (rc == ACR_OK) rc = acr_x3_image(b, ldb, K, N, pb, nullptr, nullptr, stream);
+            if (rc == ACR_OK) rc = acr_gemm_x3(ACR_GEMM_TN, 0, pa, pb, nullptr, nullptr, 0, c, ldc, nullptr, M, N, K, ws, stream);
+            return rc;
         }
         if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && math == ACR_MATH_BF16X3)
             hipLaunchKernelGGL((gemm_f32_split_kernel<false, false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
@@ -1196,22 +1416,16 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float
         grid = dim3((unsigned)g.tiles_launch);
     }
     const PlanesPlan pl = planes_plan(mode, math, M, N, K);
-    GemmF32Args gp = g;                                     // the same product on pre-split planes
-    const bool planes = pl.on && ws && al16(ws) && vec_ok;
-    if (planes) {
+    if (pl.on && ws && al16(ws) && vec_ok) {                // both operands split once into images, then the product on the images
         float* wp = ws + (gemm_ws_base_floats(mode, M, N, K) + 3) / 4 * 4;
         float* pa = wp;
         float* pb = wp + pl.a_fl;
-        launch_planes_tile(a, lda, M, K, pl.nkb, pa, st);
-        if (mode == ACR_GEMM_NT) launch_planes_tile(b, ldb, N, K, pl.nkb, pb, st);
-        else launch_planes_tile_t(b, ldb, K, N, pl.nkb, pb, nullptr, st);
-        gp.a = pa; gp.b = pb; gp.K = pl.nkb * P_BK;
+        int rc = acr_x3_image(a, lda, M, K, pa, nullptr, nullptr, stream);
+        if (rc == ACR_OK) rc = mode == ACR_GEMM_NT ? acr_x3_image(b, ldb, N, K, pb, nullptr, nullptr, stream) : acr_x3_image_t(b, ldb, K, N, pb, stream);
+        if (rc == ACR_OK) rc = acr_gemm_x3(ACR_GEMM_NT, act, pa, pb, bias, aux, ldaux, c, ldc, c2, M, N, K, ws, stream);
+        return rc;
     }
     if (g.tiles_launch == 0) {                              // a small product: every tile goes the K-split way
-    } else if (planes) {
-        if (act == 0) hipLaunchKernelGGL((gemm_f32_planes_kernel<0>), grid, dim3(256), 0, st, gp);
-        else if (act == 1) hipLaunchKernelGGL((gemm_f32_planes_kernel<1>), grid, dim3(256), 0, st, gp);
-        else hipLaunchKernelGGL((gemm_f32_planes_kernel<2>), grid, dim3(256), 0, st, gp);
     } else if (mode == ACR_GEMM_NT) {
         if (act == 0) ACR_F32_LAUNCH(true, true, 0);
         else if (act == 1) ACR_F32_LAUNCH(true, true, 1);
@@ -1227,11 +1441,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float
         gt.tile0 = g.tiles_launch; gt.tiles_launch = tp.ntail; gt.nsplit = tp.nsplit; gt.kps = tp.kps; gt.k_zs = tp.kps;
         gt.c = ws;
         const dim3 tgrid((unsigned)(tp.ntail * tp.nsplit));
-        if (planes) {
-            GemmF32Args gpt = gp;
-            gpt.tile0 = gt.tile0; gpt.tiles_launch = gt.tiles_launch; gpt.nsplit = gt.nsplit; gpt.kps = gt.kps; gpt.k_zs = gt.k_zs; gpt.c = ws;
-            hipLaunchKernelGGL((gemm_f32_planes_kernel<4>), tgrid, dim3(256), 0, st, gpt);
-        } else if (mode == ACR_GEMM_NT && split) hipLaunchKernelGGL((gemm_f32_split_kernel<true, true, 4>), tgrid, dim3(256), 0, st, gt);
+        if (mode == ACR_GEMM_NT && split) hipLaunchKernelGGL((gemm_f32_split_kernel<true, true, 4>), tgrid, dim3(256), 0, st, gt);
         else if (mode == ACR_GEMM_NT) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true, 4>), tgrid, dim3(256), 0, st, gt);
         else if (split) hipLaunchKernelGGL((gemm_f32_split_kernel<true, false, 4>), tgrid, dim3(256), 0, st, gt);
         else hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false, 4>), tgrid, dim3(256), 0, st, gt);

@@ -545,6 +545,44 @@ def gemm_f32_raw(mode, a, b, c, bias=None, aux=None, act=0, c2=None, colsum=None
     return c
 
 
+X3_IMAGES = os.environ.get("ACR_X3_IMAGES", "1") != "0"      # A/B: split-product Linears keep operand images across forward / backward
+
+
+def x3_image(x2, colsum=None):
+    """Split-product image (include/acr_hip.h "split-product images") of the fp32 matrix x2 (unit inner stride); ``colsum``
+    (cols) receives x2's column sums from the same pass."""
+    lib = L.load()
+    rows, cols = x2.shape
+    img = torch.empty(lib.acr_x3_image_floats(rows, cols), dtype=torch.float32, device=x2.device)
+    cws = torch.empty(lib.acr_x3_colsum_ws_floats(rows, cols), dtype=torch.float32, device=x2.device) if colsum is not None else None
+    L.check(lib.acr_x3_image(L.ptr(x2), x2.stride(0), rows, cols, L.ptr(img), L.ptr(colsum), L.ptr(cws), L.stream_ptr()), "acr_x3_image")
+    return img
+
+
+def x3_image_t(x2):
+    """Image of x2's transpose."""
+    lib = L.load()
+    rows, cols = x2.shape
+    img = torch.empty(lib.acr_x3_image_floats(cols, rows), dtype=torch.float32, device=x2.device)
+    L.check(lib.acr_x3_image_t(L.ptr(x2), x2.stride(0), rows, cols, L.ptr(img), L.stream_ptr()), "acr_x3_image_t")
+    return img
+
+
+def gemm_x3(mode, a_img, b_img, c, K, bias=None, aux=None, act=0, c2=None):
+    """c[M,N] from split-product images through acr_gemm_x3: 'nt' c = A[M,K] B[N,K]^T (images of A and B), 'tn' c = A[K,M]^T B[K,N]
+    (images of A and B as stored, K rows each)."""
+    lib = L.load()
+    md = GEMM_MODES[mode]
+    M, N = c.shape
+    nws = lib.acr_gemm_x3_ws_floats(md, M, N, K)
+    ws = torch.empty(nws, dtype=torch.float32, device=c.device) if nws else None
+    tok = _t0("gemm_x3_" + mode, M, N, K)
+    L.check(lib.acr_gemm_x3(md, act, L.ptr(a_img), L.ptr(b_img), L.ptr(bias), L.ptr(aux), aux.stride(0) if aux is not None else 0, L.ptr(c),
+                            c.stride(0), L.ptr(c2), M, N, K, L.ptr(ws), L.stream_ptr()), "acr_gemm_x3")
+    _t1(tok)
+    return c
+
+
 def _f32_ok(*ts):
     return all(t is None or (t.dtype == torch.float32 and t.is_cuda and t.stride(-1) == 1 and t.stride(0) % 4 == 0
                              and t.data_ptr() % 16 == 0) for t in ts)
@@ -574,8 +612,15 @@ class LinearF32Fn(Function):
         if r2 is not None and not r2.is_contiguous():
             r2 = r2.contiguous()
         y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
-        gemm_f32_raw("nt", x2, weight, y, bias=bias, aux=r2, math=math)
-        ctx.save_for_backward(x2, weight)
+        ctx.images = math == 1 and X3_IMAGES and _f32_ok(x2, weight, y, r2, bias)
+        if ctx.images:                                      # x's image serves this product and the weight gradient
+            xi = x3_image(x2)
+            gemm_x3("nt", xi, x3_image(weight), y, shp[-1], bias=bias, aux=r2)
+            ctx.save_for_backward(xi if any(ctx.needs_input_grad[1:3]) else None, weight)
+            ctx.M = x2.shape[0]
+        else:
+            gemm_f32_raw("nt", x2, weight, y, bias=bias, aux=r2, math=math)
+            ctx.save_for_backward(x2, weight)
         ctx.has_bias, ctx.has_resid, ctx.owner = bias is not None, resid is not None, owner
         return y.reshape(*shp[:-1], N)
 
@@ -587,11 +632,25 @@ class LinearF32Fn(Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.images:                                      # dy's image serves the input and the weight gradient (+ its column sums = db)
+            if not _f32_ok(dy2):
+                dy2 = dy2.clone()                           # a fresh, aligned allocation
+            xi = x2
+            db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_db else None
+            dyi = x3_image(dy2, colsum=db)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty((ctx.M, K), dtype=torch.float32, device=dy.device)
+                gemm_x3("nt", dyi, x3_image_t(weight), dx, N)
+                dx = dx.reshape(*dy.shape[:-1], K)
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+                gemm_x3("tn", dyi, xi, dw, ctx.M)
+            return dx, dw, db, (dy if ctx.has_resid else None), None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((dy2.shape[0], K), dtype=torch.float32, device=dy.device)
             _dx_f32(dy2, weight, ctx.owner, dx, math=ctx.math)
             dx = dx.reshape(*dy.shape[:-1], K)
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
             db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_db else None
@@ -614,14 +673,22 @@ class MlpF32Fn(Function):
         Hd, D = w1.shape[0], w2.shape[0]
         h = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
         a = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
-        gemm_f32_raw("nt", x2, w1, h, bias=b1, act=1, c2=a, math=math)          # a = GELU(h), and GELU'(h) in place of h (all backward needs)
         r2 = resid.reshape(-1, D) if resid is not None else None
         if r2 is not None and not r2.is_contiguous():
             r2 = r2.contiguous()
         y = torch.empty((M, D), dtype=torch.float32, device=x.device)
+        ctx.images = math == 1 and X3_IMAGES and _f32_ok(x2, w1, w2, r2, b1, b2)
+        ctx.has_resid = resid is not None
+        if ctx.images:                                      # the images of x and GELU(h) serve the forward and the weight gradients
+            xi = x3_image(x2)
+            gemm_x3("nt", xi, x3_image(w1), h, shp[-1], bias=b1, act=1, c2=a)
+            ai = x3_image(a)
+            gemm_x3("nt", ai, x3_image(w2), y, Hd, bias=b2, aux=r2)
+            ctx.save_for_backward(xi, h, ai, w1, w2)        # fp32 GELU(h) is not kept: its image is all the backward reads
+            return y.reshape(*shp[:-1], D)
+        gemm_f32_raw("nt", x2, w1, h, bias=b1, act=1, c2=a, math=math)          # a = GELU(h), and GELU'(h) in place of h (all backward needs)
         gemm_f32_raw("nt", a, w2, y, bias=b2, aux=r2, math=math)
         ctx.save_for_backward(x2, h, a, w1, w2)
-        ctx.has_resid = resid is not None
         return y.reshape(*shp[:-1], D)
 
     @staticmethod
@@ -635,6 +702,28 @@ class MlpF32Fn(Function):
         dev = dy.device
         math = ctx.math
         dw1 = db1 = dw2 = db2 = dx = None
+        if ctx.images:
+            if not _f32_ok(dy2):
+                dy2 = dy2.clone()                           # a fresh, aligned allocation
+            xi, ai = x2, a
+            D = w2.shape[0]
+            db2 = torch.empty(D, dtype=torch.float32, device=dev) if need[4] else None
+            dyi = x3_image(dy2, colsum=db2)
+            if need[3]:
+                dw2 = torch.empty_like(w2)
+                gemm_x3("tn", dyi, ai, dw2, M)
+            dh = torch.empty_like(h)
+            gemm_x3("nt", dyi, x3_image_t(w2), dh, D, aux=h, act=2)              # (dY W2) * GELU'(h); `h` holds GELU'(h) (see forward)
+            db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if need[2] else None
+            dhi = x3_image(dh, colsum=db1)
+            if need[1]:
+                dw1 = torch.empty_like(w1)
+                gemm_x3("tn", dhi, xi, dw1, M)
+            if need[0]:
+                dx = torch.empty((M, w1.shape[1]), dtype=torch.float32, device=dev)
+                gemm_x3("nt", dhi, x3_image_t(w1), dx, Hd)
+                dx = dx.reshape(*dy.shape[:-1], w1.shape[1])
+            return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None), None, None, None
         if need[3]:
             dw2 = torch.empty_like(w2)
             db2 = torch.empty(w2.shape[0], dtype=torch.float32, device=dev) if need[4] else None

@@ -234,6 +234,30 @@ size_t acr_conv1x1_wgrad_f32_ws_floats(int32_t nsamp, int32_t cout, int32_t cin,
 int acr_conv1x1_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw, float* ws,
                           float* dw, void* stream);
 
+/* ---- split-product images: operands of acr_math ACR_MATH_BF16X3 products made ONCE and used by several products -------------
+ * (a Linear's input serves its forward and its weight gradient, its output gradient the input and the weight gradient:
+ * models/vision_transformer.py:158-164,200,212 and their autograd backward).  An image holds the three bf16 planes of a
+ * row-major fp32 matrix x[rows][cols], tiled [128 rows][16 cols] exactly as the GEMM kernels copy them to LDS
+ * (csrc/gemm_f32.hip "PRE-TILED"); zero outside the matrix, so no shape conditions beyond the alignment ones.
+ *   acr_x3_image_floats(rows, cols): size of an image in floats.
+ *   acr_x3_image: image of x (pitch ld floats).  colsum (nullable, (cols)) receives the column sums of x from the same pass
+ *                 -- the bias gradient when x = dy -- through colsum_ws (acr_x3_colsum_ws_floats(rows, cols) floats).
+ *   acr_x3_image_t: image of x^T (an image of a (cols) x (rows) matrix): what ACR_GEMM_NT needs of a weight W[out][in] to form
+ *                 dx = dy . W without a transposed copy.
+ *   acr_gemm_x3: c[M,N] from images, epilogues / workspace / determinism exactly as acr_gemm_f32:
+ *     ACR_GEMM_NT  c = A[M,K] . B[N,K]^T   a_img = image of A (M x K), b_img = image of B (N x K)
+ *     ACR_GEMM_TN  c = A[K,M]^T . B[K,N]   a_img = image of A (K x M), b_img = image of B (K x N) -- the SAME images of dy and x
+ *                  the other two products read (fragments are read transposed from LDS).
+ *   ws: acr_gemm_x3_ws_floats(mode, M, N, K) floats (TN: required; NT: K-split tail slabs, may be NULL).
+ * acr_gemm_f32(math = ACR_MATH_BF16X3) is these calls on images it makes in its own workspace. */
+size_t acr_x3_image_floats(int32_t rows, int32_t cols);
+size_t acr_x3_colsum_ws_floats(int32_t rows, int32_t cols);
+int acr_x3_image(const float* x, int64_t ld, int32_t rows, int32_t cols, float* image, float* colsum, float* colsum_ws, void* stream);
+int acr_x3_image_t(const float* x, int64_t ld, int32_t rows, int32_t cols, float* image, void* stream);
+size_t acr_gemm_x3_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K);
+int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const float* b_img, const float* bias, const float* aux, int64_t ldaux, float* c,
+                int64_t ldc, float* c2, int32_t M, int32_t N, int32_t K, float* ws, void* stream);
+
 /* ---- 3x3 stride-1 SAME convolutions of the stem's bottlenecks (models/resnetv2.py:171-216 `conv2`; std_conv.py:40-65) in NCHW fp32
  * as implicit GEMMs with split products on the bf16 MFMA (math = ACR_MATH_BF16X3 only: ACR_ERR_UNSUPPORTED otherwise -- the
  * exact-fp32 arithmetic keeps the library's Winograd kernels).  No im2col buffer, no layout change.

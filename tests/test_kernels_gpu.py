@@ -877,6 +877,77 @@ def test_conv1x1_f32(N, cin, cout, H, W, math):
         assert err <= 1e-5, (n, float(err))
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 200, 100), (128, 128, 16), (1000, 768, 772), (2500, 64, 3072), (37, 260, 40)])
+def test_gemm_x3_images(M, N, K):
+    """The split-product image API (acr_x3_image / acr_x3_image_t / acr_gemm_x3): NT with bias + residual, the input-gradient form
+    through the transposed image of the weight, TN on the SAME images of dy and x the other two products read (transposed LDS
+    reads), column sums of dy from the image pass -- vs float64 at the fp32 GEMM tests' tolerance; shapes with partial row
+    blocks, K not a multiple of the 16-deep stage, N = 64 (half a tile), tails.  The results are bit-identical to
+    acr_gemm_f32(math = split) -- it is the same kernels on images it makes itself."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    dy = torch.randn(M, N, generator=g).to(dev)
+    xi, wi = ops.x3_image(x), ops.x3_image(w)
+    y = torch.empty(M, N, device=dev)
+    ops.gemm_x3("nt", xi, wi, y, K, bias=b, aux=res)
+    ref = x.double() @ w.double().t() + b.double() + res.double()
+    assert (y.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    y2 = torch.empty(M, N, device=dev)
+    ops.gemm_f32_raw("nt", x, w, y2, bias=b, aux=res, math=1)
+    assert torch.equal(y, y2)
+    db = torch.empty(N, device=dev)
+    dyi = ops.x3_image(dy, colsum=db)
+    refb = dy.double().sum(0)
+    assert (db.double() - refb).abs().max() <= 1e-5 * max(1.0, float(refb.abs().max())) + 1e-5 * float(dy.abs().sum(0).max())
+    dx = torch.empty(M, K, device=dev)
+    ops.gemm_x3("nt", dyi, ops.x3_image_t(w), dx, N)
+    refx = dy.double() @ w.double()
+    assert (dx.double() - refx).abs().max() <= 1e-5 * refx.abs().max()
+    if N % 4 == 0 and K % 4 == 0:
+        dw = torch.empty(N, K, device=dev)
+        ops.gemm_x3("tn", dyi, xi, dw, M)
+        refw = dy.double().t() @ x.double()
+        assert (dw.double() - refw).abs().max() <= 1e-5 * refw.abs().max()
+        dw2 = torch.empty(N, K, device=dev)
+        db2 = torch.empty(N, device=dev)
+        ops.gemm_f32_raw("tn", dy, x, dw2, colsum=db2, math=1)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+        dw3 = torch.empty(N, K, device=dev)
+        ops.gemm_x3("tn", dyi, xi, dw3, M)
+        assert torch.equal(dw, dw3)                          # fixed slab order
+
+
+def test_x3_image_planes_sum_to_the_operand_exactly():
+    """An image is the operand: its three bf16 planes, read back through the documented tiling, sum to the fp32 values bit for bit
+    (values spanning 2^-20 .. 2^20), and it is zero outside the matrix."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rows, cols = 200, 40
+    x = (torch.randn(rows, cols, generator=g) * torch.exp2(torch.randint(-20, 21, (rows, cols), generator=g).float())).to(dev)
+    img = ops.x3_image(x).view(torch.bfloat16)               # [row block][stage][plane][128 rows][16: two 8-element halves]
+    nrb, nkb = (rows + 127) // 128, (cols + 15) // 16
+    t = img.view(nrb, nkb, 3, 128, 2, 8).float()
+    rr = torch.arange(128, device=dev)
+    swap = ((rr >> 3) & 1).bool()
+    t = torch.where(swap.view(1, 1, 1, 128, 1, 1), t.flip(4), t)          # halves of rows 8-15 (mod 16) are stored swapped
+    full = t.sum(2).permute(0, 2, 1, 3, 4).reshape(nrb * 128, nkb * 16)
+    assert torch.equal(full[:rows, :cols], x)
+    assert float(full[rows:].abs().max()) == 0.0 and float(full[:, cols:].abs().max()) == 0.0
+    xt = ops.x3_image_t(x).view(torch.bfloat16)
+    nrb, nkb = (cols + 127) // 128, (rows + 15) // 16
+    t = xt.view(nrb, nkb, 3, 128, 2, 8).float()
+    t = torch.where(swap.view(1, 1, 1, 128, 1, 1), t.flip(4), t)
+    full = t.sum(2).permute(0, 2, 1, 3, 4).reshape(nrb * 128, nkb * 16)
+    assert torch.equal(full[:cols, :rows], x.t())
+    assert float(full[cols:].abs().max()) == 0.0 and float(full[:, rows:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 64, 16, 16), (1, 16, 48, 12, 20), (2, 128, 128, 28, 28), (1, 64, 64, 112, 112),
                                              (3, 32, 160, 20, 36), (2, 256, 256, 28, 28)])
 def test_conv3x3_split(N, cin, cout, H, W):
