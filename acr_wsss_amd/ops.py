@@ -584,7 +584,7 @@ def gemm_x3(mode, a_img, b_img, c, K, bias=None, aux=None, act=0, c2=None):
 
 
 def _f32_ok(*ts):
-    return all(t is None or (t.dtype == torch.float32 and t.is_cuda and t.stride(-1) == 1 and t.stride(0) % 4 == 0
+    return all(t is None or (t.dtype == torch.float32 and t.is_cuda and t.stride(-1) == 1 and (t.dim() == 1 or t.stride(0) % 4 == 0)
                              and t.data_ptr() % 16 == 0) for t in ts)
 
 

@@ -922,6 +922,33 @@ def test_gemm_x3_images(M, N, K):
         assert torch.equal(dw, dw3)                          # fixed slab order
 
 
+def test_split_linears_take_the_image_path():
+    """Linear and MLP under split products keep operand images across forward and backward (the path bench.py measures): the
+    autograd nodes say so, no fp32 GELU output is kept, and values / gradients equal the per-call path's bit for bit."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    torch.manual_seed(2)
+    fc1, fc2 = torch.nn.Linear(256, 512).to(dev), torch.nn.Linear(512, 256).to(dev)
+    x = torch.randn(3, 100, 256, device=dev, requires_grad=True)
+    res = torch.randn(3, 100, 256, device=dev)
+    out = {}
+    for images in (True, False):
+        ops.X3_IMAGES = images
+        try:
+            for p_ in (x, *fc1.parameters(), *fc2.parameters()):
+                p_.grad = None
+            y = ops.linear_or_hip(x, fc1, math=1)
+            assert y.grad_fn.images == images
+            z = ops.mlp_f32(x, fc1, fc2, resid=res, math=1)
+            assert z.grad_fn.images == images
+            (y.sum() * 0.5 + (z * res).sum()).backward()
+            out[images] = [t.detach().clone() for t in (y, z, x.grad, fc1.weight.grad, fc1.bias.grad, fc2.weight.grad, fc2.bias.grad)]
+        finally:
+            ops.X3_IMAGES = True
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
+
+
 def test_x3_image_planes_sum_to_the_operand_exactly():
     """An image is the operand: its three bf16 planes, read back through the documented tiling, sum to the fp32 values bit for bit
     (values spanning 2^-20 .. 2^20), and it is zero outside the matrix."""
