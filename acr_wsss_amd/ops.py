@@ -568,6 +568,21 @@ def x3_image_t(x2):
     return img
 
 
+def weight_image(weight, owner=None, transposed=False):
+    """Image of a Linear's weight (``transposed``: of W^T, what the input gradient multiplies by), cached on ``owner`` (the
+    nn.Linear) per weight version: inference makes each image once, a training step once per forward resp. backward (the
+    optimizers move the version counters on, train.py)."""
+    key = "_acr_x3_wt_img" if transposed else "_acr_x3_w_img"
+    c = getattr(owner, key, None) if owner is not None else None
+    if c is not None and c[0] == weight._version and c[1] == weight.data_ptr() and c[2].device == weight.device:
+        return c[2]
+    w2 = weight.detach()
+    img = x3_image_t(w2) if transposed else x3_image(w2)
+    if owner is not None and not torch.cuda.is_current_stream_capturing():      # a captured pass would only be run at replay
+        setattr(owner, key, (weight._version, weight.data_ptr(), img))
+    return img
+
+
 def gemm_x3(mode, a_img, b_img, c, K, bias=None, aux=None, act=0, c2=None):
     """c[M,N] from split-product images through acr_gemm_x3: 'nt' c = A[M,K] B[N,K]^T (images of A and B), 'tn' c = A[K,M]^T B[K,N]
     (images of A and B as stored, K rows each)."""
@@ -615,7 +630,7 @@ class LinearF32Fn(Function):
         ctx.images = math == 1 and X3_IMAGES and _f32_ok(x2, weight, y, r2, bias)
         if ctx.images:                                      # x's image serves this product and the weight gradient
             xi = x3_image(x2)
-            gemm_x3("nt", xi, x3_image(weight), y, shp[-1], bias=bias, aux=r2)
+            gemm_x3("nt", xi, weight_image(weight, owner), y, shp[-1], bias=bias, aux=r2)
             ctx.save_for_backward(xi if any(ctx.needs_input_grad[1:3]) else None, weight)
             ctx.M = x2.shape[0]
         else:
@@ -641,7 +656,7 @@ class LinearF32Fn(Function):
             dyi = x3_image(dy2, colsum=db)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty((ctx.M, K), dtype=torch.float32, device=dy.device)
-                gemm_x3("nt", dyi, x3_image_t(weight), dx, N)
+                gemm_x3("nt", dyi, weight_image(weight, ctx.owner, True), dx, N)
                 dx = dx.reshape(*dy.shape[:-1], K)
             if ctx.needs_input_grad[1]:
                 dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
@@ -681,9 +696,9 @@ class MlpF32Fn(Function):
         ctx.has_resid = resid is not None
         if ctx.images:                                      # the images of x and GELU(h) serve the forward and the weight gradients
             xi = x3_image(x2)
-            gemm_x3("nt", xi, x3_image(w1), h, shp[-1], bias=b1, act=1, c2=a)
+            gemm_x3("nt", xi, weight_image(w1, fc1), h, shp[-1], bias=b1, act=1, c2=a)
             ai = x3_image(a)
-            gemm_x3("nt", ai, x3_image(w2), y, Hd, bias=b2, aux=r2)
+            gemm_x3("nt", ai, weight_image(w2, fc2), y, Hd, bias=b2, aux=r2)
             ctx.save_for_backward(xi, h, ai, w1, w2)        # fp32 GELU(h) is not kept: its image is all the backward reads
             return y.reshape(*shp[:-1], D)
         gemm_f32_raw("nt", x2, w1, h, bias=b1, act=1, c2=a, math=math)          # a = GELU(h), and GELU'(h) in place of h (all backward needs)
@@ -713,7 +728,7 @@ class MlpF32Fn(Function):
                 dw2 = torch.empty_like(w2)
                 gemm_x3("tn", dyi, ai, dw2, M)
             dh = torch.empty_like(h)
-            gemm_x3("nt", dyi, x3_image_t(w2), dh, D, aux=h, act=2)              # (dY W2) * GELU'(h); `h` holds GELU'(h) (see forward)
+            gemm_x3("nt", dyi, weight_image(w2, ctx.fc2, True), dh, D, aux=h, act=2)              # (dY W2) * GELU'(h); `h` holds GELU'(h) (see forward)
             db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if need[2] else None
             dhi = x3_image(dh, colsum=db1)
             if need[1]:
@@ -721,7 +736,7 @@ class MlpF32Fn(Function):
                 gemm_x3("tn", dhi, xi, dw1, M)
             if need[0]:
                 dx = torch.empty((M, w1.shape[1]), dtype=torch.float32, device=dev)
-                gemm_x3("nt", dhi, x3_image_t(w1), dx, Hd)
+                gemm_x3("nt", dhi, weight_image(w1, ctx.fc1, True), dx, Hd)
                 dx = dx.reshape(*dy.shape[:-1], w1.shape[1])
             return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None), None, None, None
         if need[3]:

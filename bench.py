@@ -212,13 +212,31 @@ def roofline_probe(args, dev, dtype, live=None):
         dx = torch.empty(Mtok, Kw, dtype=dt, device=dev)
         dww = torch.empty(Nw, Kw, dtype=dt, device=dev)
         wt32 = w.t().contiguous()                          # what train.refresh_weight_transposes keeps per Linear
-        for key, name, call in (
+        x3 = bool(math) and getattr(ops, "X3_IMAGES", False)
+        if x3:                                              # split products: what the step's Linears launch -- products on images made once
+            xi, wi, dyi, wti = ops.x3_image(x), ops.x3_image(w), ops.x3_image(dy), ops.x3_image_t(w)
+            probes = (
+                ("acr_gemm_f32_nt", "acr_gemm_x3 NT on images (fc1 forward, %dx%dx%d)" % (Mtok, Nw, Kw), lambda: ops.gemm_x3("nt", xi, wi, y, Kw, bias=bias)),
+                ("acr_gemm_f32_dx", "acr_gemm_x3 NT on the image of W^T (fc1 input gradient, %dx%dx%d; same shape as fc2 forward)" % (Mtok, Kw, Nw),
+                 lambda: ops.gemm_x3("nt", dyi, wti, dx, Nw)),
+                ("acr_gemm_f32_tn", "acr_gemm_x3 TN on the same images of dy and x (fc1 weight gradient)", lambda: ops.gemm_x3("tn", dyi, xi, dww, Mtok)))
+        else:
+            probes = (
                 ("acr_gemm_f32_nt", "gemm_f32 NT (fc1 forward, %dx%dx%d)" % (Mtok, Nw, Kw), lambda: ops.gemm_f32_raw("nt", x, w, y, bias=bias, math=math)),
                 ("acr_gemm_f32_dx", "gemm_f32 NT on the cached W^T (fc1 input gradient, %dx%dx%d; same shape as fc2 forward)" % (Mtok, Kw, Nw),
                  lambda: ops.gemm_f32_raw("nt", dy, wt32, dx, math=math)),
-                ("acr_gemm_f32_tn", "gemm_f32 TN (fc1 weight gradient)", lambda: ops.gemm_f32_raw("tn", dy, x, dww, math=math))):
+                ("acr_gemm_f32_tn", "gemm_f32 TN (fc1 weight gradient)", lambda: ops.gemm_f32_raw("tn", dy, x, dww, math=math)))
+        for key, name, call in probes:
             t = time_kernel(call, iters=5)
             kernels[key] = _mfma_rec(name + (" [split products: 6 bf16 MFMAs per fp32 product]" if math else ""), fl, fl, t, peak)
+        if x3:                                              # the streaming pass that makes an image: 4 bytes read + 6 written per element
+            dbv = torch.empty(Nw, device=dev)
+            t = time_kernel(lambda: ops.x3_image(dy, colsum=dbv), iters=5)
+            ib = 10.0 * Mtok * Nw
+            kernels["acr_x3_image"] = {"bound": "hbm", "kernel": "planes_tile (image of dy %dx%d + its column sums = the bias gradient)" % (Mtok, Nw),
+                                       "achieved": round(ib / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ib / t / 8e12, 4),
+                                       "launch_ms": round(t * 1e3, 4), "bytes_per_launch": ib}
+            del xi, wi, dyi, wti
     if math:
         for r in kernels.values():
             if r.get("bound") == "mfma":
@@ -229,6 +247,9 @@ def roofline_probe(args, dev, dtype, live=None):
                  "acr_gemm_f32_nt": "gemm_f32_nt %dx%dx%d" % (Mt, 3072, 768), "acr_gemm_f32_dx": "gemm_f32_nt %dx%dx%d" % (Mt, 768, 3072),
                  "acr_gemm_f32_tn": "gemm_f32_tn %dx%dx%d" % (3072, 768, Mt), "acr_linear_bf16": "linear_bf16 %dx%dx%d" % (Mt, 3072, 768),
                  "acr_linear_bf16_dx": "linear_bf16 %dx%dx%d" % (Mt, 768, 3072), "acr_wgrad_bf16": "wgrad_bf16 %dx%dx%d" % (Mt, 3072, 768)}
+    if math and getattr(ops, "X3_IMAGES", False):
+        live_keys.update({"acr_gemm_f32_nt": "gemm_x3_nt %dx%dx%d" % (Mt, 3072, 768), "acr_gemm_f32_dx": "gemm_x3_nt %dx%dx%d" % (Mt, 768, 3072),
+                          "acr_gemm_f32_tn": "gemm_x3_tn %dx%dx%d" % (3072, 768, Mt)})
     for k, lk in live_keys.items():
         if live and k in kernels and lk in live:
             r, t = kernels[k], live[lk] * 1e-3
