@@ -36,6 +36,8 @@ struct Conv3Args {
     float* y;                        // (nsamp, M, H * W)
     int M, C, H, W, HW, nsamp;
     int tiles_m, tiles_n;
+    int ksplit, sps;                 // K-split of small launches: `ksplit` parts of `sps` stages each into slabs ws[part] (laid out like y)
+    float* ws;
 };
 
 __device__ __forceinline__ void c3_split3(const f32x4& lo4, const f32x4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
@@ -78,9 +80,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const Conv3Args g
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
     const int ntile = g.tiles_m * g.tiles_n;
-    const int t0 = acr_xcd_remap(blockIdx.x, ntile * g.nsamp);
+    const int t1 = acr_xcd_remap(blockIdx.x, ntile * g.nsamp * g.ksplit);
+    const int part = t1 / (ntile * g.nsamp), t0 = t1 - part * (ntile * g.nsamp);
     const int sample = t0 / ntile, tt = t0 - sample * ntile;
     const int tn = tt / g.tiles_m, tm = tt - tn * g.tiles_m;               // the tile rows of one pixel tile are neighbours
+    const int sbeg = part * g.sps;                                         // first stage of this part
     const int m0 = tm * C3_BM, n0 = tn * C3_BN;
     const int lda = 9 * g.C;
     const float* __restrict__ pa = g.w;
@@ -106,10 +110,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const Conv3Args g
     for (int i = 0; i < 2; ++i) rowb[i] = ((wave * 2 + i) * 2 + (lane >> 5)) * g.HW;
     const int pix = n0 + 4 * (lane & 31);
     const int valid0 = c3_valid9(n0 + wn * 64 + r, g.H, g.W, g.HW), valid1 = c3_valid9(n0 + wn * 64 + 32 + r, g.H, g.W, g.HW);
-    const int nst = lda / C3_BK;
+    const int nst = min(lda / C3_BK - sbeg, g.sps);
     auto issue = [&](int st) {
         float* d = smem + (st & (C3_SLOTS - 1)) * 2 * C3_TILE;
-        const int k0 = st * C3_BK;
+        const int k0 = (sbeg + st) * C3_BK;
         const int tap = k0 / g.C, ci0 = k0 - tap * g.C;                    // uniform
         const int ty = tap / 3, off = (ty - 1) * g.W + (tap - 3 * ty - 1);
 #pragma unroll
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const Conv3Args g
             ra[i][0] = *reinterpret_cast<const f32x4*>(sa + row * C3_BK + (((2 * h) ^ sw) << 2));
             ra[i][1] = *reinterpret_cast<const f32x4*>(sa + row * C3_BK + (((2 * h + 1) ^ sw) << 2));
         }
-        const int tap = (st * C3_BK) / g.C;                 // uniform
+        const int tap = ((sbeg + st) * C3_BK) / g.C;        // uniform
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float* p = sb + (8 * h) * C3_BN + wn * 64 + j * 32 + r;
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const Conv3Args g
     if (!compute) return;
     if (nst & 1) { C3_ALL(0) } else { C3_ALL(1) }
     // ---- epilogue: lane (r, h), register e of a 32x32 accumulator = row krow(e, h), column (pixel) r
-    float* yb = g.y + (int64_t)sample * g.M * g.HW;
+    float* yb = (g.ksplit > 1 ? g.ws + (int64_t)part * g.nsamp * g.M * g.HW : g.y) + (int64_t)sample * g.M * g.HW;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -398,8 +402,24 @@ extern "C" int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float*
     return acr_check_launch("acr_conv3x3_wgrad_f32");
 }
 
+// Small launches (CAM generation: two views of one image, 20-72 workgroups walking 144 stages each) are split along the
+// contraction into up to 512 workgroups' worth of parts of at least 8 stages; the parts' slabs are summed in part order.
+static int c3_fwd_ksplit(int nsamp, int cout, int cin, int HW) {
+    const int tiles = ((cout + C3_BM - 1) / C3_BM) * ((HW + C3_BN - 1) / C3_BN) * nsamp;
+    const int nst = 9 * cin / C3_BK;
+    if (tiles >= 192) return 1;
+    int ks = 512 / tiles;
+    if (ks > nst / 8) ks = nst / 8;
+    if (ks < 2) return 1;
+    const int sps = (nst + ks - 1) / ks;
+    return (nst + sps - 1) / sps;
+}
+extern "C" size_t acr_conv3x3_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W) {
+    const int ks = c3_fwd_ksplit(nsamp, cout, cin, H * W);
+    return ks > 1 ? (size_t)ks * nsamp * cout * H * W : 0;
+}
 extern "C" int acr_conv3x3_f32(int32_t math, const float* w_packed, const float* x, float* y, int32_t nsamp, int32_t cout, int32_t cin,
-                               int32_t H, int32_t W, void* stream) {
+                               int32_t H, int32_t W, float* ws, void* stream) {
     ACR_CHECK_ARG(w_packed && x && y, "acr_conv3x3_f32: null pointer");
     if (math != ACR_MATH_BF16X3) {
         acr_set_error("acr_conv3x3_f32: built for ACR_MATH_BF16X3 only (the exact-fp32 arithmetic keeps the library's Winograd kernels: "
@@ -414,8 +434,15 @@ extern "C" int acr_conv3x3_f32(int32_t math, const float* w_packed, const float*
     Conv3Args g;
     g.w = w_packed; g.x = x; g.y = y; g.M = cout; g.C = cin; g.H = H; g.W = W; g.HW = H * W; g.nsamp = nsamp;
     g.tiles_m = (cout + C3_BM - 1) / C3_BM; g.tiles_n = (g.HW + C3_BN - 1) / C3_BN;
-    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp;
+    const int nst = 9 * cin / C3_BK;
+    g.ksplit = (ws && ((uintptr_t)ws & 15) == 0) ? c3_fwd_ksplit(nsamp, cout, cin, g.HW) : 1;
+    g.sps = (nst + g.ksplit - 1) / g.ksplit; g.ws = ws;
+    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp * g.ksplit;
     ACR_CHECK_ARG(nwg < (1ll << 31), "acr_conv3x3_f32: grid too large");
     hipLaunchKernelGGL(conv3x3_split_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
+    if (g.ksplit > 1) {
+        const int64_t n4 = (int64_t)nsamp * cout * g.HW / 4;
+        hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, g.ksplit, n4, y);
+    }
     return acr_check_launch("acr_conv3x3_f32");
 }

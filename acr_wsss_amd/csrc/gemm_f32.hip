@@ -1146,23 +1146,26 @@ __global__ __launch_bounds__(256) void gemm_f32_tail_epilogue_kernel(const GemmF
 // are split s ways along K (R * s <= 512, all resident at once) into fp32 slabs, and one small kernel sums the parts in order
 // and applies the epilogue.  Only worth it from s = 3 on (two halves at two per CU take what R tiles at one per CU take).
 struct TailPlan { int ntail, nsplit, kps; };
-static TailPlan gemm_tail_plan(int M, int N, int K) {
+// x3 (products on images, gemm_f32_planes_kernel): a workgroup alone on its CU leaves every SIMD with ONE wave of six-term
+// MFMA chains and nothing to cover its LDS reads, so launches of up to 256 tiles are split two ways as well.
+static TailPlan gemm_tail_plan(int M, int N, int K, bool x3 = false) {
     TailPlan p = {0, 1, 0};
     if (acr_opt(ACR_OPT_GEMM_F32_NOTAIL) != 0 || (K % F_BK) != 0 || (N % 4) != 0) return p;
     const int tiles = ((M + F_BM - 1) / F_BM) * ((N + F_BN - 1) / F_BN);
     // A product of at most a third of the chip's 512 workgroup slots (CAM generation at batch 2: 18-170 tiles) is all tail:
     // every tile is K-split, up to 16 ways, so that the launch fills the CUs instead of running 24-96 chunks on a few of them.
-    const bool small = tiles * 3 <= 512;
+    const bool small = x3 ? tiles <= 256 : tiles * 3 <= 512;
     const int R = small ? tiles : tiles % 256;
     if ((!small && tiles < 512) || R == 0) return p;
+    const int smin = x3 && small ? 2 : 3;
     int s = 512 / R;
     if (s > (small ? 16 : 8)) s = small ? 16 : 8;
     const int maxs = K / (2 * F_BK);                         // at least two chunks per part
     if (s > maxs) s = maxs;
-    if (s < 3) return p;
+    if (s < smin) return p;
     const int kps = ((K + s - 1) / s + F_BK - 1) / F_BK * F_BK;
     s = (K + kps - 1) / kps;                                // every part non-empty
-    if (s < 3) return p;
+    if (s < smin) return p;
     p.ntail = R; p.nsplit = s; p.kps = kps;
     return p;
 }
@@ -1197,9 +1200,9 @@ static TnPlan tn_plan(int M, int N, int K) {
     return {ns, kps};
 }
 
-static size_t gemm_ws_base_floats(int mode, int M, int N, int K) {
+static size_t gemm_ws_base_floats(int mode, int M, int N, int K, bool x3 = false) {
     if (mode != ACR_GEMM_TN) {
-        const TailPlan tp = gemm_tail_plan(M, N, K);
+        const TailPlan tp = gemm_tail_plan(M, N, K, x3);
         return (size_t)tp.ntail * tp.nsplit * (F_BM * F_BN);
     }
     const TnPlan p = tn_plan(M, N, K);
@@ -1225,7 +1228,7 @@ static PlanesPlan planes_plan(int mode, int math, int M, int N, int K) {
 }
 extern "C" size_t acr_gemm_f32_ws_floats(int32_t mode, int32_t math, int32_t M, int32_t N, int32_t K) {
     const PlanesPlan pl = planes_plan(mode, math, M, N, K);
-    return (gemm_ws_base_floats(mode, M, N, K) + 3) / 4 * 4 + pl.a_fl + pl.b_fl + pl.cs_fl;
+    return (gemm_ws_base_floats(mode, M, N, K, pl.on) + 3) / 4 * 4 + pl.a_fl + pl.b_fl + pl.cs_fl;
 }
 // out[c] = sum over the nparts row-block parts of planes_tile_t_kernel, 16 columns per workgroup, 16 threads per column each
 // summing every 16th part (independent loads in flight), combined through LDS in a fixed order (deterministic)
@@ -1286,7 +1289,7 @@ extern "C" int acr_x3_image_t(const float* x, int64_t ld, int32_t rows, int32_t 
     return acr_check_launch("acr_x3_image_t");
 }
 extern "C" size_t acr_gemm_x3_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K) {
-    return mode == ACR_GEMM_NN ? 0 : (gemm_ws_base_floats(mode, M, N, K) + 3) / 4 * 4;
+    return mode == ACR_GEMM_NN ? 0 : (gemm_ws_base_floats(mode, M, N, K, true) + 3) / 4 * 4;
 }
 extern "C" int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const float* b_img, const float* bias, const float* aux, int64_t ldaux,
                            float* c, int64_t ldc, float* c2, int32_t M, int32_t N, int32_t K, float* ws, void* stream) {
@@ -1322,7 +1325,7 @@ extern "C" int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const 
     }
     ACR_CHECK_ARG(act != 1 || c2, "acr_gemm_x3: act 1 (GELU) needs c2");
     ACR_CHECK_ARG(act != 2 || aux, "acr_gemm_x3: act 2 (GELU') needs the saved derivative in aux");
-    TailPlan tp = gemm_tail_plan(M, N, K);
+    TailPlan tp = gemm_tail_plan(M, N, K, true);
     if (!ws) tp.ntail = 0;
     g.tiles_launch -= tp.ntail;
     if (g.tiles_launch > 0) {
@@ -1375,7 +1378,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float
         g.cs = colsum ? ws + (size_t)p.nsplit * M * N : nullptr;
         const PlanesPlan pl = planes_plan(mode, math, M, N, K);
         if (pl.on) {                                        // both operands split once into images, then the product on the images
-            float* wp = ws + (gemm_ws_base_floats(mode, M, N, K) + 3) / 4 * 4;
+            float* wp = ws + (gemm_ws_base_floats(mode, M, N, K, true) + 3) / 4 * 4;
             float* pa = wp;
             float* pb = wp + pl.a_fl;
             int rc = acr_x3_image(a, lda, K, M, pa, colsum, colsum ? wp + pl.a_fl + pl.b_fl : nullptr, stream);
@@ -1417,7 +1420,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float
     }
     const PlanesPlan pl = planes_plan(mode, math, M, N, K);
     if (pl.on && ws && al16(ws) && vec_ok) {                // both operands split once into images, then the product on the images
-        float* wp = ws + (gemm_ws_base_floats(mode, M, N, K) + 3) / 4 * 4;
+        float* wp = ws + (gemm_ws_base_floats(mode, M, N, K, true) + 3) / 4 * 4;
         float* pa = wp;
         float* pb = wp + pl.a_fl;
         int rc = acr_x3_image(a, lda, M, K, pa, nullptr, nullptr, stream);
@@ -1470,8 +1473,46 @@ static void conv_args(GemmF32Args& g, int M, int N, int K) {
     g.tile0 = 0; g.tiles_launch = g.tiles_m * g.tiles_n;
 }
 
+// Small launches (CAM generation: two views of one image, 8-72 workgroups) under split products: the contraction is split into
+// parts of at least 64 channels so that the launch fills the chip; raw part sums go to slabs [sample][part], summed in part
+// order (+ addend) by conv1x1_ksum_kernel.
+static int conv1x1_ksplit(int nsamp, int cout, int cin, int hw, int* kps_out) {
+    const int tiles = ((cout + F_BM - 1) / F_BM) * ((hw + F_BN - 1) / F_BN) * nsamp;
+    *kps_out = (cin + S_BK - 1) / S_BK * S_BK;
+    if (tiles >= 192 || (cin % F_BK) != 0) return 1;
+    int ks = 512 / tiles;
+    if (ks > cin / 64) ks = cin / 64;
+    if (ks < 2) return 1;
+    const int kps = ((cin + ks - 1) / ks + S_BK - 1) / S_BK * S_BK;
+    *kps_out = kps;
+    return (cin + kps - 1) / kps;
+}
+extern "C" size_t acr_conv1x1_ws_floats(int32_t math, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw) {
+    int kps;
+    if (math != ACR_MATH_BF16X3) return 0;
+    const int ks = conv1x1_ksplit(nsamp, cout, cin, hw, &kps);
+    return ks > 1 ? (size_t)ks * nsamp * cout * hw : 0;
+}
+__global__ __launch_bounds__(256) void conv1x1_ksum_kernel(const float* __restrict__ ws, int ks, int64_t per4, const float* __restrict__ addend,
+                                                           float* __restrict__ y, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int64_t n = i / per4, e = i - n * per4;
+    const f32x4* p = reinterpret_cast<const f32x4*>(ws) + n * ks * per4 + e;
+    f32x4 s = p[0];
+    for (int k = 1; k < ks; ++k) {
+        const f32x4 v = p[(int64_t)k * per4];
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    if (addend) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(addend)[i];
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    reinterpret_cast<f32x4*>(y)[i] = s;
+}
+
 extern "C" int acr_conv1x1_f32(int32_t math, const float* w, int32_t w_transposed, const float* x, const float* addend, float* y, int32_t nsamp,
-                               int32_t cout, int32_t cin, int32_t hw, void* stream) {
+                               int32_t cout, int32_t cin, int32_t hw, float* ws, void* stream) {
     // cout / cin are the channel counts of THIS product.  w_transposed = 0: w is (cout, cin).  w_transposed = 1: w is stored
     // (cin, cout) -- the forward convolution's weight handed over as is for the input gradient, where the roles swap.
     ACR_CHECK_ARG(w && x && y, "acr_conv1x1_f32: null pointer");
@@ -1489,6 +1530,19 @@ extern "C" int acr_conv1x1_f32(int32_t math, const float* w, int32_t w_transpose
     const bool dma = (cin % F_BK) == 0 && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0;
     ACR_CHECK_ARG(math == ACR_MATH_F32 || math == ACR_MATH_BF16X3, "acr_conv1x1_f32: bad math %d", math);
     const bool split = dma && math == ACR_MATH_BF16X3;
+    int kps = 0;
+    const int ks = (split && ws && al16(ws)) ? conv1x1_ksplit(nsamp, cout, cin, hw, &kps) : 1;
+    if (ks > 1) {                           // K-split small launch: slabs [sample][part] of raw sums, then the part sum (+ addend)
+        g.lda = w_transposed ? cout : cin;
+        g.nsplit = nsamp * ks; g.ksplit = ks; g.kps = kps; g.k_zs = kps;
+        g.c = ws; g.ldc = hw; g.aux = nullptr;
+        const dim3 kgrid((unsigned)(g.tiles_m * g.tiles_n * nsamp * ks));
+        if (!w_transposed) hipLaunchKernelGGL((gemm_f32_split_kernel<true, false, 3>), kgrid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_f32_split_kernel<false, false, 3>), kgrid, dim3(256), 0, st, g);
+        const int64_t per4 = (int64_t)cout * hw / 4, n4 = per4 * nsamp;
+        hipLaunchKernelGGL(conv1x1_ksum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, ks, per4, addend, y, n4);
+        return acr_check_launch("acr_conv1x1_f32(K-split)");
+    }
     if (!w_transposed) {                    // w = (cout, cin): rows = output channels, k contiguous
         g.lda = cin;
         if (split) hipLaunchKernelGGL((gemm_f32_split_kernel<true, false, 0>), grid, dim3(256), 0, st, g);

@@ -826,6 +826,14 @@ def conv1x1_fusable(x, weight, stride):
             and (H * W) % 8 == 0)
 
 
+def _conv1x1_f32_launch(math, w2, w_transposed, x, addend, y, N, co, ci, hw):
+    lib = L.load()
+    nws = lib.acr_conv1x1_ws_floats(math, N, co, ci, hw)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+    L.check(lib.acr_conv1x1_f32(math, L.ptr(w2), w_transposed, L.ptr(x), L.ptr(addend), L.ptr(y), N, co, ci, hw, L.ptr(ws), L.stream_ptr()),
+            "acr_conv1x1_f32")
+
+
 class Conv1x1Fn(Function):
     """Stride-1 1x1 convolution in NCHW on the hand-written GEMM kernels (forward, input and weight gradient).
 
@@ -841,7 +849,7 @@ class Conv1x1Fn(Function):
         y = torch.empty((N, co, H, W), dtype=x.dtype, device=x.device)
         if x.dtype == torch.float32:
             w2 = w2.contiguous()
-            L.check(L.load().acr_conv1x1_f32(math, L.ptr(w2), 0, L.ptr(x), None, L.ptr(y), N, co, C, H * W, L.stream_ptr()), "acr_conv1x1_f32")
+            _conv1x1_f32_launch(math, w2, 0, x, None, y, N, co, C, H * W)
         else:
             L.check(L.load().acr_conv1x1_bf16(L.ptr(w2), w2.stride(0), L.ptr(x), None, L.ptr(y), N, co, C, H * W, L.stream_ptr()),
                     "acr_conv1x1_bf16")
@@ -868,8 +876,7 @@ class Conv1x1Fn(Function):
             if ctx.needs_input_grad[0]:
                 w2 = weight.reshape(co, C).contiguous()
                 dx = torch.empty_like(x)
-                L.check(lib.acr_conv1x1_f32(ctx.math, L.ptr(w2), 1, L.ptr(dy), L.ptr(dskip), L.ptr(dx), N, C, co, H * W, L.stream_ptr()),
-                        "acr_conv1x1_f32")
+                _conv1x1_f32_launch(ctx.math, w2, 1, dy, dskip, dx, N, C, co, H * W)
             if ctx.needs_input_grad[1]:
                 ws = torch.empty(lib.acr_conv1x1_wgrad_f32_ws_floats(N, co, C, H * W), dtype=torch.float32, device=x.device)
                 dw = torch.empty((co, C, 1, 1), dtype=torch.float32, device=x.device)
@@ -921,6 +928,13 @@ def conv3x3_fusable(x, weight, stride, math):
             and (x.shape[2] * x.shape[3]) % 16 == 0)
 
 
+def _conv3x3_launch(wp, x, y, N, co, ci, H, W):
+    lib = L.load()
+    nws = lib.acr_conv3x3_ws_floats(N, co, ci, H, W)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+    L.check(lib.acr_conv3x3_f32(1, L.ptr(wp), L.ptr(x), L.ptr(y), N, co, ci, H, W, L.ptr(ws), L.stream_ptr()), "acr_conv3x3_f32")
+
+
 class Conv3x3Fn(Function):
     """3x3 stride-1 SAME convolution in NCHW fp32 with split products as implicit GEMMs (csrc/conv3x3.hip): forward, input
     gradient (the same kernel on dy with the taps flipped and the channel roles swapped) and weight gradient."""
@@ -932,7 +946,7 @@ class Conv3x3Fn(Function):
         x = _with_margin(x)
         wp = weight.permute(0, 2, 3, 1).reshape(co, 9 * C).contiguous()
         y = torch.empty((N, co, H, W), dtype=torch.float32, device=x.device)
-        L.check(L.load().acr_conv3x3_f32(1, L.ptr(wp), L.ptr(x), L.ptr(y), N, co, C, H, W, L.stream_ptr()), "acr_conv3x3_f32")
+        _conv3x3_launch(wp, x, y, N, co, C, H, W)
         ctx.save_for_backward(x, weight)
         return y
 
@@ -947,7 +961,7 @@ class Conv3x3Fn(Function):
         if ctx.needs_input_grad[0]:
             wd = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * co).contiguous()
             dx = torch.empty_like(x)
-            L.check(lib.acr_conv3x3_f32(1, L.ptr(wd), L.ptr(dy), L.ptr(dx), N, C, co, H, W, L.stream_ptr()), "acr_conv3x3_f32")
+            _conv3x3_launch(wd, dy, dx, N, C, co, H, W)
         if ctx.needs_input_grad[1]:
             ws = torch.empty(lib.acr_conv3x3_wgrad_ws_floats(N, co, C, H, W), dtype=torch.float32, device=x.device)
             dwp = torch.empty((co, 3, 3, C), dtype=torch.float32, device=x.device)

@@ -228,8 +228,9 @@ int acr_conv1x1_wgrad_bf16(const void* dy, const void* x, int32_t nsamp, int32_t
  * i.e. the forward weight handed over as is for the input gradient (no transposed copy).  cout / cin / hw multiples of 4.
  * acr_conv1x1_wgrad_f32: dw (cout, cin) = sum_n dy[n] . x[n]^T through one fp32 slab per sample (ws: nsamp*cout*cin floats).
  * math: acr_math, as for acr_gemm_f32. */
+size_t acr_conv1x1_ws_floats(int32_t math, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw);
 int acr_conv1x1_f32(int32_t math, const float* w, int32_t w_transposed, const float* x, const float* addend, float* y, int32_t nsamp,
-                    int32_t cout, int32_t cin, int32_t hw, void* stream);
+                    int32_t cout, int32_t cin, int32_t hw, float* ws, void* stream);
 size_t acr_conv1x1_wgrad_f32_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t hw);
 int acr_conv1x1_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw, float* ws,
                           float* dw, void* stream);
@@ -264,13 +265,16 @@ int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const float* b_im
  * acr_conv3x3_f32: y[n][co][p] = sum_t sum_ci w_packed[co][t*cin + ci] * x[n][ci][p + off_t] (zero outside the image), with
  * w_packed (cout, 9*cin) = w.permute(0,2,3,1) of the (cout, cin, 3, 3) weight.  The input gradient is the same call on dy with
  * w_packed = w.flip(2,3).permute(1,2,3,0) as (cin, 9*cout).  cin %% 16 == 0, H*W %% 4 == 0, 16-byte aligned pointers.
+ * ws: acr_conv3x3_ws_floats(...) floats or NULL (0 for launches that fill the chip: only small ones -- CAM generation on one image --
+ * are split along the contraction into slabs, summed in a fixed order).
  * The shifted tap reads leave x at its two ends (values masked, addresses dereferenced): the caller guarantees
  * ACR_CONV3X3_PAD floats of readable device memory before x and behind its last element (contents irrelevant).
  * acr_conv3x3_wgrad_f32: dw_packed (cout, 9*cin) = sum_n sum_p dy[n][co][p] * x[n][ci][p + off_t]; ws: fp32 slabs of
  * acr_conv3x3_wgrad_ws_floats(...) floats, summed in a fixed order (deterministic). */
 #define ACR_CONV3X3_PAD 512
+size_t acr_conv3x3_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W);
 int acr_conv3x3_f32(int32_t math, const float* w_packed, const float* x, float* y, int32_t nsamp, int32_t cout, int32_t cin,
-                    int32_t H, int32_t W, void* stream);
+                    int32_t H, int32_t W, float* ws, void* stream);
 size_t acr_conv3x3_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W);
 int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W,
                           float* ws, float* dw_packed, void* stream);

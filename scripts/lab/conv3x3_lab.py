@@ -35,7 +35,7 @@ for (N, C, H) in ((32, 64, 112), (32, 128, 56), (32, 256, 28)):
     gf = 2.0 * N * H * H * C * C * 9 * 1e-9
     out = []
     if only in ("", "fwd"):
-        t = timed(lambda: L.check(lib.acr_conv3x3_f32(1, L.ptr(wp), L.ptr(x), L.ptr(y), N, C, C, H, H, L.stream_ptr()), "c3"))
+        t = timed(lambda: L.check(lib.acr_conv3x3_f32(1, L.ptr(wp), L.ptr(x), L.ptr(y), N, C, C, H, H, None, L.stream_ptr()), "c3"))
         out.append("fwd %.1f us (%.0f TF-eq)" % (t, gf / t * 1e3))
     if only in ("", "wgrad"):
         t = timed(lambda: L.check(lib.acr_conv3x3_wgrad_f32(1, L.ptr(dy), L.ptr(x), N, C, C, H, H, L.ptr(ws), L.ptr(dwp), L.stream_ptr()), "c3w"))

@@ -6,7 +6,7 @@ from acr_wsss_amd.DPT.ACR import ACR
 from acr_wsss_amd.infer_cam import infer_cam_image
 dev = "cuda:0"
 torch.manual_seed(0)
-m = ACR(20, "vitb_hybrid", use_pretrain=False).to(dev).eval()
+m = ACR(20, "vitb_hybrid", use_pretrain=False, math=os.environ.get("ACR_MATH", "f32")).to(dev).eval()
 g = torch.Generator().manual_seed(0)
 img = torch.randn(1, 3, 384, 384, generator=g).to(dev)
 lab = torch.zeros(1, 20); lab[0, 3] = 1; lab[0, 11] = 1

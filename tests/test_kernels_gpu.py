@@ -976,13 +976,15 @@ def test_x3_image_planes_sum_to_the_operand_exactly():
 
 
 @pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 64, 16, 16), (1, 16, 48, 12, 20), (2, 128, 128, 28, 28), (1, 64, 64, 112, 112),
-                                             (3, 32, 160, 20, 36), (2, 256, 256, 28, 28)])
+                                             (3, 32, 160, 20, 36), (2, 256, 256, 28, 28), (2, 256, 256, 24, 24), (2, 256, 256, 48, 48),
+                                             (32, 128, 128, 56, 56)])
 def test_conv3x3_split(N, cin, cout, H, W):
     """3x3 stride-1 SAME convolution with split products as an implicit GEMM (csrc/conv3x3.hip): forward, input gradient (same
     kernel, flipped taps) and weight gradient vs fp64 conv2d at the fp32 GEMM tests' tolerance.  Covers cout = 64 (half a tile
     row), pixel tiles that run past H*W and whose rows straddle image rows (W = 20, 28, 36), H != W, 9 cin not a multiple of the
-    tile (cin = 16, 32, 64), several pixel parts in the weight gradient (112 x 112) -- and inputs WITHOUT the margin the entry
-    point asks for (ops copies them into a buffer that has it)."""
+    tile (cin = 16, 32, 64), several pixel parts in the weight gradient (112 x 112), the K-split small launches of CAM generation
+    (two views at 24 x 24 and 48 x 48: 20 / 72 workgroups split 7 ways into slabs), a full-size training launch -- and inputs
+    WITHOUT the margin the entry point asks for (ops copies them into a buffer that has it)."""
     from acr_wsss_amd import ops
     import torch.nn.functional as F
     dev = _dev()
