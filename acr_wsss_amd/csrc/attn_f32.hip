@@ -570,12 +570,14 @@ extern "C" int acr_attn_fwd(const acr_attn_desc* d, const void* q, const void* k
                   "acr_attn_fwd: q/k/v/o must be 16-byte (fp32) / 8-byte (bf16) aligned");
     ACR_CHECK_ARG(!pmean || (pmean_st >= d->T && pmean_sb >= (int64_t)d->T * pmean_st),
                   "acr_attn_fwd: pmean row pitch < T or batch stride < T*pitch");
-    if (f32 && acr_opt(ACR_OPT_ATTN_F32_GEN1) == 0) {
+#ifdef ACR_LAB_ATTN_GEN1          /* lab build (scripts/lab/build_variant.sh): the first-generation register-staged fp32 sweeps */
+    if (f32) return attn_fwd_t<float>(d, q, k, v, o, lse2, pmean, pmean_sb, pmean_st, (hipStream_t)stream);
+#endif
+    if (f32) {
         acr_attn_fwd_f32_dma(geom(d), (const float*)q, (const float*)k, (const float*)v, (float*)o, lse2, pmean, pmean_sb, pmean_st,
                              (hipStream_t)stream);
         return acr_check_launch("acr_attn_fwd");
     }
-    if (f32) return attn_fwd_t<float>(d, q, k, v, o, lse2, pmean, pmean_sb, pmean_st, (hipStream_t)stream);
     const void* ptrs[4] = {q, k, v, o};
     if (d->dtype == ACR_BF16 && acr_bf16_mfma_ok(d, ptrs, 4)) {
         acr_attn_fwd_bf16(d, q, k, v, o, lse2, pmean, pmean_sb, pmean_st, (hipStream_t)stream);
@@ -612,13 +614,15 @@ extern "C" int acr_attn_bwd(const acr_attn_desc* d, const void* q, const void* k
     ACR_CHECK_ARG(f32 ? (aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(d_o))
                       : (aligned8(q) && aligned8(k) && aligned8(v) && aligned8(o) && aligned8(d_o)),
                   "acr_attn_bwd: inputs must be 16-byte (fp32) / 8-byte (bf16) aligned");
-    if (f32 && acr_opt(ACR_OPT_ATTN_F32_GEN1) == 0) {
+#ifdef ACR_LAB_ATTN_GEN1
+    if (f32)
+        return attn_bwd_t<float>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, gmean_st, dq, dk, dv, delta_ws, (hipStream_t)stream);
+#endif
+    if (f32) {
         acr_attn_bwd_f32_dma(geom(d), (const float*)q, (const float*)k, (const float*)v, (const float*)o, (const float*)d_o, lse2,
                              gmean, gmean_sb, gmean_st, (float*)dq, (float*)dk, (float*)dv, delta_ws, (hipStream_t)stream);
         return acr_check_launch("acr_attn_bwd");
     }
-    if (f32)
-        return attn_bwd_t<float>(d, q, k, v, o, d_o, lse2, gmean, gmean_sb, gmean_st, dq, dk, dv, delta_ws, (hipStream_t)stream);
     const void* ptrs[8] = {q, k, v, o, d_o, dq, dk, dv};
     // the bf16-MFMA dQ kernel pulls G in 16-byte groups: it needs a row pitch that is a multiple of 4 floats and
     // covers roundup4(T); other layouts take the exact-fp32 kernels (still HIP, any pitch)
