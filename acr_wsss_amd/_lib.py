@@ -64,9 +64,9 @@ SIGNATURES = {
     "acr_x3_colsum_ws_floats": (c_size_t, [c_int32, c_int32]),
     "acr_x3_image": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acr_x3_image_t": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
-    "acr_gemm_x3_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
-    "acr_gemm_x3": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32,
-                              c_int32, c_void_p, c_void_p]),
+    "acr_gemm_x3_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "acr_gemm_x3": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int32,
+                              c_int32, c_int32, c_void_p, c_void_p]),
     "acr_gemm_f32": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "acr_wgrad_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),

@@ -47,6 +47,7 @@ struct GemmF32Args {
     int tiles_m, tiles_n, nsplit, kps;   // kps: contraction elements per split (multiple of F_BK)
     int tile0, tiles_launch;             // this launch covers tiles tile0 .. tile0 + tiles_launch - 1 (each nsplit times)
     int nkb_a, nkb_b;                    // gemm_f32_planes_tn_kernel: stages (16 features) per token block of the a / b image
+    int img_nkb;                         // image epilogues (ACT 5, 6): stages per row block of the OUTPUT image c2 points at (ceil(N / 16))
     // z-slices: workgroup slice z = split index.  K-split (weight gradient of a Linear): operands shared, k range z*k_zs..;
     // batch (1x1 convolutions per sample): operands / outputs advance by *_zs per slice, k range the whole contraction
     int64_t a_zs, b_zs, c_zs, aux_zs;
@@ -746,6 +747,167 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
 #define P_STAGE_B (6 * P_TILE_B)
 #define PL_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
 
+// ---- image epilogues: the product's output leaves the kernel AS the image the next product reads -----------------------------
+// ACT 5 (fc1 forward): h = acc + bias; c = GELU'(h) in fp32 (all the backward needs of h), c2 = IMAGE of GELU(h) -- fc2's operand
+//        in the forward and in its weight gradient; the fp32 activation is never written.
+// ACT 6 (fc2's input gradient): c2 = IMAGE of acc * aux (aux = the saved GELU'(h)) -- fc1's dy for its input and weight gradient;
+//        cs = per-tile-row parts of its column sums (fc1's bias gradient, summed in tile-row order by planes_colsum_kernel);
+//        no fp32 output at all.
+// Saves the 25 120 x 3072 image passes of both tensors (0.135 ms each, 24 per step) and their fp32 writes.  Rows past M and
+// columns past N are written as zeros (the image contract).
+#define X3E_PITCH 132                 // floats: 528 bytes, 16-byte aligned rows
+__device__ __forceinline__ void planes_split8(const float (&x)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2);
+__device__ __forceinline__ int planes_chunk_off(int rr, int kh);
+// one 16-byte chunk (row row_t of row block tm, columns 8 c8 .. + 7 of output tile column tn) of all three planes
+__device__ __forceinline__ void x3_image_chunk_store(char* img, int tm, int tn, int nkb, int row_t, int c8, const float (&v)[8]) {
+    const int kb = tn * 8 + (c8 >> 1);
+    if (kb >= nkb) return;
+    bf16x8 p0, p1, p2;
+    planes_split8(v, p0, p1, p2);
+    char* dst = img + ((int64_t)tm * nkb + kb) * (3 * 4096) + planes_chunk_off(row_t, c8 & 1);
+    *reinterpret_cast<bf16x8*>(dst) = p0;
+    *reinterpret_cast<bf16x8*>(dst + 4096) = p1;
+    *reinterpret_cast<bf16x8*>(dst + 2 * 4096) = p2;
+}
+// Thread -> chunks of an output tile: pass (half, j) handles row 32 j + (tid >> 3), columns 64 half + 8 (tid & 7) .. + 7 -- the
+// mapping of planes_tile_kernel, so that the column sums below add the same numbers in the same order as the image pass would
+// (a bias gradient does not depend on which of the two produced the image, bit for bit).
+// column sums of a tile from the per-thread sums csum[half][e], through `red` (>= 4096 floats of LDS nobody else is using)
+__device__ __forceinline__ void x3_tile_colsum(const float (&csum)[2][8], float* red, int tid, float* parts_row, int n0, int N) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 3) * 128 + hf * 64 + (tid & 7) * 8 + e] = csum[hf][e];
+    __syncthreads();
+    if (tid < 128 && n0 + tid < N) {
+        float t = red[tid];
+        for (int q = 1; q < 32; ++q) t += red[q * 128 + tid];
+        parts_row[n0 + tid] = t;
+    }
+}
+template <int ACT>
+__device__ __forceinline__ void x3_finish_image(const GemmF32Args& g, f32x16 (&acc)[2][2], float* tl, int tm, int tn, int m0, int n0, int wm,
+                                                int wn, int r, int h, int tid) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col_t = wn * 64 + j * 32 + r, col = n0 + col_t;
+        const bool cok = col < g.N;
+        const float bj = (ACT == 5 && g.bias && cok) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float x[16];
+            if (ACT == 6) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wm * 64 + i * 32 + acr_krow(e, h);
+                    x[e] = (row < g.M && cok) ? g.aux[(int64_t)row * g.ldaux + col] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row_t = wm * 64 + i * 32 + acr_krow(e, h), row = m0 + row_t;
+                const bool ok = row < g.M && cok;
+                float val;
+                if (ACT == 5) {
+                    const float v = acc[i][j][e] + bj;
+                    const float er = erff(v * 0.70710678118654752440f);
+                    val = v * 0.5f * (1.0f + er);
+                    if (ok) g.c[(int64_t)row * g.ldc + col] = 0.5f * (1.0f + er) + v * (expf(-0.5f * v * v) * 0.39894228040143267794f);
+                } else {
+                    val = acc[i][j][e] * x[e];
+                }
+                tl[row_t * X3E_PITCH + col_t] = ok ? val : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    char* img = reinterpret_cast<char*>(g.c2);
+    float csum[2][8];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[hf][e] = 0.f;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row_t = j * 32 + (tid >> 3), c8 = hf * 8 + (tid & 7);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(tl + row_t * X3E_PITCH + c8 * 8);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(tl + row_t * X3E_PITCH + c8 * 8 + 4);
+            const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            if (ACT == 6) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum[hf][e] += v[e];
+            }
+            x3_image_chunk_store(img, tm, tn, g.img_nkb, row_t, c8, v);
+        }
+    if (ACT == 6 && g.cs) {
+        __syncthreads();                                    // every thread is done reading the tile: reuse it for the reduction
+        x3_tile_colsum(csum, tl, tid, g.cs + (int64_t)tm * g.N, n0, g.N);
+    }
+}
+// The same for K-split tail tiles (gemm_tail_plan): one workgroup per tail tile sums its `nsplit` slabs in part order -- a slab is
+// row-major, so a thread's 8 consecutive columns are two float4 per part -- applies the epilogue and writes the image chunks.
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_x3_tail_image_kernel(const GemmF32Args g, const float* __restrict__ ws, int ntail, int nsplit) {
+    __shared__ float red[4096];
+    const int tid = threadIdx.x, tix = blockIdx.x;
+    const int tt = g.tile0 + tix;
+    int tm, tn;
+    tile_coords(tt, g.tiles_m, g.tiles_n, tm, tn);
+    const int m0 = tm * F_BM, n0 = tn * F_BN;
+    char* img = reinterpret_cast<char*>(g.c2);
+    float csum[2][8];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[hf][e] = 0.f;
+#pragma unroll
+    for (int hj = 0; hj < 8; ++hj) {
+        const int hf = hj >> 2, j = hj & 3;
+        const int row_t = j * 32 + (tid >> 3), c8 = hf * 8 + (tid & 7);
+        const int row = m0 + row_t, col = n0 + c8 * 8;
+        const float* p = ws + (int64_t)tix * (F_BM * F_BN) + row_t * F_BN + c8 * 8;
+        f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+        for (int k = 1; k < nsplit; ++k) {
+            const float* q = p + (int64_t)k * ntail * (F_BM * F_BN);
+            const f32x4 u = *reinterpret_cast<const f32x4*>(q), w = *reinterpret_cast<const f32x4*>(q + 4);
+            a[0] += u[0]; a[1] += u[1]; a[2] += u[2]; a[3] += u[3]; b[0] += w[0]; b[1] += w[1]; b[2] += w[2]; b[3] += w[3];
+        }
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        const bool rok = row < g.M;
+        if (rok && col < g.N) {                             // host: N % 8 == 0 for the image epilogues
+            if (ACT == 5) {
+                f32x4 d0, d1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float hv = v[e] + (g.bias ? g.bias[col + e] : 0.f);
+                    const float er = erff(hv * 0.70710678118654752440f);
+                    v[e] = hv * 0.5f * (1.0f + er);
+                    const float d = 0.5f * (1.0f + er) + hv * (expf(-0.5f * hv * hv) * 0.39894228040143267794f);
+                    if (e < 4) d0[e] = d; else d1[e - 4] = d;
+                }
+                float* cp = g.c + (int64_t)row * g.ldc + col;
+                *reinterpret_cast<f32x4*>(cp) = d0; *reinterpret_cast<f32x4*>(cp + 4) = d1;
+            } else {
+                const float* xp = g.aux + (int64_t)row * g.ldaux + col;
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp), x1 = *reinterpret_cast<const f32x4*>(xp + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= e < 4 ? x0[e] : x1[e - 4];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        if (ACT == 6) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[hf][e] += v[e];
+        }
+        x3_image_chunk_store(img, tm, tn, g.img_nkb, row_t, c8, v);
+    }
+    if (ACT == 6 && g.cs) x3_tile_colsum(csum, red, tid, g.cs + (int64_t)tm * g.N, n0, g.N);
+}
+
 template <int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Args g) {
     __shared__ __attribute__((aligned(1024))) float smem[P_SLOTS * P_STAGE_B / 4];      // 72 KiB
@@ -836,7 +998,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
 #undef PL_MFMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end
     __syncthreads();                                        // every wave is done with the ring: the finish may reuse it
-    gemm_f32_finish<true, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, 0.f, false);
+    if (ACT == 5 || ACT == 6) x3_finish_image<ACT>(g, acc, smem, tm, tn, m0, n0, wm, wn, r, h, tid);
+    else gemm_f32_finish<true, ACT == 5 || ACT == 6 ? 0 : ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, 0.f, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1288,14 +1451,17 @@ extern "C" int acr_x3_image_t(const float* x, int64_t ld, int32_t rows, int32_t 
     launch_planes_tile_t(x, ld, rows, cols, (rows + P_BK - 1) / P_BK, image, nullptr, (hipStream_t)stream);
     return acr_check_launch("acr_x3_image_t");
 }
-extern "C" size_t acr_gemm_x3_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K) {
-    return mode == ACR_GEMM_NN ? 0 : (gemm_ws_base_floats(mode, M, N, K, true) + 3) / 4 * 4;
+extern "C" size_t acr_gemm_x3_ws_floats(int32_t mode, int32_t act, int32_t M, int32_t N, int32_t K) {
+    if (mode == ACR_GEMM_NN) return 0;
+    const size_t base = (gemm_ws_base_floats(mode, M, N, K, true) + 3) / 4 * 4;
+    return base + (act == 4 ? ((size_t)((M + F_BM - 1) / F_BM) * N + 3) / 4 * 4 : 0);        // act 4: column-sum parts per tile row
 }
 extern "C" int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const float* b_img, const float* bias, const float* aux, int64_t ldaux,
-                           float* c, int64_t ldc, float* c2, int32_t M, int32_t N, int32_t K, float* ws, void* stream) {
-    ACR_CHECK_ARG(a_img && b_img && c, "acr_gemm_x3: null pointer");
+                           float* c, int64_t ldc, float* c2, float* colsum, int32_t M, int32_t N, int32_t K, float* ws, void* stream) {
+    ACR_CHECK_ARG(a_img && b_img && (c || act == 4), "acr_gemm_x3: null pointer");
     ACR_CHECK_ARG(M > 0 && N > 0 && K > 0, "acr_gemm_x3: empty problem (M=%d N=%d K=%d)", M, N, K);
-    ACR_CHECK_ARG((mode == ACR_GEMM_NT || mode == ACR_GEMM_TN) && act >= 0 && act <= 2, "acr_gemm_x3: mode must be ACR_GEMM_NT or ACR_GEMM_TN (got %d), act 0..2 (got %d)", mode, act);
+    ACR_CHECK_ARG((mode == ACR_GEMM_NT || mode == ACR_GEMM_TN) && act >= 0 && act <= 4, "acr_gemm_x3: mode must be ACR_GEMM_NT or ACR_GEMM_TN (got %d), act 0..4 (got %d)", mode, act);
+    ACR_CHECK_ARG(!colsum || act == 4, "acr_gemm_x3: colsum comes with act 4 only (the image passes give it otherwise)");
     ACR_CHECK_ARG(al16(a_img) && al16(b_img) && al16(c) && (ldc % 4) == 0 && (!bias || al16(bias)) && (!aux || (al16(aux) && (ldaux % 4) == 0)) && (!c2 || al16(c2)),
                   "acr_gemm_x3: pointers must be 16-byte aligned, pitches %% 4 == 0");
     ACR_CHECK_ARG(!ws || al16(ws), "acr_gemm_x3: ws must be 16-byte aligned");
@@ -1323,16 +1489,22 @@ extern "C" int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const 
         hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit, n4, c);
         return acr_check_launch("acr_gemm_x3(TN)");
     }
-    ACR_CHECK_ARG(act != 1 || c2, "acr_gemm_x3: act 1 (GELU) needs c2");
-    ACR_CHECK_ARG(act != 2 || aux, "acr_gemm_x3: act 2 (GELU') needs the saved derivative in aux");
+    ACR_CHECK_ARG((act != 1 && act != 3 && act != 4) || c2, "acr_gemm_x3: act 1 / 3 / 4 need c2");
+    ACR_CHECK_ARG((act != 2 && act != 4) || aux, "acr_gemm_x3: act 2 / 4 (GELU') need the saved derivative in aux");
+    ACR_CHECK_ARG(act < 3 || ((N % 8) == 0 && (!aux || (ldaux % 4) == 0)), "acr_gemm_x3: image epilogues need N %% 8 == 0");
+    ACR_CHECK_ARG(act != 4 || !colsum || ws, "acr_gemm_x3: act 4 with colsum needs ws");
     TailPlan tp = gemm_tail_plan(M, N, K, true);
     if (!ws) tp.ntail = 0;
+    float* parts = (act == 4 && colsum) ? ws + (gemm_ws_base_floats(mode, M, N, K, true) + 3) / 4 * 4 : nullptr;
+    g.cs = parts; g.img_nkb = (N + P_BK - 1) / P_BK;
     g.tiles_launch -= tp.ntail;
     if (g.tiles_launch > 0) {
         const dim3 grid((unsigned)g.tiles_launch);
         if (act == 0) hipLaunchKernelGGL((gemm_f32_planes_kernel<0>), grid, dim3(256), 0, st, g);
         else if (act == 1) hipLaunchKernelGGL((gemm_f32_planes_kernel<1>), grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((gemm_f32_planes_kernel<2>), grid, dim3(256), 0, st, g);
+        else if (act == 2) hipLaunchKernelGGL((gemm_f32_planes_kernel<2>), grid, dim3(256), 0, st, g);
+        else if (act == 3) hipLaunchKernelGGL((gemm_f32_planes_kernel<5>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_f32_planes_kernel<6>), grid, dim3(256), 0, st, g);
     }
     if (tp.ntail) {                                         // the tail tiles, K-split into slabs, and their epilogue (gemm_tail_plan)
         GemmF32Args gt = g;
@@ -1343,8 +1515,11 @@ extern "C" int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const 
         const dim3 egrid((unsigned)(tp.ntail * 16));
         if (act == 0) hipLaunchKernelGGL((gemm_f32_tail_epilogue_kernel<0>), egrid, dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
         else if (act == 1) hipLaunchKernelGGL((gemm_f32_tail_epilogue_kernel<1>), egrid, dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
-        else hipLaunchKernelGGL((gemm_f32_tail_epilogue_kernel<2>), egrid, dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
+        else if (act == 2) hipLaunchKernelGGL((gemm_f32_tail_epilogue_kernel<2>), egrid, dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
+        else if (act == 3) hipLaunchKernelGGL((gemm_x3_tail_image_kernel<5>), dim3((unsigned)tp.ntail), dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
+        else hipLaunchKernelGGL((gemm_x3_tail_image_kernel<6>), dim3((unsigned)tp.ntail), dim3(256), 0, st, ge, (const float*)ws, tp.ntail, tp.nsplit);
     }
+    if (parts) hipLaunchKernelGGL(planes_colsum_kernel, dim3((N + 15) / 16), dim3(256), 0, st, (const float*)parts, g.tiles_m, N, colsum);
     return acr_check_launch("acr_gemm_x3");
 }
 
@@ -1383,7 +1558,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float
             float* pb = wp + pl.a_fl;
             int rc = acr_x3_image(a, lda, K, M, pa, colsum, colsum ? wp + pl.a_fl + pl.b_fl : nullptr, stream);
             if (rc == ACR_OK) rc = acr_x3_image(b, ldb, K, N, pb, nullptr, nullptr, stream);
-            if (rc == ACR_OK) rc = acr_gemm_x3(ACR_GEMM_TN, 0, pa, pb, nullptr, nullptr, 0, c, ldc, nullptr, M, N, K, ws, stream);
+            if (rc == ACR_OK) rc = acr_gemm_x3(ACR_GEMM_TN, 0, pa, pb, nullptr, nullptr, 0, c, ldc, nullptr, nullptr, M, N, K, ws, stream);
             return rc;
         }
         if ((K % F_BK) == 0 && off32_ok(M, N, K, lda, ldb, mode) && acr_opt(ACR_OPT_GEMM_F32_REGSTAGE) == 0 && math == ACR_MATH_BF16X3)
@@ -1425,7 +1600,7 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float
         float* pb = wp + pl.a_fl;
         int rc = acr_x3_image(a, lda, M, K, pa, nullptr, nullptr, stream);
         if (rc == ACR_OK) rc = mode == ACR_GEMM_NT ? acr_x3_image(b, ldb, N, K, pb, nullptr, nullptr, stream) : acr_x3_image_t(b, ldb, K, N, pb, stream);
-        if (rc == ACR_OK) rc = acr_gemm_x3(ACR_GEMM_NT, act, pa, pb, bias, aux, ldaux, c, ldc, c2, M, N, K, ws, stream);
+        if (rc == ACR_OK) rc = acr_gemm_x3(ACR_GEMM_NT, act, pa, pb, bias, aux, ldaux, c, ldc, c2, nullptr, M, N, K, ws, stream);
         return rc;
     }
     if (g.tiles_launch == 0) {                              // a small product: every tile goes the K-split way

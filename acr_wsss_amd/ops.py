@@ -583,19 +583,28 @@ def weight_image(weight, owner=None, transposed=False):
     return img
 
 
-def gemm_x3(mode, a_img, b_img, c, K, bias=None, aux=None, act=0, c2=None):
+def gemm_x3(mode, a_img, b_img, c, K, bias=None, aux=None, act=0, c2=None, colsum=None, shape=None):
     """c[M,N] from split-product images through acr_gemm_x3: 'nt' c = A[M,K] B[N,K]^T (images of A and B), 'tn' c = A[K,M]^T B[K,N]
-    (images of A and B as stored, K rows each)."""
+    (images of A and B as stored, K rows each).  act 3 / 4: the output leaves as an image in ``c2`` (include/acr_hip.h); act 4
+    has no fp32 output (``c`` = None, ``shape`` = (M, N)) and gives its column sums in ``colsum``."""
     lib = L.load()
     md = GEMM_MODES[mode]
-    M, N = c.shape
-    nws = lib.acr_gemm_x3_ws_floats(md, M, N, K)
-    ws = torch.empty(nws, dtype=torch.float32, device=c.device) if nws else None
+    M, N = c.shape if c is not None else shape
+    dev = a_img.device
+    nws = lib.acr_gemm_x3_ws_floats(md, act, M, N, K)
+    ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
     tok = _t0("gemm_x3_" + mode, M, N, K)
     L.check(lib.acr_gemm_x3(md, act, L.ptr(a_img), L.ptr(b_img), L.ptr(bias), L.ptr(aux), aux.stride(0) if aux is not None else 0, L.ptr(c),
-                            c.stride(0), L.ptr(c2), M, N, K, L.ptr(ws), L.stream_ptr()), "acr_gemm_x3")
+                            c.stride(0) if c is not None else N, L.ptr(c2), L.ptr(colsum), M, N, K, L.ptr(ws), L.stream_ptr()), "acr_gemm_x3")
     _t1(tok)
     return c
+
+
+X3_IMAGE_EPILOGUES = os.environ.get("ACR_X3_IMAGE_EPILOGUES", "1") != "0"      # A/B: the MLP's 4x-wide tensors leave their GEMMs as images
+
+
+def x3_image_empty(rows, cols, device):
+    return torch.empty(L.load().acr_x3_image_floats(rows, cols), dtype=torch.float32, device=device)
 
 
 def _f32_ok(*ts):
@@ -687,7 +696,6 @@ class MlpF32Fn(Function):
         M = x2.shape[0]
         Hd, D = w1.shape[0], w2.shape[0]
         h = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
-        a = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
         r2 = resid.reshape(-1, D) if resid is not None else None
         if r2 is not None and not r2.is_contiguous():
             r2 = r2.contiguous()
@@ -696,11 +704,19 @@ class MlpF32Fn(Function):
         ctx.has_resid = resid is not None
         if ctx.images:                                      # the images of x and GELU(h) serve the forward and the weight gradients
             xi = x3_image(x2)
-            gemm_x3("nt", xi, weight_image(w1, fc1), h, shp[-1], bias=b1, act=1, c2=a)
-            ai = x3_image(a)
+            ctx.epi = X3_IMAGE_EPILOGUES and Hd % 8 == 0
+            if ctx.epi:                                     # GELU(h) leaves fc1 as fc2's operand image; it never exists in fp32
+                ai = x3_image_empty(M, Hd, x.device)
+                gemm_x3("nt", xi, weight_image(w1, fc1), h, shp[-1], bias=b1, act=3, c2=ai)
+            else:
+                a = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
+                gemm_x3("nt", xi, weight_image(w1, fc1), h, shp[-1], bias=b1, act=1, c2=a)
+                ai = x3_image(a)
+                del a
             gemm_x3("nt", ai, weight_image(w2, fc2), y, Hd, bias=b2, aux=r2)
             ctx.save_for_backward(xi, h, ai, w1, w2)        # fp32 GELU(h) is not kept: its image is all the backward reads
             return y.reshape(*shp[:-1], D)
+        a = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
         gemm_f32_raw("nt", x2, w1, h, bias=b1, act=1, c2=a, math=math)          # a = GELU(h), and GELU'(h) in place of h (all backward needs)
         gemm_f32_raw("nt", a, w2, y, bias=b2, aux=r2, math=math)
         ctx.save_for_backward(x2, h, a, w1, w2)
@@ -727,10 +743,14 @@ class MlpF32Fn(Function):
             if need[3]:
                 dw2 = torch.empty_like(w2)
                 gemm_x3("tn", dyi, ai, dw2, M)
-            dh = torch.empty_like(h)
-            gemm_x3("nt", dyi, weight_image(w2, ctx.fc2, True), dh, D, aux=h, act=2)              # (dY W2) * GELU'(h); `h` holds GELU'(h) (see forward)
             db1 = torch.empty(Hd, dtype=torch.float32, device=dev) if need[2] else None
-            dhi = x3_image(dh, colsum=db1)
+            if ctx.epi:                                     # (dY W2) * GELU'(h) leaves the product as fc1's dy image (+ its column sums)
+                dhi = x3_image_empty(M, Hd, dev)
+                gemm_x3("nt", dyi, weight_image(w2, ctx.fc2, True), None, D, aux=h, act=4, c2=dhi, colsum=db1, shape=(M, Hd))
+            else:
+                dh = torch.empty_like(h)
+                gemm_x3("nt", dyi, weight_image(w2, ctx.fc2, True), dh, D, aux=h, act=2)          # `h` holds GELU'(h) (see forward)
+                dhi = x3_image(dh, colsum=db1)
             if need[1]:
                 dw1 = torch.empty_like(w1)
                 gemm_x3("tn", dhi, xi, dw1, M)

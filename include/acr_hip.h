@@ -250,15 +250,21 @@ int acr_conv1x1_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t
  *     ACR_GEMM_NT  c = A[M,K] . B[N,K]^T   a_img = image of A (M x K), b_img = image of B (N x K)
  *     ACR_GEMM_TN  c = A[K,M]^T . B[K,N]   a_img = image of A (K x M), b_img = image of B (K x N) -- the SAME images of dy and x
  *                  the other two products read (fragments are read transposed from LDS).
- *   ws: acr_gemm_x3_ws_floats(mode, M, N, K) floats (TN: required; NT: K-split tail slabs, may be NULL).
+ *     act (NT): 0, 1, 2 as acr_gemm_f32; and two epilogues whose output leaves the kernel AS the image the next product reads
+ *       (an MLP's 4x-wide tensors never exist in fp32; N %% 8 == 0):
+ *       3: with h = acc + bias: c = GELU'(h) (fp32, as act 1) and c2 = IMAGE of GELU(h) (acr_x3_image_floats(M, N) floats);
+ *       4: c2 = IMAGE of acc * aux, c unused (may be NULL), colsum (nullable, (N)) = its column sums (the bias gradient of
+ *          the Linear whose dy this is), deterministic.
+ *   ws: acr_gemm_x3_ws_floats(mode, act, M, N, K) floats (TN: required; NT: K-split tail slabs (+ act 4: column-sum parts), may be
+ *       NULL when colsum is NULL).
  * acr_gemm_f32(math = ACR_MATH_BF16X3) is these calls on images it makes in its own workspace. */
 size_t acr_x3_image_floats(int32_t rows, int32_t cols);
 size_t acr_x3_colsum_ws_floats(int32_t rows, int32_t cols);
 int acr_x3_image(const float* x, int64_t ld, int32_t rows, int32_t cols, float* image, float* colsum, float* colsum_ws, void* stream);
 int acr_x3_image_t(const float* x, int64_t ld, int32_t rows, int32_t cols, float* image, void* stream);
-size_t acr_gemm_x3_ws_floats(int32_t mode, int32_t M, int32_t N, int32_t K);
+size_t acr_gemm_x3_ws_floats(int32_t mode, int32_t act, int32_t M, int32_t N, int32_t K);
 int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const float* b_img, const float* bias, const float* aux, int64_t ldaux, float* c,
-                int64_t ldc, float* c2, int32_t M, int32_t N, int32_t K, float* ws, void* stream);
+                int64_t ldc, float* c2, float* colsum, int32_t M, int32_t N, int32_t K, float* ws, void* stream);
 
 /* ---- 3x3 stride-1 SAME convolutions of the stem's bottlenecks (models/resnetv2.py:171-216 `conv2`; std_conv.py:40-65) in NCHW fp32
  * as implicit GEMMs with split products on the bf16 MFMA (math = ACR_MATH_BF16X3 only: ACR_ERR_UNSUPPORTED otherwise -- the

@@ -922,6 +922,38 @@ def test_gemm_x3_images(M, N, K):
         assert torch.equal(dw, dw3)                          # fixed slab order
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 3072, 768), (25120, 3072, 768), (2100, 520, 96)])
+def test_gemm_x3_image_epilogues(M, N, K):
+    """acr_gemm_x3 act 3 / 4: the product's output leaves the kernel as the next product's image.  The image equals, bit for bit,
+    the image pass run over the fp32 result of act 1 / 2 (same erf form, same split), the fp32 GELU' of act 3 equals act 1's, and
+    act 4's column sums equal the image pass's (same summation order); covers the K-split tail tiles (1000 x 3072: 192 tiles, all
+    tail; 25120 x 3072: 120 of 4728), partial row blocks and a last column tile that is not full (N = 520)."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    xi, wi = ops.x3_image(x), ops.x3_image(w)
+    h1, a1 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    ops.gemm_x3("nt", xi, wi, h1, K, bias=b, act=1, c2=a1)
+    h3, ai = torch.empty(M, N, device=dev), ops.x3_image_empty(M, N, dev)
+    ai.fill_(float("nan"))
+    ops.gemm_x3("nt", xi, wi, h3, K, bias=b, act=3, c2=ai)
+    assert torch.equal(h1, h3)
+    assert torch.equal(ai.view(torch.int32), ops.x3_image(a1).view(torch.int32))
+    aux = torch.randn(M, N, generator=g).to(dev)
+    d2 = torch.empty(M, N, device=dev)
+    ops.gemm_x3("nt", xi, wi, d2, K, aux=aux, act=2)
+    db_ref = torch.empty(N, device=dev)
+    ref_img = ops.x3_image(d2, colsum=db_ref)
+    di, db = ops.x3_image_empty(M, N, dev), torch.empty(N, device=dev)
+    di.fill_(float("nan"))
+    ops.gemm_x3("nt", xi, wi, None, K, aux=aux, act=4, c2=di, colsum=db, shape=(M, N))
+    assert torch.equal(di.view(torch.int32), ref_img.view(torch.int32))
+    assert torch.equal(db, db_ref)
+
+
 def test_split_linears_take_the_image_path():
     """Linear and MLP under split products keep operand images across forward and backward (the path bench.py measures): the
     autograd nodes say so, no fp32 GELU output is kept, and values / gradients equal the per-call path's bit for bit."""
@@ -932,21 +964,23 @@ def test_split_linears_take_the_image_path():
     x = torch.randn(3, 100, 256, device=dev, requires_grad=True)
     res = torch.randn(3, 100, 256, device=dev)
     out = {}
-    for images in (True, False):
-        ops.X3_IMAGES = images
+    for images in (True, "no epilogue images", False):
+        ops.X3_IMAGES = bool(images)
+        ops.X3_IMAGE_EPILOGUES = images is True
         try:
             for p_ in (x, *fc1.parameters(), *fc2.parameters()):
                 p_.grad = None
             y = ops.linear_or_hip(x, fc1, math=1)
-            assert y.grad_fn.images == images
+            assert y.grad_fn.images == bool(images)
             z = ops.mlp_f32(x, fc1, fc2, resid=res, math=1)
-            assert z.grad_fn.images == images
+            assert z.grad_fn.images == bool(images) and (not images or z.grad_fn.epi == (images is True))
             (y.sum() * 0.5 + (z * res).sum()).backward()
             out[images] = [t.detach().clone() for t in (y, z, x.grad, fc1.weight.grad, fc1.bias.grad, fc2.weight.grad, fc2.bias.grad)]
         finally:
-            ops.X3_IMAGES = True
-    for a, b in zip(out[True], out[False]):
-        assert torch.equal(a, b)
+            ops.X3_IMAGES = ops.X3_IMAGE_EPILOGUES = True
+    for other in ("no epilogue images", False):
+        for a, b in zip(out[True], out[other]):
+            assert torch.equal(a, b)
 
 
 def test_x3_image_planes_sum_to_the_operand_exactly():
