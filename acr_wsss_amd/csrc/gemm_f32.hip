@@ -950,7 +950,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
 #pragma unroll
     for (int i = 0; i < 6; ++i) dma1(min(1, nst - 1), 1, i);
     bf16x8 ap[2][2][3], bp[2][2][3];                        // [register set][block][plane]
+#if defined(PL_LAB_MFMA16) && defined(PL_LAB_READS20)     /* + 8 more fragment reads per stage (20 instead of 12) */
+    bf16x8 xr[8];
+#define PL_LAB_EXTRA(K12) if ((K12) < 8) PL_RD(xr[(K12)], fas, ((K12) % 3) * P_TILE_B + 512);
+#else
+#define PL_LAB_EXTRA(K12)
+#endif
+#ifdef PL_LAB_MFMA16      /* lab timing build (wrong results): the same operand registers through twice as many 16x16x32 MFMAs -- same matrix cycles */
+    f32x4 a16[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { a16[i][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; a16[i][j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#define PL_MFMA(SET, I, J, PA, PB)                                                                                          \
+    a16[I][J][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[SET][I][PA], bp[SET][J][PB], a16[I][J][0], 0, 0, 0);          \
+    a16[I][J][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bp[SET][J][PB], ap[SET][I][PA], a16[I][J][1], 0, 0, 0);
+#else
 #define PL_MFMA(SET, I, J, PA, PB) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][PA], bp[SET][J][PB], acc[I][J], 0, 0, 0);
+#endif
 #define PL_PAIR(SET, I, J, T)                                                       \
     if (T == 0) { PL_MFMA(SET, I, J, 0, 2) PL_MFMA(SET, I, J, 2, 0) }              \
     else if (T == 1) { PL_MFMA(SET, I, J, 1, 1) PL_MFMA(SET, I, J, 0, 1) }         \
@@ -971,6 +988,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
         if ((K12) < 6) PL_RD(ap[SET][(K12) / 3][(K12) % 3], fas, ((K12) % 3) * P_TILE_B + ((K12) / 3) * 1024);          \
         else PL_RD(bp[SET][((K12) - 6) / 3][(K12) % 3], fbs, ((K12) % 3) * P_TILE_B + (((K12) - 6) / 3) * 1024);        \
         if ((K12) & 1) dma1(rst, rslot, (K12) >> 1);                                                                   \
+        PL_LAB_EXTRA(K12)                                                                                               \
         __builtin_amdgcn_sched_barrier(0);
         PL_GROUP(0) PL_GROUP(1) PL_GROUP(2) PL_GROUP(3) PL_GROUP(4) PL_GROUP(5)
         PL_GROUP(6) PL_GROUP(7) PL_GROUP(8) PL_GROUP(9) PL_GROUP(10) PL_GROUP(11)
@@ -989,6 +1007,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
             slot = slot == 2 ? 0 : slot + 1;
         }
     }
+#if defined(PL_LAB_MFMA16) && defined(PL_LAB_READS20)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) asm volatile("" :: "v"(xr[q]));
+#endif
 #define PL_ALL(SET)                                                                                      \
     PL_PAIR(SET, 0, 0, 0) PL_PAIR(SET, 0, 0, 1) PL_PAIR(SET, 0, 0, 2) PL_PAIR(SET, 0, 1, 0) PL_PAIR(SET, 0, 1, 1) PL_PAIR(SET, 0, 1, 2) \
     PL_PAIR(SET, 1, 0, 0) PL_PAIR(SET, 1, 0, 1) PL_PAIR(SET, 1, 0, 2) PL_PAIR(SET, 1, 1, 0) PL_PAIR(SET, 1, 1, 1) PL_PAIR(SET, 1, 1, 2)
@@ -996,6 +1018,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
 #undef PL_ALL
 #undef PL_PAIR
 #undef PL_MFMA
+#ifdef PL_LAB_MFMA16
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[i][j][e] += a16[i][j][0][e]; acc[i][j][4 + e] += a16[i][j][1][e]; }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end
     __syncthreads();                                        // every wave is done with the ring: the finish may reuse it
     if (ACT == 5 || ACT == 6) x3_finish_image<ACT>(g, acc, smem, tm, tn, m0, n0, wm, wn, r, h, tid);
