@@ -79,6 +79,7 @@ SIGNATURES = {
     "acr_conv1x1_wgrad_bf16": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                          c_void_p]),
     "acr_conv1x1_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "acr_conv1x1_x3": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "acr_conv1x1_f32": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "acr_conv1x1_wgrad_f32_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "acr_conv1x1_wgrad_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

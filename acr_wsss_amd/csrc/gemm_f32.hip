@@ -1149,6 +1149,129 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_tn_kernel(const GemmF3
     gemm_f32_finish<true, 3>(g, acc, smem, split, tt, tn, m0, n0, 0, wm, wn, r, h, tid, 0.f, false);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The stem's 1x1 convolutions (forward and input gradient) under split products: y[n] (M x pixels) = W (M x K) . x[n] (K x pixels).
+// The weight is tiny and shared by every workgroup: it comes as an IMAGE (acr_x3_image / acr_x3_image_t of the standardised
+// weight), so only the activation tile -- fp32 [k][pixels] as stored, no pass over the big tensors -- is split in registers:
+// half the VALU work of gemm_f32_split_kernel per MFMA (that kernel is VALU-port bound, profiles/r04_pmc_split_gemm.txt).
+// Slot = [A p0 p1 p2 (12 KiB, one contiguous piece of the image) | B fp32 16 k-rows x 128 pixels (8 KiB)], ring of 3, DMA two
+// stages ahead, 5 pieces per wave and stage (3 of A, 2 of B); waits, barrier and interleaving as gemm_f32_planes_kernel.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define W_STAGE_B (3 * P_TILE_B + S_TILE * 4)        // 20 KiB
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_f32_wimg_kernel(const GemmF32Args g) {
+    __shared__ __attribute__((aligned(1024))) float smem[P_SLOTS * W_STAGE_B / 4];      // 60 KiB
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int ntile = g.tiles_launch;
+    const int t0 = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
+    const int split = t0 / ntile, tt = g.tile0 + (t0 - split * ntile);
+    int tm, tn;
+    if (ACT == 3) { tm = tt / g.tiles_n; tn = tt - tm * g.tiles_n; }
+    else tile_coords(tt, g.tiles_m, g.tiles_n, tm, tn);
+    const int m0 = tm * F_BM, n0 = tn * F_BN;
+    const int zs = split / g.ksplit;
+    const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);      // host: multiples of 16
+    const int nkb = (g.K + P_BK - 1) / P_BK;
+    const char* __restrict__ pa = reinterpret_cast<const char*>(g.a) + ((int64_t)tm * nkb + kbeg / P_BK) * (3 * P_TILE_B) + wave * 3072 + lane * 16;
+    const float* __restrict__ pb = g.b + (int64_t)zs * g.b_zs + (int64_t)kbeg * g.ldb;
+    int offb[2];                                            // B pieces 2 wave + i: k rows 2 (2 wave + i) + (lane >> 5), 4 pixels per lane
+#pragma unroll
+    for (int i = 0; i < 2; ++i) offb[i] = ((wave * 2 + i) * 2 + (lane >> 5)) * (int)g.ldb + min(n0 + 4 * (lane & 31), g.N - 4);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nst = (kend - kbeg) / P_BK;
+    char* sm = reinterpret_cast<char*>(smem);
+    auto dma1 = [&](int st, int slot, int i) {              // i = 0..2: A pieces 3 wave + i; i = 3, 4: B pieces 2 wave + (i - 3)
+        if (i < 3)
+            __builtin_amdgcn_global_load_lds((glb_vp)(pa + (int64_t)st * (3 * P_TILE_B) + i * 1024), (lds_vp)(sm + slot * W_STAGE_B + (wave * 3 + i) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((glb_vp)(pb + (int64_t)st * P_BK * g.ldb + offb[i - 3]),
+                                             (lds_vp)(sm + slot * W_STAGE_B + 3 * P_TILE_B + (wave * 2 + i - 3) * 1024), 16, 0, 0);
+    };
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)sm;
+    const uint32_t fa = lbase + (wm * 64 + r) * 32 + (h ^ ((r >> 3) & 1)) * 16;
+    const uint32_t fb = lbase + 3 * P_TILE_B + ((8 * h) * F_BN + wn * 64 + r) * 4;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma1(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma1(min(1, nst - 1), 1, i);
+    bf16x8 ap[2][2][3], bp[2][2][3];                        // [register set][block][plane]
+    float rb[2][8];
+#define WI_MFMA6(SET, I, J)                                                                                                  \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][2], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][2], bp[SET][J][0], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][1], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][1], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][0], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][0], acc[I][J], 0, 0, 0);
+#define WI_RD32(dst, addr, OFF) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
+    auto step = [&](int st, int slot, auto set_tag, auto first_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // younger: the 5 pieces of stage st + 1
+        acr_barrier_nofence();
+        const int rslot = slot == 0 ? 2 : slot - 1;         // (st + 2) % 3
+        const int rst = min(st + 2, nst - 1);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma1(rst, rslot, i);
+        const uint32_t fas = fa + slot * W_STAGE_B, fbs = fb + slot * W_STAGE_B;
+        // stage st: the B fragments raw (fp32, 8 k of one pixel per lane), the A fragments as planes
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            WI_RD32(rb[j][0], fbs, 0 * F_BN * 4 + j * 128); WI_RD32(rb[j][1], fbs, 1 * F_BN * 4 + j * 128); WI_RD32(rb[j][2], fbs, 2 * F_BN * 4 + j * 128);
+            WI_RD32(rb[j][3], fbs, 3 * F_BN * 4 + j * 128); WI_RD32(rb[j][4], fbs, 4 * F_BN * 4 + j * 128); WI_RD32(rb[j][5], fbs, 5 * F_BN * 4 + j * 128);
+            WI_RD32(rb[j][6], fbs, 6 * F_BN * 4 + j * 128); WI_RD32(rb[j][7], fbs, 7 * F_BN * 4 + j * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            PL_RD(ap[SET][i][0], fas, 0 * P_TILE_B + i * 1024); PL_RD(ap[SET][i][1], fas, 1 * P_TILE_B + i * 1024); PL_RD(ap[SET][i][2], fas, 2 * P_TILE_B + i * 1024);
+        }
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[0][2]), "+v"(rb[0][3]), "+v"(rb[0][4]), "+v"(rb[0][5]), "+v"(rb[0][6]),
+                     "+v"(rb[0][7]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[1][2]), "+v"(rb[1][3]), "+v"(rb[1][4]), "+v"(rb[1][5]), "+v"(rb[1][6]), "+v"(rb[1][7]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 lo = {rb[j][0], rb[j][1], rb[j][2], rb[j][3]}, hi = {rb[j][4], rb[j][5], rb[j][6], rb[j][7]};
+            split3_bf16(lo, hi, bp[SET][j][0], bp[SET][j][1], bp[SET][j][2]);
+        }
+        if (!FIRST) {
+            WI_MFMA6(SET ^ 1, 0, 0) WI_MFMA6(SET ^ 1, 0, 1) WI_MFMA6(SET ^ 1, 1, 0) WI_MFMA6(SET ^ 1, 1, 1)
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA of stage st - 1
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // four VALU instructions of stage st's split
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ap[SET][0][0]), "+v"(ap[SET][0][1]), "+v"(ap[SET][0][2]), "+v"(ap[SET][1][0]), "+v"(ap[SET][1][1]), "+v"(ap[SET][1][2]));
+    };
+    step(0, 0, std::integral_constant<int, 0>{}, std::true_type{});
+    int slot = 1;
+    for (int st = 1; st < nst; st += 2) {
+        step(st, slot, std::integral_constant<int, 1>{}, std::false_type{});
+        slot = slot == 2 ? 0 : slot + 1;
+        if (st + 1 < nst) {
+            step(st + 1, slot, std::integral_constant<int, 0>{}, std::false_type{});
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+    if (nst & 1) { WI_MFMA6(0, 0, 0) WI_MFMA6(0, 0, 1) WI_MFMA6(0, 1, 0) WI_MFMA6(0, 1, 1) }
+    else { WI_MFMA6(1, 0, 0) WI_MFMA6(1, 0, 1) WI_MFMA6(1, 1, 0) WI_MFMA6(1, 1, 1) }
+#undef WI_MFMA6
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end
+    __syncthreads();
+    gemm_f32_finish<true, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, 0.f, false);
+}
+
 // ---- the split passes (HBM-bound: 4 bytes read, 6 written per element) ----------------------------------------------------------
 __device__ __forceinline__ void planes_split8(const float (&x)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
 #pragma unroll
@@ -1760,6 +1883,36 @@ extern "C" int acr_conv1x1_f32(int32_t math, const float* w, int32_t w_transpose
         else hipLaunchKernelGGL((gemm_f32_kernel<false, false, 0>), grid, dim3(256), 0, st, g);
     }
     return acr_check_launch("acr_conv1x1_f32");
+}
+
+// The same convolution with the weight given as a split-product image (acr_x3_image of W (cout x cin) for the forward;
+// acr_x3_image_t of the forward's W for the input gradient, where cout / cin are THIS product's): gemm_f32_wimg_kernel.
+extern "C" int acr_conv1x1_x3(const float* w_img, const float* x, const float* addend, float* y, int32_t nsamp, int32_t cout, int32_t cin,
+                              int32_t hw, float* ws, void* stream) {
+    ACR_CHECK_ARG(w_img && x && y, "acr_conv1x1_x3: null pointer");
+    ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && hw >= 4 && (hw % 4) == 0 && (cin % P_BK) == 0 && (cout % 4) == 0,
+                  "acr_conv1x1_x3: need hw, cout %% 4 == 0, cin %% 16 == 0 (n=%d co=%d ci=%d hw=%d)", nsamp, cout, cin, hw);
+    ACR_CHECK_ARG(al16(w_img) && al16(x) && al16(y) && al16(addend), "acr_conv1x1_x3: 16-byte alignment");
+    ACR_CHECK_ARG((int64_t)cin * hw < (1ll << 30), "acr_conv1x1_x3: sample too large for 32-bit offsets");
+    hipStream_t st = (hipStream_t)stream;
+    GemmF32Args g;
+    conv_args(g, cout, hw, cin);
+    g.a = w_img; g.lda = 0; g.b = x; g.ldb = hw; g.b_zs = (int64_t)cin * hw;
+    g.c = y; g.ldc = hw; g.c_zs = (int64_t)cout * hw;
+    g.aux = addend; g.ldaux = hw; g.aux_zs = (int64_t)cout * hw;
+    g.nsplit = nsamp; g.kps = cin; g.k_zs = 0;
+    int kps = 0;
+    const int ks = (ws && al16(ws)) ? conv1x1_ksplit(nsamp, cout, cin, hw, &kps) : 1;
+    if (ks > 1) {                                           // K-split small launch (conv1x1_ksplit): slabs, then the part sum (+ addend)
+        g.nsplit = nsamp * ks; g.ksplit = ks; g.kps = kps; g.k_zs = kps;
+        g.c = ws; g.aux = nullptr;
+        hipLaunchKernelGGL((gemm_f32_wimg_kernel<3>), dim3((unsigned)(g.tiles_m * g.tiles_n * nsamp * ks)), dim3(256), 0, st, g);
+        const int64_t per4 = (int64_t)cout * hw / 4, n4 = per4 * nsamp;
+        hipLaunchKernelGGL(conv1x1_ksum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, ks, per4, addend, y, n4);
+        return acr_check_launch("acr_conv1x1_x3(K-split)");
+    }
+    hipLaunchKernelGGL((gemm_f32_wimg_kernel<0>), dim3((unsigned)(g.tiles_m * g.tiles_n * nsamp)), dim3(256), 0, st, g);
+    return acr_check_launch("acr_conv1x1_x3");
 }
 
 // pixels of a sample are additionally split so that tiles x samples x parts fills the chip's 512 workgroup slots (a 64x64

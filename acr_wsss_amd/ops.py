@@ -846,10 +846,18 @@ def conv1x1_fusable(x, weight, stride):
             and (H * W) % 8 == 0)
 
 
+CONV1X1_WIMG = os.environ.get("ACR_CONV1X1_WIMG", "1") != "0"      # A/B: split-product 1x1 convolutions with the weight as an image
+
+
 def _conv1x1_f32_launch(math, w2, w_transposed, x, addend, y, N, co, ci, hw):
+    """y[n] (co x hw) = W . x[n] (+ addend).  w_transposed = 0: w2 is (co, ci); 1: w2 is the forward's (ci, co) weight (input gradient)."""
     lib = L.load()
     nws = lib.acr_conv1x1_ws_floats(math, N, co, ci, hw)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+    if math == 1 and CONV1X1_WIMG and ci % 32 == 0:
+        wi = x3_image_t(w2) if w_transposed else x3_image(w2)
+        L.check(lib.acr_conv1x1_x3(L.ptr(wi), L.ptr(x), L.ptr(addend), L.ptr(y), N, co, ci, hw, L.ptr(ws), L.stream_ptr()), "acr_conv1x1_x3")
+        return
     L.check(lib.acr_conv1x1_f32(math, L.ptr(w2), w_transposed, L.ptr(x), L.ptr(addend), L.ptr(y), N, co, ci, hw, L.ptr(ws), L.stream_ptr()),
             "acr_conv1x1_f32")
 

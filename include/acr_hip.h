@@ -232,6 +232,11 @@ int acr_conv1x1_wgrad_bf16(const void* dy, const void* x, int32_t nsamp, int32_t
 size_t acr_conv1x1_ws_floats(int32_t math, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw);
 int acr_conv1x1_f32(int32_t math, const float* w, int32_t w_transposed, const float* x, const float* addend, float* y, int32_t nsamp,
                     int32_t cout, int32_t cin, int32_t hw, float* ws, void* stream);
+/* acr_conv1x1_x3: the same product under ACR_MATH_BF16X3 with the weight given as a split-product image -- acr_x3_image of W
+ * (cout, cin) for the forward, acr_x3_image_t of the forward's weight for the input gradient -- so that only the activation tile
+ * is split inside the kernel (half the vector work per MFMA).  cin %% 16 == 0; ws as acr_conv1x1_f32 (acr_conv1x1_ws_floats). */
+int acr_conv1x1_x3(const float* w_img, const float* x, const float* addend, float* y, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw,
+                   float* ws, void* stream);
 size_t acr_conv1x1_wgrad_f32_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t hw);
 int acr_conv1x1_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw, float* ws,
                           float* dw, void* stream);
