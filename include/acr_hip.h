@@ -85,8 +85,8 @@ typedef enum acr_option {
     ACR_OPT_WGRAD_WAVES = 4,    /* 4 or 8 waves per 256x256 workgroup */
     ACR_OPT_DQ_VARIANT = 5,     /* acr_attn_bwd (bf16) dQ sweep: 0 = by presence of G, 2 = 2-wave, 4 = 4-wave */
     ACR_OPT_GEMM_F32_REGSTAGE = 6, /* 1: acr_gemm_f32 always takes the register-staged kernel (A/B of the LDS-DMA kernel) */
-    ACR_OPT_RESERVED_7 = 7,     /* was ACR_OPT_ATTN_F32_GEN1: the first-generation fp32 attention sweeps left the product library (round 4;
-                                   lab build flag -DACR_LAB_ATTN_GEN1, scripts/lab/build_variant.sh) */
+    ACR_OPT_GEMM_X3_MFMA16 = 7, /* 1: acr_gemm_x3 on v_mfma_f32_16x16x32_bf16 (two split terms per MFMA) instead of 32x32x16 (A/B: measured no faster).
+                                   (Option 7 was ACR_OPT_ATTN_F32_GEN1 in ABI 1: those sweeps left the library, lab flag -DACR_LAB_ATTN_GEN1.) */
     ACR_OPT_ATTN_F32_NW = 8,    /* acr_attn_fwd_scores: 5 = five 32-query blocks (waves) per forward workgroup instead of four (A/B: slower) */
     ACR_OPT_GEMM_F32_NOTAIL = 9, /* 1: acr_gemm_f32 NT / NN never K-splits the tiles beyond the last whole half-round (A/B) */
     ACR_OPT_ATTN_F32_NOSPLITTAIL = 10, /* 1: resident-score attention keeps the leftover 32-row block as an ordinary (1 live wave) workgroup (A/B) */

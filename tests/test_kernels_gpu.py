@@ -877,8 +877,18 @@ def test_conv1x1_f32(N, cin, cout, H, W, math):
         assert err <= 1e-5, (n, float(err))
 
 
+@pytest.fixture
+def x3_mfma(request):
+    """acr_gemm_x3 on its default 32x32x16 MFMAs or on the 16x16x32 A/B kernels (two split terms per MFMA, LDS-staged finish)."""
+    from acr_wsss_amd import _lib
+    _lib.set_option("gemm_x3_mfma16", 1 if request.param == "mfma16" else 0)
+    yield request.param
+    _lib.set_option("gemm_x3_mfma16", 0)
+
+
+@pytest.mark.parametrize("x3_mfma", ["mfma32", "mfma16"], indirect=True)
 @pytest.mark.parametrize("M,N,K", [(300, 200, 100), (128, 128, 16), (1000, 768, 772), (2500, 64, 3072), (37, 260, 40)])
-def test_gemm_x3_images(M, N, K):
+def test_gemm_x3_images(M, N, K, x3_mfma):
     """The split-product image API (acr_x3_image / acr_x3_image_t / acr_gemm_x3): NT with bias + residual, the input-gradient form
     through the transposed image of the weight, TN on the SAME images of dy and x the other two products read (transposed LDS
     reads), column sums of dy from the image pass -- vs float64 at the fp32 GEMM tests' tolerance; shapes with partial row
@@ -922,8 +932,9 @@ def test_gemm_x3_images(M, N, K):
         assert torch.equal(dw, dw3)                          # fixed slab order
 
 
+@pytest.mark.parametrize("x3_mfma", ["mfma32", "mfma16"], indirect=True)
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 3072, 768), (25120, 3072, 768), (2100, 520, 96)])
-def test_gemm_x3_image_epilogues(M, N, K):
+def test_gemm_x3_image_epilogues(M, N, K, x3_mfma):
     """acr_gemm_x3 act 3 / 4: the product's output leaves the kernel as the next product's image.  The image equals, bit for bit,
     the image pass run over the fp32 result of act 1 / 2 (same erf form, same split), the fp32 GELU' of act 3 equals act 1's, and
     act 4's column sums equal the image pass's (same summation order); covers the K-split tail tiles (1000 x 3072: 192 tiles, all
