@@ -118,8 +118,9 @@ SIGNATURES = {
     "acr_groupnorm_bwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                          c_void_p]),
+    "acr_groupnorm_fwd_ws_floats": (c_size_t, [c_int32, c_int32, c_int32]),
     "acr_groupnorm_fwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
-                                        c_float, c_int32, c_void_p]),
+                                        c_float, c_int32, c_void_p, c_void_p]),
     "acr_groupnorm_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "acr_weight_std_bf16": (c_int32, [c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p]),

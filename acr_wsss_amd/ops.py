@@ -1111,9 +1111,15 @@ class GroupNormActFn(Function):
         lib = L.load()
         y = empty_with_margin(x)                          # a 3x3 convolution reads it next (Conv3x3Fn)
         stats = torch.empty(N * 32 * 2, dtype=torch.float32, device=x.device)
-        fwd = lib.acr_groupnorm_fwd_f32 if x.dtype == torch.float32 else lib.acr_groupnorm_fwd_bf16
-        L.check(fwd(L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), N, C, H * W, eps, act, L.stream_ptr()),
-                "acr_groupnorm_fwd")
+        if x.dtype == torch.float32:
+            # gradient-free passes (CAM generation) of a few samples: the (sample, group) pairs are cut into parts (two launches)
+            nws = lib.acr_groupnorm_fwd_ws_floats(N, C, H * W) if not any(ctx.needs_input_grad) else 0
+            ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+            L.check(lib.acr_groupnorm_fwd_f32(L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), N, C, H * W, eps, act,
+                                              L.ptr(ws), L.stream_ptr()), "acr_groupnorm_fwd_f32")
+        else:
+            L.check(lib.acr_groupnorm_fwd_bf16(L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), N, C, H * W, eps, act,
+                                               L.stream_ptr()), "acr_groupnorm_fwd_bf16")
         ctx.save_for_backward(x, weight, bias, stats, resid if act == 2 else None)
         ctx.act = act
         return y

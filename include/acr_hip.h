@@ -366,9 +366,12 @@ int acr_groupnorm_bwd_bf16(const void* dy, const void* x, const void* resid, con
                            void* dgamma, void* dbeta, int32_t N, int32_t C, int32_t HW, int32_t act, void* stream);
 
 /* The same at the reference precision (fp32 NCHW tensors, fp32 gamma / beta / gradients): a group is streamed twice instead
- * of being held in registers; HW a multiple of 4; deterministic (fixed-order block reductions, no atomics). */
+ * of being held in registers; HW a multiple of 4; deterministic (fixed-order block reductions, no atomics).
+ * ws (forward; nullable): acr_groupnorm_fwd_ws_floats(N, C, HW) floats -- non-zero only for launches of a few samples (CAM
+ * generation on one image), whose (sample, group) pairs are then cut into parts over two launches. */
+size_t acr_groupnorm_fwd_ws_floats(int32_t N, int32_t C, int32_t HW);
 int acr_groupnorm_fwd_f32(const float* x, const float* resid, const float* gamma, const float* beta, float* y, float* stats,
-                          int32_t N, int32_t C, int32_t HW, float eps, int32_t act, void* stream);
+                          int32_t N, int32_t C, int32_t HW, float eps, int32_t act, float* ws, void* stream);
 int acr_groupnorm_bwd_f32(const float* dy, const float* x, const float* resid, const float* gamma, const float* beta,
                           const float* stats, float* dx, float* dresid, float* dgamma_part, float* dbeta_part, float* dgamma,
                           float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t act, void* stream);

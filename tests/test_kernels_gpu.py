@@ -877,6 +877,33 @@ def test_conv1x1_f32(N, cin, cout, H, W, math):
         assert err <= 1e-5, (n, float(err))
 
 
+@pytest.mark.parametrize("N,C,H,W,act", [(2, 1024, 24, 24, "add_relu"), (2, 256, 48, 48, "relu"), (1, 256, 96, 96, "none"), (2, 64, 96, 96, "relu")])
+def test_groupnorm_f32_small_launch_parts(N, C, H, W, act):
+    """GroupNorm forward of a gradient-free pass over a few samples (CAM generation): every (sample, group) is cut into parts
+    (two launches, acr_groupnorm_fwd_f32 with ws) -- same values as the one-workgroup-per-group kernel up to the order of the
+    fp32 sums, vs float64."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(dev)
+    r = torch.randn(N, C, H, W, generator=g).to(dev) if act == "add_relu" else None
+    gw, gb = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev)
+    from acr_wsss_amd import _lib
+    assert _lib.load().acr_groupnorm_fwd_ws_floats(N, C, H * W) > 0
+    with torch.no_grad():
+        y = ops.groupnorm_act(x, gw, gb, act, r)            # no gradient needed: the parts path
+    xg = x.clone().requires_grad_(True)
+    y1 = ops.groupnorm_act(xg, gw, gb, act, r)               # gradient needed: one workgroup per (sample, group)
+    ref = F.group_norm(x.double(), 32, gw.double(), gb.double(), 1e-5)
+    if act == "add_relu":
+        ref = F.relu(ref + r.double())
+    elif act == "relu":
+        ref = F.relu(ref)
+    assert (y.double() - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert (y - y1).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.fixture
 def x3_mfma(request):
     """acr_gemm_x3 on its default 32x32x16 MFMAs or on the 16x16x32 A/B kernels (two split terms per MFMA, LDS-staged finish)."""
