@@ -940,6 +940,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
     const int nst = (kend - kbeg) / P_BK;
     char* sm = reinterpret_cast<char*>(smem);
     auto dma1 = [&](int st, int slot, int i) {
+#ifdef PL_LAB_LESSDMA     /* lab timing build (wrong results): a quarter fewer DMA pieces -- what a 256 x 128 workgroup tile would fetch per MFMA */
+        if (wave >= 2 && i >= 3) return;
+#endif
         __builtin_amdgcn_global_load_lds((glb_vp)(pw + (int64_t)st * (3 * P_TILE_B) + i * 1024), (lds_vp)(sm + slot * P_STAGE_B + (wave * 6 + i) * 1024), 16, 0, 0);
     };
     const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)sm;
@@ -978,6 +981,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
     auto step = [&](int st, int slot, auto set_tag, auto first_tag) {
         constexpr int SET = decltype(set_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
+#ifdef PL_LAB_LESSDMA
+        if (wave >= 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else
+#endif
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // younger: the 6 pieces of stage st + 1
         acr_barrier_nofence();
         const int rslot = slot == 0 ? 2 : slot - 1;         // (st + 2) % 3
