@@ -154,6 +154,19 @@ class ACR(DPT):
         self.math = math
         return self
 
+    def invalidate_caches(self):
+        """After weights were written through ``.data`` (an EMA swap, ``p.data.copy_()``): drop everything derived from the
+        weights that is keyed on (version, address) and therefore cannot see such a write -- the cached split-product weight
+        images, the fp32 W^T copies and the captured inference prefixes."""
+        from .. import ops
+        from ..train import refresh_weight_transposes
+        refresh_weight_transposes(self)                   # also drops the weight images
+        for m in self.modules():
+            m.__dict__.pop("_prefix_graphs", None)
+            if "_frozen" in m.__dict__:                    # ResNetV2's frozen standardised conv weights
+                m._frozen = None
+        return self
+
     def forward_mirror(self, x1, x2):
         """DPT/ACR.py:170-174.  One 2B pass instead of two sequential B passes."""
         b = x1.shape[0]

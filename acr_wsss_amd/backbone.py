@@ -374,8 +374,14 @@ class PrefixGraph:
     ~700 small launches per pass that the host cannot issue as fast as the GPU retires them at batch 2.  The graph owns
     its input, its MeanStack (the head-mean maps of blocks < k land in it on every replay) and the tokens it returns;
     the attention state the blocks expose (``get_attn`` / ``last_pm``) is re-pointed to this graph's buffers on replay.
-    Weights are read in place, so in-place updates are seen; the frozen standardised conv weights are a cached copy
-    (ResNetV2._standardised) -- ``valid`` compares its generation and the parameter addresses."""
+    What the captured launches READ is fixed at capture: parameter storages, the frozen standardised conv weights (a cached
+    copy, ResNetV2._standardised) and -- under split products -- the cached weight IMAGES of the prefix Linears
+    (ops.weight_image: the warm-up passes fill that cache, the capture hits it).  The graph keeps references to those images
+    (they cannot return to the allocator under it) and ``valid`` compares parameter addresses, every parameter's autograd
+    VERSION (an in-place update -- load_state_dict into the same storages, an optimizer step in eval mode -- makes the graph
+    stale: exact fp32 would have seen it through the storages, the images would not) and the stem cache's generation.
+    Writes through ``.data`` are invisible to all of these: ``ACR.invalidate_caches()`` / ``train.refresh_weight_transposes``
+    after such a write."""
 
     def __init__(self, vit, x, k):
         self.k = k
@@ -400,14 +406,22 @@ class PrefixGraph:
         self.state = [(blk.attn._saved, blk.attn.last_pm) for blk in self._blocks]
         self.stem_generation = stem.frozen_generation if stem is not None else 0
         self.addresses = self._addresses(vit)
+        self.versions = self._versions(vit)
+        # the weight images the captured products read (cache entries of the prefix Linears as the capture found them)
+        self._images = [m.__dict__[key][2] for blk in self._blocks for m in blk.modules() if isinstance(m, nn.Linear)
+                        for key in ("_acr_x3_w_img", "_acr_x3_wt_img") if key in m.__dict__]
 
     @staticmethod
     def _addresses(vit):
         return tuple(p.data_ptr() for p in vit.parameters())
 
+    @staticmethod
+    def _versions(vit):
+        return tuple(p._version for p in vit.parameters())
+
     def valid(self, vit):
         stem = vit.patch_embed.backbone if isinstance(vit.patch_embed, HybridEmbed) else None
-        if self.addresses != self._addresses(vit):
+        if self.addresses != self._addresses(vit) or self.versions != self._versions(vit):
             return False
         if stem is not None:
             # rebuilds the cache when a conv weight changed in place; then the generation moves and the graph is stale

@@ -571,16 +571,35 @@ def x3_image_t(x2):
 def weight_image(weight, owner=None, transposed=False):
     """Image of a Linear's weight (``transposed``: of W^T, what the input gradient multiplies by), cached on ``owner`` (the
     nn.Linear) per weight version: inference makes each image once, a training step once per forward resp. backward (the
-    optimizers move the version counters on, train.py)."""
+    optimizers move the version counters on, train.py).  The cache entry remembers the stream that built the image and an
+    event behind the build: a consumer on ANOTHER stream (CAM generation runs each scale on a stream of its own) waits for
+    that event first -- a cache hit must not read an image whose split pass is still queued elsewhere.  What the key cannot see
+    -- as with WeightTransposes -- are writes through ``.data``: ``invalidate_weight_images(model)`` /
+    ``train.refresh_weight_transposes(model)`` drop the cached images."""
     key = "_acr_x3_wt_img" if transposed else "_acr_x3_w_img"
     c = getattr(owner, key, None) if owner is not None else None
     if c is not None and c[0] == weight._version and c[1] == weight.data_ptr() and c[2].device == weight.device:
+        cur = torch.cuda.current_stream(weight.device)
+        if c[3] != cur and not torch.cuda.is_current_stream_capturing():
+            cur.wait_event(c[4])
         return c[2]
     w2 = weight.detach()
     img = x3_image_t(w2) if transposed else x3_image(w2)
     if owner is not None and not torch.cuda.is_current_stream_capturing():      # a captured pass would only be run at replay
-        setattr(owner, key, (weight._version, weight.data_ptr(), img))
+        cur = torch.cuda.current_stream(weight.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        setattr(owner, key, (weight._version, weight.data_ptr(), img, cur, ev))
     return img
+
+
+def invalidate_weight_images(model):
+    """Drop every cached split-product weight image under ``model`` (after a weight was written through ``.data``, which moves
+    neither the version counter nor the address the cache is keyed on)."""
+    for m in model.modules():
+        for key in ("_acr_x3_w_img", "_acr_x3_wt_img"):
+            if key in m.__dict__:
+                delattr(m, key)
 
 
 def gemm_x3(mode, a_img, b_img, c, K, bias=None, aux=None, act=0, c2=None, colsum=None, shape=None):
@@ -953,7 +972,7 @@ def conv3x3_fusable(x, weight, stride, math):
     return (math == 1 and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and stride == 1
             and tuple(weight.shape[2:]) == (3, 3) and x.is_contiguous() and not torch.is_autocast_enabled()
             and x.shape[1] % 16 == 0 and weight.shape[0] % 16 == 0 and x.shape[3] % 4 == 0 and x.shape[3] >= 16
-            and (x.shape[2] * x.shape[3]) % 16 == 0)
+            and (x.shape[2] * x.shape[3]) % 16 == 0 and x.shape[3] + 129 <= CONV3X3_PAD)     # the margin bound the entry points enforce
 
 
 def _conv3x3_launch(wp, x, y, N, co, ci, H, W):

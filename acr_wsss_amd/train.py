@@ -303,6 +303,7 @@ def refresh_weight_transposes(model):
     on W as stored, since a copy is only ever used while its weight's version matches.  The bf16 mode's MasterWeights keeps its
     own set."""
     from . import ops as _ops
+    _ops.invalidate_weight_images(model)                  # split-product images are keyed like the transposes: same blind spot for .data writes
     wt = getattr(model, "_acr_wt_f32", None)
     if wt is None:
         p0 = next(model.parameters(), None)

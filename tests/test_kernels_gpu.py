@@ -159,12 +159,14 @@ def test_attention_bf16(B, T, H, with_g, f32math):
     assert err.mean() <= (1.5e-3 if f32math else 3e-3) * scale, float(err.mean() / scale)
 
 
-@pytest.mark.parametrize("B,T,dtype", [(32, 785, torch.float32), (32, 785, torch.bfloat16), (16, 2305, torch.float32)])
-def test_attention_full_size_is_per_sample(B, T, dtype):
+@pytest.mark.parametrize("B,T,dtype,math", [(32, 785, torch.float32, 0), (32, 785, torch.float32, 1), (32, 785, torch.bfloat16, 0),
+                                             (16, 2305, torch.float32, 0), (16, 2305, torch.float32, 1)])
+def test_attention_full_size_is_per_sample(B, T, dtype, math):
     """BASELINE-size launches (32 views x 12 heads x 785 tokens: one training step; 16 samples x 2305 tokens: eight images at scale 2,
     a 4 GB score buffer, byte offsets beyond 2^32) checked through a size-independent property: attention is per sample, so the
     LAST sample of the big batch must come out exactly as when it is run alone -- forward, head mean and every gradient.  (The
-    small-shape tests above pin the values against fp64; this pins the indexing at full size.)"""
+    small-shape tests above pin the values against fp64; this pins the indexing at full size.)  math = 1: the split-product
+    kernels the bench's headline launches (their bf16 planes live BEHIND the score buffer: offsets past 983 MB resp. 4 GB)."""
     from acr_wsss_amd import ops
     dev = _dev()
     H = 12
@@ -178,7 +180,8 @@ def test_attention_full_size_is_per_sample(B, T, dtype):
         x = qkv[sl].clone().requires_grad_(True)
         n = x.shape[0]
         stack = ops.MeanStack(n, 1, T, dev)
-        o, pm = ops.attention_core(x, H, stack, 0, None)
+        o, pm = ops.attention_core(x, H, stack, 0, None, math)
+        assert o.grad_fn.math == math
         torch.autograd.backward([o, pm], [d_o[sl].contiguous(), gst[sl][:, :, :T]])
         outs.append((o.detach()[-1].clone(), pm.detach()[-1].clone(), x.grad[-1].clone()))
         del x, o, pm, stack
@@ -1103,12 +1106,12 @@ def test_conv3x3_margin_contract():
     assert ops._with_margin(y) is y
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_stem_kernels_full_size_are_per_sample(dtype):
+@pytest.mark.parametrize("dtype,math", [(torch.float32, 0), (torch.float32, 1), (torch.bfloat16, 0)])
+def test_stem_kernels_full_size_are_per_sample(dtype, math):
     """GroupNorm (+ residual + ReLU) and the NCHW 1x1 convolution at the largest launches of the BASELINE step (32 views, 256 channels
     at 112 x 112: 103 M elements per tensor), through a size-independent property: both are per sample in y and dx, so the last of the
     32 samples must equal the same sample run alone, bit for bit (the weight gradients sum over samples and are left to the fp64
-    tests at small N)."""
+    tests at small N).  math = 1: the split-product 1x1 kernels the bench's headline launches (weight image + in-register split)."""
     from acr_wsss_amd import ops
     dev = _dev()
     N, C, Hh, Ww = 32, 256, 112, 112
@@ -1119,22 +1122,67 @@ def test_stem_kernels_full_size_are_per_sample(dtype):
     cw = (one(64, C, 1, 1) * C ** -0.5).contiguous()
     dyc = one(N, 64, Hh, Ww)
     res = []
-    for sl in (slice(0, N), slice(N - 1, N)):
+    # under split products a launch of fewer than 192 tiles (one sample here: 98) is cut along the CONTRACTION into slabs (CAM
+    # generation's small launches, conv1x1_ksplit) -- another grouping of the same fp32 sum, equal to rounding only (the fp64
+    # value tests cover it); the bit-for-bit comparison therefore runs the sample in the smallest batch on the unsplit path
+    sub = 2 if math else 1
+    for sl, slc in ((slice(0, N), slice(0, N)), (slice(N - 1, N), slice(N - sub, N))):
         xi = x[sl].clone().requires_grad_(True)
         ri = r[sl].clone().requires_grad_(True)
         assert ops.groupnorm_fusable(xi, ri) and ops.conv1x1_fusable(xi, cw, 1)
         y = ops.groupnorm_act(xi, gw, gb, "add_relu", ri)
         (y.float() * dy[sl].float()).sum().backward()
         gn = (y.detach()[-1].clone(), xi.grad[-1].clone(), ri.grad[-1].clone())
-        xc = x[sl].clone().requires_grad_(True)
-        yc = ops.conv1x1(xc, cw)
-        (yc.float() * dyc[sl].float()).sum().backward()
+        xc = x[slc].clone().requires_grad_(True)
+        yc = ops.conv1x1(xc, cw, None, math)
+        (yc.float() * dyc[slc].float()).sum().backward()
         res.append(gn + (yc.detach()[-1].clone(), xc.grad[-1].clone()))
         del xi, ri, y, xc, yc
         torch.cuda.empty_cache()
     for name, a, b in zip(("gn y", "gn dx", "gn dres", "conv y", "conv dx"), res[0], res[1]):
         assert torch.isfinite(a.float()).all()
         assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("N,C,S", [(32, 64, 112), (32, 256, 28)])
+def test_conv3x3_full_size_is_per_sample(N, C, S):
+    """The stem's 3x3 convolutions (split products, csrc/conv3x3.hip) at the BASELINE batch -- 32 views x 64 channels x 112^2 (stage 0,
+    the largest launch) and 32 x 256 x 28^2 (stage 2) -- through the same per-sample property: y and dx of the last sample equal the
+    same sample in a batch of half the size bit for bit, and the weight gradient of the batch (summed over samples in a fixed slab order) agrees with the
+    fp64 sum of per-sample gradients at the fp32 GEMM tests' tolerance."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(N + C + S)
+    x = torch.randn(N, C, S, S, generator=g).to(dev)
+    w = (torch.randn(C, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(dev)
+    dy = torch.randn(N, C, S, S, generator=g).to(dev)
+    res = []
+    # the sub-batch stays on the unsplit path (>= 192 tiles: launches below that are cut along the contraction into slabs, another
+    # grouping of the same fp32 sum -- covered by test_conv3x3_split against fp64)
+    for sl in (slice(0, N), slice(N // 2, N)):
+        xi = x[sl].clone().requires_grad_(True)
+        wi = w.clone().requires_grad_(True)
+        assert ops.conv3x3_fusable(xi, wi, 1, 1)
+        y = ops.conv3x3(xi, wi)
+        (y * dy[sl]).sum().backward()
+        res.append((y.detach()[-1].clone(), xi.grad[-1].clone(), wi.grad.clone()))
+        del xi, y
+    for name, a, b in zip(("y", "dx"), res[0][:2], res[1][:2]):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    # last sample against fp64, and the batch weight gradient against fp64 in chunks of 4 samples (memory)
+    xd = x[-1:].double().requires_grad_(True)
+    ref = F.conv2d(xd, w.double(), padding=1)
+    (ref * dy[-1:].double()).sum().backward()
+    assert (res[0][0].double() - ref[0]).abs().max() <= 1e-5 * ref.abs().max()
+    assert (res[0][1].double() - xd.grad[0]).abs().max() <= 1e-5 * xd.grad.abs().max()
+    dw = torch.zeros_like(w, dtype=torch.float64)
+    for i in range(0, N, 4):
+        wd = w.double().requires_grad_(True)
+        (F.conv2d(x[i:i + 4].double(), wd, padding=1) * dy[i:i + 4].double()).sum().backward()
+        dw += wd.grad
+    assert (res[0][2].double() - dw).abs().max() <= 1e-5 * dw.abs().max()
 
 
 def test_f32_input_gradients_on_cached_transposes_are_bit_identical():
