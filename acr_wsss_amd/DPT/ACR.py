@@ -154,6 +154,16 @@ class ACR(DPT):
         self.math = math
         return self
 
+    def late_gradient_parameters(self):
+        """Parameters whose gradients arrive with the very last kernels of backward (the stem's convolutions below its last
+        stage, backbone.ResNetV2.late_gradient_parameters): ``dp.GradSync(model.parameters(), late_params=...)`` gives them
+        the last bucket to themselves."""
+        out = []
+        for m in self.modules():
+            if m is not self and hasattr(m, "late_gradient_parameters"):
+                out += m.late_gradient_parameters()
+        return out
+
     def invalidate_caches(self):
         """After weights were written through ``.data`` (an EMA swap, ``p.data.copy_()``): drop everything derived from the
         weights that is keyed on (version, address) and therefore cannot see such a write -- the cached split-product weight

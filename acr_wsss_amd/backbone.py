@@ -70,6 +70,13 @@ class StdConv2dSame(nn.Conv2d):
         if self.dynamic_pad:
             x = pad_same(x, self.kernel_size[0], self.stride[0])
         w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
+        if self.hip_1x1 and self.hip_1x1_strided and self.kernel_size == (1, 1) and self.stride[0] == 2 and x.is_cuda:
+            # the two stride-2 1x1 convolutions (the shortcuts of stages 1 and 2; SAME padding is empty for a 1x1 kernel:
+            # y[i][j] = W x[2i][2j]): subsample first, then the same NCHW GEMM kernels as every other 1x1 -- the library ran
+            # them as layout transposes + a Tensile GEMM; autograd's slice backward scatters the input gradient back
+            xs = x[:, :, ::2, ::2].contiguous()
+            if ops.conv1x1_fusable(xs, w_hat, 1):
+                return ops.conv1x1(xs, w_hat, self._w_hat_t, self.acr_math)
         if self.hip_1x1 and ops.conv1x1_fusable(x, w_hat, self.stride[0]):
             return ops.conv1x1(x, w_hat, self._w_hat_t, self.acr_math)     # NCHW 1x1 conv = per-sample MFMA GEMM, no layout transposes
         if self.hip_3x3 and not self.dynamic_pad and ops.conv3x3_fusable(x, w_hat, self.stride[0], self.acr_math):
@@ -85,6 +92,7 @@ class StdConv2dSame(nn.Conv2d):
         return self.forward(x), x
 
     hip_1x1 = True
+    hip_1x1_strided = os.environ.get("ACR_CONV1X1_STRIDED_HIP", "1") != "0"      # A/B: stride-2 1x1 convolutions as subsample + HIP GEMM
     hip_3x3 = os.environ.get("ACR_CONV3X3_HIP", "1") != "0"      # A/B: the stem's 3x3 convolutions under f32_split on csrc/conv3x3.hip
     acr_math = 0            # _lib.MATH code of the fp32 products (set_math)
 
@@ -193,12 +201,34 @@ class ResNetV2(nn.Module):
             key = (x.dtype,) + tuple((c.weight.data_ptr(), c.weight._version) for c in convs)
             if self._frozen is not None and self._frozen[0] == key:
                 return self._frozen[1], self._frozen[2]
-        w_hats = ops.weight_std_all([c.weight for c in convs], convs[0].eps)
-        wts = ops.WeightStdAllFn.last_transposed
+        # One launch per GROUP of convolutions (stem + stages 0-1 | stage 2), not one for all 52: a group's backward launch runs
+        # when ITS last weight gradient has arrived, so the 42 MB of stage-2 weight gradients (backward reaches that stage
+        # first) leave for their all-reduce ~25 ms before backward ends instead of with its very last kernel (dp.GradSync;
+        # profiles/r04_gradsync_timeline.json: the last two buckets became launchable 0.1 ms before the end)
+        w_hats, wts = [None] * len(convs), [None] * len(convs)
+        for idx in self._wstd_groups(convs):
+            outs = ops.weight_std_all([convs[i].weight for i in idx], convs[0].eps)
+            outs_t = ops.WeightStdAllFn.last_transposed
+            for j, i in enumerate(idx):
+                w_hats[i], wts[i] = outs[j], outs_t[j]
         if frozen:
             self._frozen = (key, w_hats, wts)
             self.frozen_generation += 1
         return w_hats, wts
+
+    def _wstd_groups(self, convs):
+        """Index lists into ``convs`` (module order): everything up to and including stage 1, and the last stage."""
+        last = set(id(m) for m in self.stages[-1].modules() if isinstance(m, StdConv2dSame))
+        early = [i for i, c in enumerate(convs) if id(c) not in last]
+        late = [i for i, c in enumerate(convs) if id(c) in last]
+        return [g for g in (early, late) if g]
+
+    def late_gradient_parameters(self):
+        """The parameters whose gradients only exist once backward has run through the whole stem (the convolutions of the stem
+        and of every stage but the last: their weight-standardisation backward is one launch at the end): dp.GradSync keeps
+        them in a bucket of their own so that nothing else waits for them."""
+        last = set(id(p) for p in self.stages[-1].parameters())
+        return [p for p in self.parameters() if id(p) not in last]
 
     def refresh_frozen(self, dtype):
         """Bring the frozen standardised-weight cache up to date on the current stream (no-op while a weight wants a gradient)."""

@@ -702,8 +702,8 @@ extern "C" int acr_attn_bwd_scores(const acr_attn_desc* d, const void* q, const 
         rc = check_x3(d, "acr_attn_bwd_scores");
         if (rc) return rc;
         ACR_CHECK_ARG(aligned16(delta_ws) && aligned16(dq) && aligned16(dk) && aligned16(dv), "acr_attn_bwd_scores: delta_ws / dq / dk / dv must be 16-byte aligned");
-        acr_attn_bwd_f32_x3(geom(d), (const float*)o, (const float*)d_o, lse2, scores, gmean, gmean_sb, gmean_st, (float*)dq, (float*)dk,
-                            (float*)dv, delta_ws, (hipStream_t)stream);
+        acr_attn_bwd_f32_x3(geom(d), (const float*)q, (const float*)k, (const float*)v, (const float*)o, (const float*)d_o, lse2, scores,
+                            gmean, gmean_sb, gmean_st, (float*)dq, (float*)dk, (float*)dv, delta_ws, (hipStream_t)stream);
         return acr_check_launch("acr_attn_bwd_scores");
     }
     acr_attn_bwd_f32_sres(geom(d), (const float*)q, (const float*)k, (const float*)v, (const float*)o, (const float*)d_o, lse2,

@@ -26,6 +26,7 @@
 
 #include "acr_common.h"
 #include "attn_f32.h"
+#include "attn_f32_sres_tails.h"
 
 typedef __bf16 bf16_t;
 typedef __attribute__((address_space(3))) void* x3_lds_vp;
@@ -356,10 +357,21 @@ __device__ __forceinline__ int64_t x3_block(int H, int NB, int b, int hd, int qb
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf16_t* __restrict__ qp, const bf16_t* __restrict__ kp,
                                                              const bf16_t* __restrict__ vp, float* __restrict__ o, float* __restrict__ lse2,
-                                                             float* __restrict__ sres) {
+                                                             float* __restrict__ sres, const float* __restrict__ q32,
+                                                             const float* __restrict__ k32, const float* __restrict__ v32,
+                                                             AttnGeom g32, int ntail) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * X3_SLOT_B];        // [slot][K planes | V planes]
-    const int NB = (g.T + 31) >> 5, nqt = (NB + 3) >> 2;
-    int id = acr_xcd_remap(blockIdx.x, gridDim.x);
+    __shared__ float mlsh[4 * 64];                                             // split tail: (m | l) of the four partial sweeps
+    // The last `ntail` workgroups of the grid (dispatched after every full one) are split-tail workgroups, one per (b, h): T = 785
+    // is 25 blocks = 6 x 4 + ONE, which as a seventh workgroup with a single live wave costs a full workgroup's time.  They are
+    // the resident-score generation's (attn_f32_sres_tails.h): exact-fp32 products from the fp32 operands on 1/NB of the rows.
+    const int nmain = (int)gridDim.x - ntail;
+    if ((int)blockIdx.x >= nmain) {
+        attn_fwd_tail_body<4>(reinterpret_cast<float*>(smem), mlsh, g32, q32, k32, v32, o, lse2, sres, acr_xcd_remap((int)blockIdx.x - nmain, ntail));
+        return;
+    }
+    const int NB = (g.T + 31) >> 5, nqt = ntail ? NB >> 2 : (NB + 3) >> 2;
+    int id = acr_xcd_remap(blockIdx.x, nmain);
     const int qt = id % nqt; id /= nqt;
     const int hd = id % g.H;
     const int b = id / g.H;
@@ -477,12 +489,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
 // LDS ring two steps ahead and ITS 32 x 32 block of G into a private single-slot tile one step ahead -- all by LDS-DMA (register
 // prefetch rings become loop-carried copies that hipcc waits for right after issuing the loads).
 //   dP^T = V dO^T (24 MFMAs)   dS^T = exp2(S - lse2) (dP^T + G/H - delta)   dQ += dS K (24 MFMAs)
-__device__ __forceinline__ void attn_dq_x3_body(char* smem, float* ssm, float* gsm, int bid, int nblk, const X3Geom& g,
+__device__ __forceinline__ void attn_dq_x3_body(char* smem, float* ssm, float* gsm, int bid, int nblk, bool tails, const X3Geom& g,
                                                 const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp,
                                                 const bf16_t* __restrict__ dop, const float* __restrict__ lse2,
                                                 const float* __restrict__ delta, const float* __restrict__ sres,
                                                 const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st, float* __restrict__ dq) {
-    const int NB = (g.T + 31) >> 5, nqt = (NB + X3_BW - 1) / X3_BW;
+    const int NB = (g.T + 31) >> 5, nqt = tails ? NB / X3_BW : (NB + X3_BW - 1) / X3_BW;
     int id = acr_xcd_remap(bid, nblk);
     const int qt = id % nqt; id /= nqt;
     const int hd = id % g.H;
@@ -624,13 +636,14 @@ __device__ __forceinline__ void attn_dq_x3_body(char* smem, float* ssm, float* g
 // single-slot LDS tile (refilled right after the step's reads; natural [query][key] rows: the lane's reads are 32 consecutive
 // floats); lse2 / delta of the step's 32 queries sit one per lane and reach the accumulator rows by ds_bpermute.
 //   dP = dO V^T (24 MFMAs)   P = exp2(S - lse2)   dS = P (dP + G/H - delta)   dV += P^T dO (24)   dK += dS^T Q (24)
-__device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, float* gsm, float* rcm, int bid, int nblk, const X3Geom& g,
+__device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, float* gsm, float* rcm, int bid, int nblk, bool tails,
+                                                  const X3Geom& g,
                                                   const bf16_t* __restrict__ qp, const bf16_t* __restrict__ vp,
                                                   const bf16_t* __restrict__ dop, const float* __restrict__ lse2,
                                                   const float* __restrict__ delta, const float* __restrict__ sres,
                                                   const float* __restrict__ gm, int64_t gm_sb, int64_t gm_st, float* __restrict__ dk,
                                                   float* __restrict__ dv) {
-    const int NB = (g.T + 31) >> 5, nkt = (NB + X3_BW - 1) / X3_BW;
+    const int NB = (g.T + 31) >> 5, nkt = tails ? NB / X3_BW : (NB + X3_BW - 1) / X3_BW;
     int id = acr_xcd_remap(bid, nblk);
     const int ktile = id % nkt; id /= nkt;
     const int hd = id % g.H;
@@ -803,23 +816,39 @@ __device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, float*
     }
 }
 
-// dK/dV and dQ in ONE launch (one partly filled last round instead of two): first half of the grid dK/dV, second half dQ.
+// dK/dV and dQ in ONE launch (one partly filled last round instead of two).  Grid: [dK/dV full | dQ full | dK/dV split tails | dQ
+// split tails]: T = 785 is 25 blocks = 3 eight-wave workgroups + ONE block per (b, h) and sweep, which as a fourth workgroup with a
+// single live wave took 3 of the launch's 12 rounds of the chip.  That block is a split-tail workgroup of the resident-score
+// generation instead (attn_f32_sres_tails.h, eight waves dealing the other dimension; exact-fp32 products from the fp32 q, k, v,
+// d_o), dispatched after every full workgroup.
 __global__ __launch_bounds__(64 * X3_BW, 2) void attn_bwd_x3_kernel(X3Geom g, const bf16_t* __restrict__ qp, const bf16_t* __restrict__ kp,
                                                                    const bf16_t* __restrict__ vp, const bf16_t* __restrict__ dop,
                                                                    const float* __restrict__ lse2, const float* __restrict__ delta,
                                                                    const float* __restrict__ sres, const float* __restrict__ gm,
                                                                    int64_t gm_sb, int64_t gm_st, float* __restrict__ dq,
-                                                                   float* __restrict__ dk, float* __restrict__ dv) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * X3_SLOT_B];                 // [slot][Q | dO planes]  resp.  [slot][K | V planes]
-    __shared__ __attribute__((aligned(1024))) float ssm[X3_BW * 2 * X3_SB_FLOATS];      // dK/dV: [wave][slot] score blocks
-    __shared__ __attribute__((aligned(1024))) float gsm[X3_BW * X3_SB_FLOATS];          // dK/dV: [wave] G block
-    __shared__ __attribute__((aligned(256))) float rcm[X3_BW * 64];                     // dK/dV: [wave][lse2 x 32 | delta x 32]
-    const int half = (int)gridDim.x >> 1;
+                                                                   float* __restrict__ dk, float* __restrict__ dv,
+                                                                   const float* __restrict__ q32, const float* __restrict__ k32,
+                                                                   const float* __restrict__ v32, const float* __restrict__ do32,
+                                                                   AttnGeom g32, int ntail) {
+    // one LDS block, carved: [slot][Q | dO planes] resp. [slot][K | V planes] (48 KB) | [wave][slot] score blocks (64 KB) | [wave] G
+    // block (32 KB) | [wave][lse2 x 32 | delta x 32] (2 KB); the split tails use the first 128 KB as 8 tile images + 8 score blocks
+    __shared__ __attribute__((aligned(1024))) char lds[2 * X3_SLOT_B + X3_BW * 3 * X3_SB_FLOATS * 4 + X3_BW * 256];
+    char* smem = lds;
+    float* ssm = reinterpret_cast<float*>(lds + 2 * X3_SLOT_B);
+    float* gsm = ssm + X3_BW * 2 * X3_SB_FLOATS;
+    float* rcm = gsm + X3_BW * X3_SB_FLOATS;
+    const int half = ((int)gridDim.x - 2 * ntail) >> 1;
     const int bid = (int)blockIdx.x;
     if (bid < half)
-        attn_dkdv_x3_body(smem, ssm, gsm, rcm, bid, half, g, qp, vp, dop, lse2, delta, sres, gm, gm_sb, gm_st, dk, dv);
+        attn_dkdv_x3_body(smem, ssm, gsm, rcm, bid, half, ntail != 0, g, qp, vp, dop, lse2, delta, sres, gm, gm_sb, gm_st, dk, dv);
+    else if (bid < 2 * half)
+        attn_dq_x3_body(smem, ssm, gsm, bid - half, half, ntail != 0, g, kp, vp, dop, lse2, delta, sres, gm, gm_sb, gm_st, dq);
+    else if (bid < 2 * half + ntail)
+        attn_dkdv_tail_body<X3_BW>(reinterpret_cast<float*>(lds), reinterpret_cast<float*>(lds) + X3_BW * DT_FLOATS, g32, q32, v32, do32, lse2,
+                                   delta, sres, gm, gm_sb, gm_st, dk, dv, acr_xcd_remap(bid - 2 * half, ntail));
     else
-        attn_dq_x3_body(smem, ssm, gsm, bid - half, half, g, kp, vp, dop, lse2, delta, sres, gm, gm_sb, gm_st, dq);
+        attn_dq_tail_body<X3_BW>(reinterpret_cast<float*>(lds), g32, k32, v32, do32, lse2, delta, sres, gm, gm_sb, gm_st, dq,
+                                 acr_xcd_remap(bid - 2 * half - ntail, ntail));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -835,6 +864,8 @@ int64_t acr_attn_x3_scores_floats(const AttnGeom& g) {                  // score
 int64_t acr_attn_x3_bwd_ws_floats(const AttnGeom& g) {                  // delta (rounded to 16 bytes) + the 3 planes of dO
     return (((int64_t)g.B * g.H * g.T + 3) & ~(int64_t)3) + 3 * ((int64_t)g.B * g.T * g.H * 64) / 2;
 }
+// one leftover 32-row block beyond a whole number of workgroups (nw blocks each), and at least one full workgroup
+static bool x3_split_tail(int NB, int nw) { return acr_opt(ACR_OPT_ATTN_F32_NOSPLITTAIL) == 0 && (NB % nw) == 1 && NB > nw; }
 static X3Geom x3_geom(const AttnGeom& g) {
     X3Geom x;
     x.B = g.B; x.H = g.H; x.T = g.T; x.D = g.H * 64; x.scale = g.scale;
@@ -854,13 +885,18 @@ void acr_attn_fwd_f32_x3(const AttnGeom& g, const float* q, const float* k, cons
     const int64_t n8 = (int64_t)g.B * g.T * g.H * 8;
     hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((n8 + 255) / 256), 3), dim3(256), 0, st, a);
     const int NB = (g.T + 31) / 32;
-    hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3(g.B * g.H * ((NB + 3) / 4)), dim3(256), 0, st, x, (const bf16_t*)planes,
-                       (const bf16_t*)(planes + 3 * x.plane), (const bf16_t*)(planes + 6 * x.plane), o, lse2, scores);
+    // measured (scripts/lab/attn_gen.py, A/B through ACR_OPT_ATTN_F32_NOSPLITTAIL): the forward's split tails pay from NB = 33 on
+    // (T = 1025: 0.624 -> 0.612 ms, T = 2305 at B = 2: 0.355 -> 0.342 ms) but not at T = 785 (0.705 -> 0.724 ms: a tail workgroup's
+    // 6-7 unpipelined exact-fp32 steps take about as long as the 25 pipelined split-product steps of a three-per-CU full one)
+    const int ntail = (x3_split_tail(NB, 4) && NB >= 33) ? g.B * g.H : 0;
+    hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3(g.B * g.H * (ntail ? NB / 4 : (NB + 3) / 4) + ntail), dim3(256), 0, st, x, (const bf16_t*)planes,
+                       (const bf16_t*)(planes + 3 * x.plane), (const bf16_t*)(planes + 6 * x.plane), o, lse2, scores, q, k, v, g, ntail);
     if (pmean) acr_attn_pmean_sres(g, scores, lse2, pmean, pmean_sb, pmean_st, st);
 }
 
-void acr_attn_bwd_f32_x3(const AttnGeom& g, const float* o, const float* d_o, const float* lse2, const float* scores, const float* gm,
-                         int64_t gm_sb, int64_t gm_st, float* dq, float* dk, float* dv, float* delta_ws, hipStream_t st) {
+void acr_attn_bwd_f32_x3(const AttnGeom& g, const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                         const float* lse2, const float* scores, const float* gm, int64_t gm_sb, int64_t gm_st, float* dq, float* dk,
+                         float* dv, float* delta_ws, hipStream_t st) {
     const X3Geom x = x3_geom(g);
     const bf16_t* planes = reinterpret_cast<const bf16_t*>(scores + x3_score_floats(g));
     bf16_t* dop = reinterpret_cast<bf16_t*>(delta_ws + (((int64_t)g.B * g.H * g.T + 3) & ~(int64_t)3));
@@ -871,9 +907,11 @@ void acr_attn_bwd_f32_x3(const AttnGeom& g, const float* o, const float* d_o, co
     hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((n8 + 255) / 256), 1), dim3(256), 0, st, a);
     acr_attn_delta_sres(g, scores, o, d_o, lse2, gm, gm_sb, gm_st, delta_ws, st);
     const int NB = (g.T + 31) / 32;
-    const int nmain = g.B * g.H * ((NB + X3_BW - 1) / X3_BW);
-    hipLaunchKernelGGL(attn_bwd_x3_kernel, dim3(2 * nmain), dim3(64 * X3_BW), 0, st, x, planes, planes + 3 * x.plane, planes + 6 * x.plane,
-                       (const bf16_t*)dop, lse2, (const float*)delta_ws, scores, gm, gm_sb, gm_st, dq, dk, dv);
+    const int ntail = x3_split_tail(NB, X3_BW) ? g.B * g.H : 0;
+    const int nmain = g.B * g.H * (ntail ? NB / X3_BW : (NB + X3_BW - 1) / X3_BW);
+    hipLaunchKernelGGL(attn_bwd_x3_kernel, dim3(2 * nmain + 2 * ntail), dim3(64 * X3_BW), 0, st, x, planes, planes + 3 * x.plane,
+                       planes + 6 * x.plane, (const bf16_t*)dop, lse2, (const float*)delta_ws, scores, gm, gm_sb, gm_st, dq, dk, dv, q, k, v, d_o, g,
+                       ntail);
 }
 
 extern "C" int acr_split3_bf16(const float* x, int64_t rows, int64_t cols, int64_t ld, void* planes, int64_t plane_stride, void* stream) {

@@ -36,7 +36,18 @@ class GradSync:
     would average already-averaged values with raw ones when the ranks disagree on who was late).
     ``strict=True`` (or ACR_DP_STRICT=1) turns any disagreement between ranks into an error instead."""
 
-    def __init__(self, params, process_group=None, bucket_mb=64, strict=None, always_reduce=False, record_timeline=False):
+    def __init__(self, params, process_group=None, bucket_mb=64, strict=None, always_reduce=False, record_timeline=False,
+                 late_params=None, static_graph=False, recheck_every=0):
+        """``late_params``: parameters whose gradients are known to arrive at the very end of backward (the stem convolutions
+        below the last ResNet stage: ACR.late_gradient_parameters()); they get the LAST bucket(s) to themselves, so that no
+        other gradient waits for them (round 4's timeline: 86 MB became launchable 0.1 ms before backward ended because 6 MB of
+        early-stage weights shared their buckets).
+        ``static_graph``: the model's autograd graph is the same every step (true for ACR training).  The per-step host-side
+        agreement (one gloo MAX all-reduce of 3 flags per parameter: a cross-rank host rendezvous) is then only run until ONE
+        step has passed in which every rank agreed, nothing was late and the set of gradient-less parameters did not change;
+        from then on each rank checks its OWN step against that learned pattern and raises if it deviates (a collective
+        decided by one rank alone would hang the others).  ``recheck_every`` = N > 0 runs the collective agreement every N-th
+        step anyway (all ranks count steps alike) as a debug check."""
         import os
         # record_timeline: a device event at prepare() (backward about to start), at every bucket launch and at finish()
         # (backward fully issued), on the launch stream -> timeline() says when each bucket became launchable inside backward
@@ -48,16 +59,23 @@ class GradSync:
         self._params = params
         self._pidx = {p: i for i, p in enumerate(params)}
         cap = int(bucket_mb * (1 << 20))
-        groups, cur, cur_bytes = [], [], 0
-        for p in reversed(params):                         # ~ order in which backward produces gradients
-            nbytes = p.numel() * p.element_size()
-            if cur and (cur_bytes + nbytes > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
+        late_ids = set(id(p) for p in (late_params or ()))
+        groups = []
+        # ~ the order in which backward produces gradients: reverse parameter order, the declared-late ones behind everything
+        for part in ([p for p in reversed(params) if id(p) not in late_ids], [p for p in reversed(params) if id(p) in late_ids]):
+            cur, cur_bytes = [], 0
+            for p in part:
+                nbytes = p.numel() * p.element_size()
+                if cur and (cur_bytes + nbytes > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                    groups.append(cur)
+                    cur, cur_bytes = [], 0
+                cur.append(p)
+                cur_bytes += nbytes
+            if cur:
                 groups.append(cur)
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += nbytes
-        if cur:
-            groups.append(cur)
+        self.static_graph, self.recheck_every = bool(static_graph), int(recheck_every)
+        self._static_ok = False                           # True once a fully agreeing, pattern-stable step has been seen
+        self._static_nograd = None                        # the learned set of gradient-less parameters (indices)
         self.buckets, self._of, self._view = [], {}, {}
         for grp in groups:
             b = _Bucket()
@@ -98,7 +116,7 @@ class GradSync:
             self._side = dist.new_group(
                 ranks=dist.get_process_group_ranks(process_group) if process_group is not None else None, backend="gloo")
         self.stats = {"steps": 0, "bucket_launches_in_backward": 0, "bucket_launches_in_finish": 0, "late_reexchanges": 0,
-                      "rank_disagreements": 0}
+                      "rank_disagreements": 0, "agreement_exchanges": 0}
 
     def describe(self):
         """What bench.py reports about the exchange (sizes in MB per bucket, launch counters so far)."""
@@ -204,7 +222,22 @@ class GradSync:
         mine = set(self._late)
         late = [p in mine for p in self._params]
         nograd = [p.grad is None for p in self._params]
-        if self._agree:
+        agree = self._agree
+        if agree and self.static_graph and self._static_ok:
+            # static graph, pattern learned: no host rendezvous.  This rank's step must match the pattern every rank agreed on
+            # (then the collective sequence below is the same everywhere: no late exchange, the same buckets).
+            if self.recheck_every > 0 and (self.stats["steps"] + 1) % self.recheck_every == 0:
+                pass                                      # debug: run the collective agreement on this step anyway
+            else:
+                mism = sum(1 for i, n in enumerate(nograd) if n != (i in self._static_nograd))
+                if mine or mism:
+                    raise RuntimeError("GradSync(static_graph=True): this step deviates from the learned gradient pattern (%d late "
+                                       "parameter(s), %d presence change(s)); the graph is not static -- construct GradSync with "
+                                       "static_graph=False" % (len(mine), mism))
+                agree = False
+        prev_unused = self._unused
+        if agree:
+            self.stats["agreement_exchanges"] += 1
             # one small host-side exchange, per parameter: "late" on ANY rank, "has a gradient" on ANY rank, "has none" on ANY
             flags = torch.tensor([float(x) for x in late] + [float(not x) for x in nograd] + [float(x) for x in nograd],
                                  dtype=torch.float32)
@@ -221,6 +254,12 @@ class GradSync:
                                        "to run on" % disagree)
             late = any_late
             nograd = [not a for a in any_grad]
+            if self.static_graph:
+                now = set(i for i, n in enumerate(nograd) if n)
+                # decided from all-reduced values only, so that every rank enters (and leaves) the static regime on the same step
+                stable = (not any(any_late) and not any(a and n for a, n in zip(any_grad, any_nograd))
+                          and now == set(self._pidx[p] for p in prev_unused))
+                self._static_ok, self._static_nograd = stable, now
         for b in self.buckets:
             self._wait(b)
         if any(late):
@@ -242,7 +281,7 @@ class GradSync:
                 v.add_(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
                 p.grad = v
-        if self._agree:                                   # a gradient that exists on another rank only: its average is ours too
+        if agree:                                         # a gradient that exists on another rank only: its average is ours too
             for b in self.buckets:
                 for p, v in zip(b.params, b.views):
                     if p.grad is None and not nograd[self._pidx[p]]:

@@ -557,7 +557,9 @@ def run_mode(args, dtype, world, rank, dev):
     else:
         opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=100000)
         amp = torch.bfloat16 if dtype == "bf16" else None          # f32_split: fp32 tensors, no autocast
-    sync = GradSync(model.parameters()) if (world > 1 or os.environ.get("ACR_FORCE_GRADSYNC") == "1") else None
+    # the training graph is static: after one agreeing step the per-step host-side flag exchange is skipped (dp.GradSync)
+    sync = (GradSync(model.parameters(), late_params=model.late_gradient_parameters(), static_graph=os.environ.get("ACR_DP_STATIC", "1") != "0")
+            if (world > 1 or os.environ.get("ACR_FORCE_GRADSYNC") == "1") else None)
 
     def step():
         return train_step(model, opt, img, label, args.alpha, grad_sync=sync, amp_dtype=amp)
@@ -612,6 +614,7 @@ def run_mode(args, dtype, world, rank, dev):
                         "bucket_launches_in_finish": info["bucket_launches_in_finish"],
                         "bucket_launches_in_backward_per_step": round(info["bucket_launches_in_backward"] / per_step, 2),
                         "late_reexchanges": info["late_reexchanges"], "rank_disagreements": info["rank_disagreements"],
+                        "host_agreement_exchanges": info["agreement_exchanges"], "static_graph": sync.static_graph,
                         "steps_counted": info["steps"]}
     del model, opt, sync, step, img, label, loss
     gc.collect()

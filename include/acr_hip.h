@@ -127,8 +127,10 @@ int acr_attn_bwd(const acr_attn_desc* desc, const void* q, const void* k, const 
  * desc->dtype = ACR_F32_BF16X3 (csrc/attn_f32_x3.hip): the same contract on the same fp32 tensors, with S, PV, dP, dQ, dK, dV
  * as split products on the bf16 MFMA (acr_math ACR_MATH_BF16X3); softmax, lse2, delta and the head mean stay fp32.  The
  * forward splits q, k, v once into bf16 planes kept BEHIND the score blocks (acr_attn_scores_floats(desc) accounts for them:
- * nine bf16 planes of B*T*H*64 elements), the backward reads them from there (its q / k / v
- * arguments are ignored) and splits d_o into planes behind delta: delta_ws must hold acr_attn_bwd_ws_floats(desc) floats
+ * nine bf16 planes of B*T*H*64 elements), the backward reads them from there (its q / k / v arguments must still be the
+ * forward's tensors: when T leaves exactly ONE 32-row block beyond a whole number of workgroups -- T = 785, 1025, 2305 -- that
+ * block's rows are computed by the exact-fp32 split-tail workgroups of the ACR_F32 kernels from the fp32 operands) and splits
+ * d_o into planes behind delta: delta_ws must hold acr_attn_bwd_ws_floats(desc) floats
  * (B*H*T for ACR_F32) and be 16-byte aligned.  head strides must be >= 64. */
 int64_t acr_attn_scores_floats(const acr_attn_desc* desc);
 int64_t acr_attn_bwd_ws_floats(const acr_attn_desc* desc);

@@ -49,7 +49,7 @@ def main():
             img = img.to(torch.bfloat16)
         else:
             opt = PolyOptimizer(model.parameters(), lr=0.05, weight_decay=5e-4, max_step=100000)
-        sync = GradSync(model.parameters(), record_timeline=True)
+        sync = GradSync(model.parameters(), record_timeline=True, late_params=model.late_gradient_parameters())
         for _ in range(6):
             train_step(model, opt, img, label, 125, grad_sync=sync)
         steps = sync.timeline()[-3:]

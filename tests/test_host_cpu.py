@@ -279,6 +279,99 @@ def test_grad_sync_survives_rank_dependent_gradient_presence():
         assert (float(seg.abs().max()) == 0.0) == (not who)
 
 
+def _dp_static_worker(rank, world, port, out):
+    import time
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from acr_wsss_amd.dp import GradSync, broadcast_parameters
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    net = _dp_net()
+    unused = net[3].unused
+    broadcast_parameters(net, 0)
+    late = list(net[0].parameters())                     # "the stem": declared late, gets the last bucket(s) to itself
+    sync = GradSync(net.parameters(), bucket_mb=0.0003, late_params=late, static_graph=True, recheck_every=4)
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    xs, ys = x[rank::world], y[rank::world]
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    exchanges, logs = [], []
+    for it in range(9):
+        opt.zero_grad(set_to_none=True)
+        loss = ((net(xs) - ys) ** 2).mean()
+        sync.prepare()
+        loss.backward()
+        sync.finish()
+        exchanges.append(sync.stats["agreement_exchanges"])
+        logs.append(list(sync.launch_log))
+        opt.step()
+    out[rank] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    # a step that breaks the learned pattern on EVERY rank (the unused tensor takes part): each rank raises on its own, before
+    # any collective it alone would have decided on
+    err = None
+    try:
+        loss = ((net(xs + unused.sum() * 1e-2) - ys) ** 2).mean()
+        sync.prepare()
+        loss.backward()
+        sync.finish()
+    except RuntimeError as e:
+        err = str(e)
+    out["err%d" % rank] = err
+    if rank == 0:
+        out["exchanges"] = exchanges
+        out["logs"] = logs
+        out["late_last"] = [all(any(p is q for q in late) for p in b.params) for b in sync.buckets]
+        # what the skipped rendezvous costs: the same 3-flags-per-parameter MAX all-reduce for the real model's 315 tensors
+        flags = torch.zeros(3 * 315)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        out["flag_exchange_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    else:
+        flags = torch.zeros(3 * 315)
+        dist.barrier()
+        for _ in range(20):
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_grad_sync_static_graph_skips_the_host_rendezvous(world):
+    """with static_graph=True the per-step gloo flag exchange runs until one fully agreeing, pattern-stable step
+    has been seen (steps 0 and 1 here: step 0 learns the unused tensor, step 1 confirms it), then only every `recheck_every`-th
+    step; results equal the single-process full-batch run; parameters declared late own the last buckets; a step that deviates
+    from the learned pattern raises on every rank instead of hanging.  Also times the skipped exchange (945 floats, MAX) over
+    the ranks, printed for DESIGN.md 6."""
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_dp_static_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(1, world):
+        torch.testing.assert_close(out[0], out[r], rtol=0, atol=0)
+    ex = out["exchanges"]
+    # steps (1-based) 1, 2: learning; then only the re-checks at steps 4 and 8
+    assert ex == [1, 2, 2, 3, 3, 3, 3, 4, 4], ex
+    late_last = out["late_last"]
+    k = late_last.index(True)
+    assert k > 0 and all(late_last[k:]) and not any(late_last[:k])          # the declared-late parameters: last buckets, nothing else in them
+    nb = len(late_last)
+    assert all([i for i, _ in lg] == list(range(nb)) for lg in out["logs"])
+    assert all(out["err%d" % r] and "static_graph" in out["err%d" % r] for r in range(world))
+    torch.manual_seed(100)
+    net = _dp_net()
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    for it in range(9):
+        opt.zero_grad(set_to_none=True)
+        ((net(x) - y) ** 2).mean().backward()
+        opt.step()
+    ref = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    torch.testing.assert_close(out[0], ref, rtol=1e-5, atol=1e-6)
+    print("gloo MAX all-reduce of 945 floats over %d CPU ranks: %.3f ms" % (world, out["flag_exchange_ms"]))
+
+
 def test_infer_list_sharding():
     """infer_cam.shard_indices -- what infer_cam_list(rank, world) iterates: rank r takes items r::world; the union over
     ranks is the list, no overlaps (the files written per rank are checked on the GPU:
