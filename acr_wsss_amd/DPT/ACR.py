@@ -173,6 +173,7 @@ class ACR(DPT):
         refresh_weight_transposes(self)                   # also drops the weight images
         for m in self.modules():
             m.__dict__.pop("_prefix_graphs", None)
+            m.__dict__.pop("_pass_graphs", None)
             if "_frozen" in m.__dict__:                    # ResNetV2's frozen standardised conv weights
                 m._frozen = None
         return self

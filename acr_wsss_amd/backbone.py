@@ -473,6 +473,130 @@ class PrefixGraph:
         return self.out, self.res_features
 
 
+class PassGraph:
+    """One whole GETAM pass for one input geometry as TWO captured hipGraphs that share a memory pool (VERDICT r4 #9b):
+
+      forward graph   the model's ``forward_cam`` on a static input (stem, all blocks, heads; gradients enabled, backward
+                      truncated at ``start_layer``) -> class logits, head-mean stack, patch CAMs;
+      class graph     d(sum(logits * mask)) / d(tokens entering block start_layer) + ``getam_all`` for a static (samples, C)
+                      mask -> the GETAM rows of every sample.  Replayed once per class rank with another mask.
+
+    A one-image pass over four scales used to be ~890 host-side launches (the PrefixGraph only covered the gradient-free
+    prefix: every Function of blocks >= start_layer and of each class's backward was issued from Python) with the GPU idle
+    13 % of the span; now it is 1 + kmax replays per geometry.  The autograd graph of the captured forward (its saved
+    activations live in the pool) is kept alive by ``cls_pred``; the class graph was captured against exactly those buffers.
+    Same kernels in the same order as eager launches: results are bit-identical
+    (tests/test_model_gpu.py::test_infer_pass_graph_equals_eager_launches).  Validity is PrefixGraph's: parameter addresses
+    and versions, the stem cache's generation; the cached weight images the captured products read are held here."""
+
+    def __init__(self, model, inp, start_layer, func):
+        vit = model.pretrained.model
+        dev = inp.device
+        self.inp = inp.detach().clone(memory_format=torch.preserve_format)
+        self.mask = torch.zeros((inp.shape[0], model.num_class), dtype=torch.float32, device=dev)
+        stem = vit.patch_embed.backbone if isinstance(vit.patch_embed, HybridEmbed) else None
+
+        def forward():
+            with torch.enable_grad():
+                cls_pred, _, attn, patch_cam = model.forward_cam(self.inp)
+            return cls_pred, attn, patch_cam.detach().float(), vit.trunc_input
+
+        def classes(cls_pred, trunc):
+            with torch.enable_grad():
+                tgt = (cls_pred.float() * self.mask).sum()
+                torch.autograd.grad(tgt, trunc, retain_graph=True)
+            return model.getam_all(start_layer=start_layer, func=func)
+
+        side = torch.cuda.Stream(device=dev)               # warm-up off the caller's stream, as torch.cuda.graph asks
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                 # MIOpen find / library workspaces / the frozen weight cache / weight images: uncaptured
+                cls_pred, _, _, trunc = forward()
+                classes(cls_pred, trunc)
+            del cls_pred, trunc
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.fwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph):
+            self.cls_pred, self.attn, self.patch, self.trunc = forward()
+        self.cls_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.cls_graph, pool=self.fwd_graph.pool()):
+            self.rows = classes(self.cls_pred, self.trunc)
+        self._blocks = list(vit.blocks)
+        self.state = [(blk.attn._saved, blk.attn.last_pm, blk.attn._saved_do) for blk in self._blocks]
+        self.taps = dict(model.pretrained.activations)
+        self.stem_generation = stem.frozen_generation if stem is not None else 0
+        self.addresses = tuple(p.data_ptr() for p in model.parameters())
+        self.versions = tuple(p._version for p in model.parameters())
+        self._images = [m.__dict__[key][2] for m in model.modules() if isinstance(m, nn.Linear)
+                        for key in ("_acr_x3_w_img", "_acr_x3_wt_img") if key in m.__dict__]
+
+    def valid(self, model):
+        vit = model.pretrained.model
+        stem = vit.patch_embed.backbone if isinstance(vit.patch_embed, HybridEmbed) else None
+        if (self.addresses != tuple(p.data_ptr() for p in model.parameters())
+                or self.versions != tuple(p._version for p in model.parameters())):
+            return False
+        if stem is not None:
+            convs = [m for m in stem.modules() if isinstance(m, StdConv2dSame)]
+            if all(c.weight.dtype == self.inp.dtype for c in convs):
+                stem._standardised(convs, self.inp)
+            return stem.frozen_generation == self.stem_generation
+        return True
+
+    def run(self, model, inp, masks):
+        """Replay the pass on ``inp`` and the class graph once per mask.  Returns (patch CAMs, head-mean stack, [rows per mask]):
+        the stack is the graph's own buffer (valid until the next replay of this geometry ON THE SAME STREAM), the others are
+        copies."""
+        self.inp.copy_(inp)
+        self.fwd_graph.replay()
+        rows = []
+        for m in masks:
+            self.mask.copy_(m)
+            self.cls_graph.replay()
+            rows.append(self.rows.clone())
+        for blk, (saved, pm, sdo) in zip(self._blocks, self.state):      # the attention-state API reads this pass
+            blk.attn._saved, blk.attn.last_pm, blk.attn._saved_do = saved, pm, sdo
+            blk.attn._saved_gpm = None
+            blk.attn._override = {}
+        model.pretrained.activations.clear()
+        model.pretrained.activations.update(self.taps)
+        return self.patch.clone(), self.attn, rows
+
+
+def pass_graph(model, inp, start_layer, func):
+    """The PassGraph for passes shaped like ``inp`` -- or None when such a pass cannot be replayed (a parameter or the input wants
+    a gradient, a kernel timer is recording, the switch is off, or an earlier capture of this geometry failed)."""
+    vit = model.pretrained.model
+    if (not getattr(vit, "graph_pass", False) or not start_layer or not inp.is_cuda or inp.requires_grad or ops.KERNEL_TIMER is not None
+            or torch.is_autocast_enabled() or torch.cuda.is_current_stream_capturing() or model.truncate_at != start_layer
+            or any(p.requires_grad for p in model.parameters())):
+        return None
+    key = (tuple(inp.shape), inp.dtype, inp.device, inp.is_contiguous(memory_format=torch.channels_last), start_layer, func, model.training,
+           vit.acr_math, vit.blocks[0].attn.acr_math, model.num_class)
+    cache = vit.__dict__.setdefault("_pass_graphs", OrderedDict())
+    g = cache.get(key)
+    if g is not None and g is not False and not g.valid(model):
+        del cache[key]
+        g = None
+    if g is None:
+        keep = vit.graph_prefix
+        vit.graph_prefix = False               # the pass is captured whole: no nested replay of a prefix graph
+        try:
+            g = PassGraph(model, inp, start_layer, func)
+        except RuntimeError as e:              # an op that cannot be captured on this build: stay on eager launches
+            import warnings
+            warnings.warn("hipGraph capture of the GETAM pass failed (%s); running it eagerly" % str(e).splitlines()[0])
+            torch.cuda.synchronize()
+            g = False
+        finally:
+            vit.graph_prefix = keep
+        cache[key] = g
+        while len(cache) > vit.max_prefix_graphs:
+            cache.popitem(last=False)
+    cache.move_to_end(key)
+    return g or None
+
+
 class VisionTransformer(nn.Module):
     def __init__(self, embed_dim=768, depth=12, num_heads=12, hybrid=True, patch=16, img_size=384,
                  num_classes=1000, distilled=False, in_chans=3):
@@ -580,11 +704,13 @@ class VisionTransformer(nn.Module):
 
     acr_math = 0            # _lib.MATH code of the patch-embedding projection's fp32 products (set_math)
     graph_prefix = os.environ.get("ACR_INFER_GRAPH", "1") != "0"      # A/B: hipGraph replay of the gradient-free prefix
+    graph_pass = os.environ.get("ACR_INFER_PASS_GRAPH", "1") != "0"   # A/B: whole GETAM passes as captured graphs (PassGraph)
     max_prefix_graphs = 8
 
     def train(self, mode=True):
         if mode:                               # back to training: the captured prefixes' private pools (activations of every
             self.__dict__.pop("_prefix_graphs", None)      # geometry seen) go back to the allocator
+            self.__dict__.pop("_pass_graphs", None)
         return super().train(mode)
 
     def prefix_graph(self, x, k):

@@ -29,11 +29,7 @@ struct AttnGeomB {
     int64_t osb, ost, osh;
 };
 
-#ifdef LAB_NOEXP       // lab: what the transcendental costs (wrong results)
-__device__ __forceinline__ float fast_exp2(float x) { return x * 1e-3f; }
-#else
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-#endif
 
 #ifdef LAB_TLB                     // lab builds only (scripts/lab/attn_bf16_phases.py): per-phase cycle sums of every wave 0
 __device__ unsigned long long g_lab_attnb[8 * 16384];
@@ -503,10 +499,8 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
     auto step = [&](int k0, auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         LABB_MARK();
-#ifndef LAB_NOSTAGE     // lab: what streaming the K/V tiles costs (wrong results)
         tile_gload<128, EDGE>(kr, k + base, g.st, k0 + 64, g.T, tid);
         tile_gload<128, EDGE>(vr, v + base, g.st, k0 + 64, g.T, tid);
-#endif
         f32x4 gq[2][4];
         if (HAS_G) {
 #pragma unroll
@@ -514,11 +508,7 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
 #pragma unroll
                 for (int grp = 0; grp < 4; ++grp) {
                     const int go = k0 + 32 * kb + 8 * grp;
-#ifdef LAB_NOGLOAD     // lab: what fetching G costs (wrong results)
-                    gq[kb][grp] = f32x4{1e-3f, 2e-3f, -1e-3f, 1e-4f} * (float)go;
-#else
                     __builtin_memcpy(&gq[kb][grp], grow + (EDGE ? min(go, gmax) : go), 16);
-#endif
                 }
         }
         ACR_MEMBAR();
@@ -554,25 +544,19 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
             LABB_ADD(2);
             mma_accop_a_bf(dq0, s, ktc, 0, lane);           // dQ[query = krow][d = 32*blk + r]
             mma_accop_a_bf(dq1, s, ktc, 1, lane);
-#ifndef LAB_NOY
             if (HAS_G) {
                 mma_accop_a_bf(y0, dp, ktc, 0, lane);       // Y[query = krow][d]
                 mma_accop_a_bf(y1, dp, ktc, 1, lane);
             }
-#endif
             LABB_ADD(3);
         }
         ACR_MEMBAR();
-#ifndef LAB_NOSTAGE
         tile_lstore<128>(kt[cur ^ 1], kr, k0 + 64, g.T, tid);
         tile_lstore<128>(vt[cur ^ 1], vr, k0 + 64, g.T, tid);
-#endif
         LABB_ADD(4);
         __syncthreads();
         LABB_ADD(5);
-#ifndef LAB_NOSTAGE
         cur ^= 1;
-#endif
     };
     int k0 = 0;
     for (; k0 + 128 <= g.T; k0 += 64) step(k0, std::false_type{});
@@ -825,11 +809,7 @@ __global__ __launch_bounds__(128, 2) void attn_dkdv_bf16_kernel(AttnGeomB g, con
                     const float* gu = gm + (int64_t)b * gm_sb + (int64_t)(q0 + 32 * qb) * gst;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg)
-#ifdef LAB_NOGLOAD
-                        gv[reg] = 1e-3f * (float)(reg + q0);
-#else
                         gv[reg] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gu + ((reg & 3) + 8 * (reg >> 2)) * gst) + gloff);
-#endif
                 }
             }
             ACR_MEMBAR();

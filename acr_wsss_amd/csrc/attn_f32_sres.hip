@@ -661,17 +661,12 @@ static bool split_tail(int NB) { return acr_opt(ACR_OPT_ATTN_F32_NOSPLITTAIL) ==
 void acr_attn_fwd_f32_sres(const AttnGeom& g, const float* q, const float* k, const float* v, float* o, float* lse2, float* scores,
                            float* pmean, int64_t pmean_sb, int64_t pmean_st, hipStream_t st) {
     const int NB = (g.T + 31) / 32;
-    // waves (32-query blocks) per workgroup: 4.  T = 785 is 25 blocks = 5 x 5 exactly (with 4 every (b, h) carries a seventh
-    // workgroup with one live wave), but measured at B = 32, H = 12: 5-wave workgroups 0.86 ms vs 0.64 ms -- 160 VGPRs allow 12
-    // wave slots per CU, i.e. only two 5-wave workgroups (10 waves on SIMDs as 3,3,2,2) against three 4-wave ones.  Kept
-    // behind ACR_OPT_ATTN_F32_NW = 5 for A/B runs.
-    if (acr_opt(ACR_OPT_ATTN_F32_NW) == 5) {
-        hipLaunchKernelGGL(attn_fwd_sres_kernel<5>, dim3(g.B * g.H * ((NB + 4) / 5)), dim3(320), 0, st, g, q, k, v, o, lse2, scores, 0);
-    } else {
-        const int ntail = split_tail(NB) ? g.B * g.H : 0;
-        const int nmain = g.B * g.H * (ntail ? NB / 4 : (NB + 3) / 4);
-        hipLaunchKernelGGL(attn_fwd_sres_kernel<4>, dim3(nmain + ntail), dim3(256), 0, st, g, q, k, v, o, lse2, scores, ntail);
-    }
+    // waves (32-query blocks) per workgroup: 4.  T = 785 is 25 blocks = 5 x 5 exactly, but five-wave workgroups measured 0.86 ms
+    // against 0.64 ms at B = 32, H = 12 (160 VGPRs allow 12 wave slots per CU, i.e. only two 5-wave workgroups against three
+    // 4-wave ones): the leftover block goes to a split-tail workgroup instead (attn_f32_sres_tails.h)
+    const int ntail = split_tail(NB) ? g.B * g.H : 0;
+    const int nmain = g.B * g.H * (ntail ? NB / 4 : (NB + 3) / 4);
+    hipLaunchKernelGGL(attn_fwd_sres_kernel<4>, dim3(nmain + ntail), dim3(256), 0, st, g, q, k, v, o, lse2, scores, ntail);
     if (pmean) acr_attn_pmean_sres(g, scores, lse2, pmean, pmean_sb, pmean_st, st);
 }
 

@@ -86,11 +86,7 @@ __device__ __forceinline__ void x3_wait_vm(int n) {
 // barrier of every second step (`s_waitcnt vmcnt(0)`, found in the ISA) -- the counted wait above it is the synchronisation
 __device__ __forceinline__ void x3_barrier(int n_younger) {
     x3_wait_vm(n_younger);
-#ifdef X3_FENCED_BARRIER          /* lab A/B */
-    __syncthreads();
-#else
     acr_barrier_nofence();
-#endif
 }
 #endif
 

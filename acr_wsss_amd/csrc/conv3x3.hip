@@ -14,9 +14,12 @@
 // to work: scripts/lab/micro/dma_unaligned.hip); pixels whose tap falls outside the image are zeroed in registers on the
 // fragment (8 v_cndmask per fragment, a per-lane 9-bit validity mask computed once) right before the three-way split.
 // Shifted reads run up to W + 1 floats before a sample's first channel row and up to 128 + W + 1 floats past its last one:
-// inside the tensor that is the neighbouring channel / sample (values masked), at the tensor's two ends it is the
-// ACR_CONV3X3_PAD floats of readable memory the CALLER guarantees on either side (contents irrelevant; ops.py allocates the
-// producers' outputs with that margin).  Arithmetic, tile structure, ring and counted waits are gemm_f32_split_kernel's.
+// inside the tensor that is the neighbouring channel / sample (values masked).  At the tensor's two ENDS they would leave the
+// allocation: the (at most two) workgroups per launch whose window touches an end take a careful issue path (c3_edge_fix) --
+// every lane's DMA source is clamped into the tensor, and the lanes whose 16 bytes were not entirely inside it overwrite their
+// LDS slot with guarded element loads (zero outside) once the DMA has landed.  No byte outside [x, x + numel) is ever
+// addressed; rounds 3-4 asked the caller for ACR_CONV3X3_PAD floats of readable slack instead.
+// Arithmetic, tile structure, ring and counted waits are gemm_f32_split_kernel's.
 #include <type_traits>
 
 #include "acr_common.h"
@@ -74,6 +77,24 @@ __device__ __forceinline__ int c3_valid9(int p, int H, int W, int HW) {
     return m;
 }
 
+// Careful form of one 16-byte LDS-DMA piece for the workgroups at the tensor's two ends.  `idx` = float index of the lane's first
+// element relative to `base` (may be negative or reach past `total`), `dst` = the piece's LDS base (the lane's 16 bytes land at
+// dst + 4 * lane floats).  The DMA is always issued (the stage's vmcnt arithmetic stays what the counted waits assume) from an
+// address clamped into [base, base + total - 4]; a lane whose window was not entirely inside then waits for it and overwrites
+// its slot element by element, zero where the element lies outside the tensor (those values are masked by the caller anyway).
+__device__ __forceinline__ void c3_dma_careful(const float* __restrict__ base, int64_t idx, int64_t total, float* dst, int lane) {
+    const int64_t cl = idx < 0 ? 0 : (idx > total - 4 ? total - 4 : idx);
+    __builtin_amdgcn_global_load_lds((c3_glb_vp)(base + cl), (c3_lds_vp)dst, 16, 0, 0);
+    if (cl != idx) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the clamped DMA has written this lane's slot
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (idx + e >= 0 && idx + e < total) ? base[idx + e] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * lane + e] = v[e];
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const Conv3Args g) {
     __shared__ __attribute__((aligned(1024))) float smem[C3_SLOTS * 2 * C3_TILE];      // [slot][A | B], 64 KiB
     const int tid = threadIdx.x, lane = tid & 63;
@@ -111,6 +132,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const Conv3Args g
     const int pix = n0 + 4 * (lane & 31);
     const int valid0 = c3_valid9(n0 + wn * 64 + r, g.H, g.W, g.HW), valid1 = c3_valid9(n0 + wn * 64 + 32 + r, g.H, g.W, g.HW);
     const int nst = min(lda / C3_BK - sbeg, g.sps);
+    // the two ends of the tensor: the first pixel tile of sample 0 reaches up to W + 1 floats in front of it, the last pixel
+    // tile(s) of the last sample up to 128 + W + 1 floats behind it
+    const int64_t total = (int64_t)g.nsamp * g.C * g.HW;
+    const bool edge = (sample == 0 && n0 < g.W + 1) || (sample == g.nsamp - 1 && n0 + C3_BN + g.W + 1 > g.HW);
     auto issue = [&](int st) {
         float* d = smem + (st & (C3_SLOTS - 1)) * 2 * C3_TILE;
         const int k0 = (sbeg + st) * C3_BK;
@@ -119,7 +144,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const Conv3Args g
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((c3_glb_vp)(pa + k0 + offa[i]), (c3_lds_vp)(d + (wave * 2 + i) * 256), 16, 0, 0);
-        const float* xb = pb + (int64_t)ci0 * g.HW + (pix + off);                // may leave the sample at its ends: see the header
+        if (edge) {                                          // uniform: this workgroup's windows can leave the tensor (see the header)
+            const int64_t i0 = (int64_t)sample * g.C * g.HW + (int64_t)ci0 * g.HW + (pix + off);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) c3_dma_careful(g.x, i0 + rowb[i], total, d + C3_TILE + (wave * 2 + i) * 256, lane);
+            return;
+        }
+        const float* xb = pb + (int64_t)ci0 * g.HW + (pix + off);                // leaves the sample at its ends, never the tensor
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((c3_glb_vp)(xb + rowb[i]), (c3_lds_vp)(d + C3_TILE + (wave * 2 + i) * 256), 16, 0, 0);
@@ -259,12 +290,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const Conv3
     }
     int xh0 = (kbeg + 8 * h) % g.W, xh1 = (kbeg + 8 * h + 4) % g.W;      // column of the first pixel of the lane's two halves
     const int nst = (kend - kbeg) / C3_BK;
+    // the shifted rows of x leave the tensor only in front of sample 0's first pixels and behind the last sample's last ones
+    const int64_t total = (int64_t)g.nsamp * g.C * g.HW;
+    const bool edge = (sample == 0 && kbeg < g.W + 1) || (sample == g.nsamp - 1 && kend + g.W + 1 > g.HW);
     auto issue = [&](int st) {
         float* d = smem + (st & (C3_SLOTS - 1)) * 2 * C3_TILE;
         const int k0 = kbeg + st * C3_BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((c3_glb_vp)(pa + k0 + offa[i]), (c3_lds_vp)(d + (wave * 2 + i) * 256), 16, 0, 0);
+        if (edge) {                                          // uniform (see c3_dma_careful)
+            const int64_t i0 = (int64_t)sample * g.C * g.HW + k0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) c3_dma_careful(g.x, i0 + offb[i], total, d + C3_TILE + (wave * 2 + i) * 256, lane);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((c3_glb_vp)(pb + k0 + offb[i]), (c3_lds_vp)(d + C3_TILE + (wave * 2 + i) * 256), 16, 0, 0);
@@ -383,7 +423,6 @@ extern "C" int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float*
     ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && (cout % 4) == 0 && (cin % 4) == 0 && H > 0 && W > 0 && (W % 4) == 0 && W >= C3_BK &&
                       (HW % C3_BK) == 0,
                   "acr_conv3x3_wgrad_f32: need cout, cin %% 4 == 0, W %% 4 == 0, W >= 16, H*W %% 16 == 0 (n=%d co=%d ci=%d %dx%d)", nsamp, cout, cin, H, W);
-    ACR_CHECK_ARG(W + C3_BN + 1 <= ACR_CONV3X3_PAD, "acr_conv3x3_wgrad_f32: W = %d exceeds the margin ACR_CONV3X3_PAD covers", W);
     ACR_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)dw_packed & 15) == 0,
                   "acr_conv3x3_wgrad_f32: 16-byte alignment");
     ACR_CHECK_ARG((int64_t)cout * HW < (1ll << 30) && (int64_t)cin * HW < (1ll << 30), "acr_conv3x3_wgrad_f32: operand too large for 32-bit offsets");
@@ -428,7 +467,6 @@ extern "C" int acr_conv3x3_f32(int32_t math, const float* w_packed, const float*
     }
     ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && (cin % C3_BK) == 0 && H > 0 && W > 0 && ((int64_t)H * W) % 4 == 0 && (int64_t)H * W >= 4,
                   "acr_conv3x3_f32: need cin %% 16 == 0 and H*W %% 4 == 0 (n=%d co=%d ci=%d %dx%d)", nsamp, cout, cin, H, W);
-    ACR_CHECK_ARG(W + C3_BN + 1 <= ACR_CONV3X3_PAD, "acr_conv3x3_f32: W = %d exceeds the margin ACR_CONV3X3_PAD covers", W);
     ACR_CHECK_ARG(((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "acr_conv3x3_f32: 16-byte alignment");
     ACR_CHECK_ARG((int64_t)cout * 9 * cin < (1ll << 30) && (int64_t)cin * H * W < (1ll << 30), "acr_conv3x3_f32: operand too large for 32-bit offsets");
     Conv3Args g;

@@ -500,12 +500,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
 #define S_SLOTS 4
 
 __device__ __forceinline__ void split3_bf16(const f32x4& lo4, const f32x4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
-#if defined(SPLIT_LAB) && SPLIT_LAB == 1        // lab timing build: no split arithmetic (wrong results), loads + MFMAs only
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    const i32x4 a = __builtin_bit_cast(i32x4, lo4), b = __builtin_bit_cast(i32x4, hi4);
-    p0 = __builtin_bit_cast(bf16x8, a); p1 = __builtin_bit_cast(bf16x8, b); p2 = __builtin_bit_cast(bf16x8, a ^ b);
-    return;
-#endif
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float x = e < 4 ? lo4[e] : hi4[e - 4];
@@ -638,10 +632,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
         if (st < nst) issue(st);
     bf16x8 ap[2][2][3], bp[2][2][3];                        // [register set][block][piece]
     f32x4 ra[2][2], rb[2][2];
-#if defined(SPLIT_LAB) && SPLIT_LAB == 2        // lab timing build: no MFMAs (wrong results), loads + split only
-#define ACR_SPLIT_MFMA6(SET, I, J)                                                                                        \
-    acc[I][J][0] += (float)ap[SET][I][0][0] + (float)bp[SET][J][2][1] + (float)ap[SET][I][2][2] + (float)bp[SET][J][0][3] + (float)ap[SET][I][1][4] + (float)bp[SET][J][1][5];
-#else
 #define ACR_SPLIT_MFMA6(SET, I, J)                                                                                        \
     acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][2], acc[I][J], 0, 0, 0);               \
     acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][2], bp[SET][J][0], acc[I][J], 0, 0, 0);               \
@@ -649,7 +639,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
     acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][1], acc[I][J], 0, 0, 0);               \
     acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][0], acc[I][J], 0, 0, 0);               \
     acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][0], acc[I][J], 0, 0, 0);
-#endif
     // stage st: wait until it has landed (stages st+1, st+2 may stay in flight: 4 DMA instructions each), publish it, refill the
     // slot stage st-1 was read from, read + split stage st into register set SET while the MFMAs of stage st-1 (set SET^1) run
     auto step = [&](int st, auto set_tag, auto first_tag) {
@@ -940,9 +929,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
     const int nst = (kend - kbeg) / P_BK;
     char* sm = reinterpret_cast<char*>(smem);
     auto dma1 = [&](int st, int slot, int i) {
-#ifdef PL_LAB_LESSDMA     /* lab timing build (wrong results): a quarter fewer DMA pieces -- what a 256 x 128 workgroup tile would fetch per MFMA */
-        if (wave >= 2 && i >= 3) return;
-#endif
         __builtin_amdgcn_global_load_lds((glb_vp)(pw + (int64_t)st * (3 * P_TILE_B) + i * 1024), (lds_vp)(sm + slot * P_STAGE_B + (wave * 6 + i) * 1024), 16, 0, 0);
     };
     const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)sm;
@@ -953,24 +939,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
 #pragma unroll
     for (int i = 0; i < 6; ++i) dma1(min(1, nst - 1), 1, i);
     bf16x8 ap[2][2][3], bp[2][2][3];                        // [register set][block][plane]
-#if defined(PL_LAB_MFMA16) && defined(PL_LAB_READS20)     /* + 8 more fragment reads per stage (20 instead of 12) */
-    bf16x8 xr[8];
-#define PL_LAB_EXTRA(K12) if ((K12) < 8) PL_RD(xr[(K12)], fas, ((K12) % 3) * P_TILE_B + 512);
-#else
-#define PL_LAB_EXTRA(K12)
-#endif
-#ifdef PL_LAB_MFMA16      /* lab timing build (wrong results): the same operand registers through twice as many 16x16x32 MFMAs -- same matrix cycles */
-    f32x4 a16[2][2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { a16[i][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; a16[i][j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#define PL_MFMA(SET, I, J, PA, PB)                                                                                          \
-    a16[I][J][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[SET][I][PA], bp[SET][J][PB], a16[I][J][0], 0, 0, 0);          \
-    a16[I][J][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bp[SET][J][PB], ap[SET][I][PA], a16[I][J][1], 0, 0, 0);
-#else
 #define PL_MFMA(SET, I, J, PA, PB) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][PA], bp[SET][J][PB], acc[I][J], 0, 0, 0);
-#endif
 #define PL_PAIR(SET, I, J, T)                                                       \
     if (T == 0) { PL_MFMA(SET, I, J, 0, 2) PL_MFMA(SET, I, J, 2, 0) }              \
     else if (T == 1) { PL_MFMA(SET, I, J, 1, 1) PL_MFMA(SET, I, J, 0, 1) }         \
@@ -981,10 +950,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
     auto step = [&](int st, int slot, auto set_tag, auto first_tag) {
         constexpr int SET = decltype(set_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
-#ifdef PL_LAB_LESSDMA
-        if (wave >= 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else
-#endif
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // younger: the 6 pieces of stage st + 1
         acr_barrier_nofence();
         const int rslot = slot == 0 ? 2 : slot - 1;         // (st + 2) % 3
@@ -995,7 +960,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
         if ((K12) < 6) PL_RD(ap[SET][(K12) / 3][(K12) % 3], fas, ((K12) % 3) * P_TILE_B + ((K12) / 3) * 1024);          \
         else PL_RD(bp[SET][((K12) - 6) / 3][(K12) % 3], fbs, ((K12) % 3) * P_TILE_B + (((K12) - 6) / 3) * 1024);        \
         if ((K12) & 1) dma1(rst, rslot, (K12) >> 1);                                                                   \
-        PL_LAB_EXTRA(K12)                                                                                               \
         __builtin_amdgcn_sched_barrier(0);
         PL_GROUP(0) PL_GROUP(1) PL_GROUP(2) PL_GROUP(3) PL_GROUP(4) PL_GROUP(5)
         PL_GROUP(6) PL_GROUP(7) PL_GROUP(8) PL_GROUP(9) PL_GROUP(10) PL_GROUP(11)
@@ -1014,10 +978,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
             slot = slot == 2 ? 0 : slot + 1;
         }
     }
-#if defined(PL_LAB_MFMA16) && defined(PL_LAB_READS20)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) asm volatile("" :: "v"(xr[q]));
-#endif
 #define PL_ALL(SET)                                                                                      \
     PL_PAIR(SET, 0, 0, 0) PL_PAIR(SET, 0, 0, 1) PL_PAIR(SET, 0, 0, 2) PL_PAIR(SET, 0, 1, 0) PL_PAIR(SET, 0, 1, 1) PL_PAIR(SET, 0, 1, 2) \
     PL_PAIR(SET, 1, 0, 0) PL_PAIR(SET, 1, 0, 1) PL_PAIR(SET, 1, 0, 2) PL_PAIR(SET, 1, 1, 0) PL_PAIR(SET, 1, 1, 1) PL_PAIR(SET, 1, 1, 2)
@@ -1025,271 +985,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_planes_kernel(const GemmF32Ar
 #undef PL_ALL
 #undef PL_PAIR
 #undef PL_MFMA
-#ifdef PL_LAB_MFMA16
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[i][j][e] += a16[i][j][0][e]; acc[i][j][4 + e] += a16[i][j][1][e]; }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end
     __syncthreads();                                        // every wave is done with the ring: the finish may reuse it
     if (ACT == 5 || ACT == 6) x3_finish_image<ACT>(g, acc, smem, tm, tn, m0, n0, wm, wn, r, h, tid);
     else gemm_f32_finish<true, ACT == 5 || ACT == 6 ? 0 : ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, 0.f, false);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// The same products on v_mfma_f32_16x16x32_bf16, TWO of the six terms per instruction (A/B: ACR_OPT_GEMM_X3_MFMA16; NOT the
-// default).  A bare loop of 16x16x32 MFMAs sustains 2.0 PF on this chip against 1.8 PF for 32x32x16
-// (scripts/lab/micro/mfma_bf16_shapes.hip: a quarter of the accumulator traffic per FLOP), the image products are bounded by
-// the clock the chip can hold, and a timing build that pushed the SAME operand registers through 16x16x32 MFMAs
-// (-DPL_LAB_MFMA16, wrong results) ran the NT product 7-9 % faster, 4-5 % with the 20 fragment reads below.  The real kernel
-// does not: 0.55-0.58 ms against 0.54-0.57 ms on the fc1 / fc2 shapes (scripts/lab/gemm_x3_time.py) -- what it saves in the
-// matrix pipe it spends on 67 % more LDS traffic and the LDS-staged finish.  Kept as a tested A/B (test_gemm_x3_images[mfma16]).
-// A 16x16x32 MFMA sums over 32 "k" = four lane groups g of 8.  Here g = 2 q + hh: hh is the 8-element half of the 16-deep
-// stage, and q selects one of TWO (A plane, B plane) pairs -- so one instruction computes two split terms over the stage:
-//     Z = (a2 | a0) x V = (b0 | b2) -> a2 b0 + a0 b2        Y = (a1 | a0) x U = (b0 | b1) -> a1 b0 + a0 b1
-//     X = (a0 | a1) x U            -> a0 b0 + a1 b1         (issued in this order: small terms first)
-// i.e. 3 MFMAs per 16 x 16 block and stage, 3 A fragments per 16-row block, 2 B fragments per 16-column block (20 reads of 1 KiB
-// per wave and stage instead of 12).  Same images, same ring, same DMA; the wave's 64 x 64 tile is 4 x 4 blocks; B fragments of a
-// stage stay in registers (two sets), A fragments stream per row block (two sets), and the last row block of stage t - 1 runs
-// behind the barrier of stage t while its first fragments are read.  The 16 x 16 accumulator layout (col = lane & 15, row =
-// 4 (lane >> 4) + reg) leaves through an LDS tile and ONE row-major finish for every epilogue (x3_rowmajor_finish).
-// ---------------------------------------------------------------------------------------------------------------------------------
-template <int ACT>
-__device__ __forceinline__ void x3_rowmajor_finish(const GemmF32Args& g, const float* tl, float* red, int split, int tt, int tm, int tn, int m0,
-                                                   int n0, int tid) {
-    char* img = reinterpret_cast<char*>(g.c2);
-    float csum[2][8];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) csum[hf][e] = 0.f;
-#pragma unroll
-    for (int hj = 0; hj < 8; ++hj) {
-        const int hf = hj >> 2, j = hj & 3;
-        const int row_t = j * 32 + (tid >> 3), c8 = hf * 8 + (tid & 7);
-        const int row = m0 + row_t, col = n0 + c8 * 8;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(tl + row_t * X3E_PITCH + c8 * 8);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(tl + row_t * X3E_PITCH + c8 * 8 + 4);
-        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        if (ACT == 4) {                                     // K-split tail tile: raw sums into the compact slab
-            float* slab = g.c + ((int64_t)split * g.tiles_launch + (tt - g.tile0)) * (F_BM * F_BN) + row_t * F_BN + c8 * 8;
-            *reinterpret_cast<f32x4*>(slab) = a; *reinterpret_cast<f32x4*>(slab + 4) = b;
-            continue;
-        }
-        if (ACT == 3) {                                     // weight-gradient slab [M][ldc]
-            float* slab = g.c + (int64_t)split * g.M * g.ldc + (int64_t)row * g.ldc + col;
-            if (row < g.M) {
-                if (col + 8 <= g.N) { *reinterpret_cast<f32x4*>(slab) = a; *reinterpret_cast<f32x4*>(slab + 4) = b; }
-                else
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) if (col + e < g.N) slab[e] = v[e];
-            }
-            continue;
-        }
-        const bool rok = row < g.M;
-        const bool full = rok && col + 8 <= g.N;
-        if (ACT == 0 || ACT == 1 || ACT == 2) {
-            if (!rok || col >= g.N) continue;
-            float o[8], o2[8];
-            float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const bool want_aux = (ACT == 0 && g.aux) || ACT == 2;
-            if (full) {                                     // whole chunk inside the matrix: 16-byte loads (host: 16-byte aligned, pitches % 4)
-                if (ACT != 2 && g.bias) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + col), b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bv[e] = e < 4 ? b0[e] : b1[e - 4];
-                }
-                if (want_aux) {
-                    const float* xp = g.aux + (int64_t)row * g.ldaux + col;
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp), x1 = *reinterpret_cast<const f32x4*>(xp + 4);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xv[e] = e < 4 ? x0[e] : x1[e - 4];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (col + e < g.N) {
-                        if (ACT != 2 && g.bias) bv[e] = g.bias[col + e];
-                        if (want_aux) xv[e] = g.aux[(int64_t)row * g.ldaux + col + e];
-                    }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = v[e] + bv[e];
-                if (ACT == 0) {
-                    o[e] = x + xv[e];
-                } else if (ACT == 1) {
-                    const float er = erff(x * 0.70710678118654752440f);
-                    o2[e] = x * 0.5f * (1.0f + er);
-                    o[e] = 0.5f * (1.0f + er) + x * (expf(-0.5f * x * x) * 0.39894228040143267794f);
-                } else {
-                    o[e] = x * xv[e];
-                }
-            }
-            float* cp = g.c + (int64_t)row * g.ldc + col;
-            if (full) {
-                *reinterpret_cast<f32x4*>(cp) = f32x4{o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4*>(cp + 4) = f32x4{o[4], o[5], o[6], o[7]};
-                if (ACT == 1) {
-                    float* c2p = g.c2 + (int64_t)row * g.ldc + col;
-                    *reinterpret_cast<f32x4*>(c2p) = f32x4{o2[0], o2[1], o2[2], o2[3]}; *reinterpret_cast<f32x4*>(c2p + 4) = f32x4{o2[4], o2[5], o2[6], o2[7]};
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (col + e < g.N) { cp[e] = o[e]; if (ACT == 1) g.c2[(int64_t)row * g.ldc + col + e] = o2[e]; }
-            }
-            continue;
-        }
-        // image epilogues (host: N % 8 == 0)
-        if (full) {
-            if (ACT == 5) {
-                f32x4 d0, d1;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float hv = v[e] + (g.bias ? g.bias[col + e] : 0.f);
-                    const float er = erff(hv * 0.70710678118654752440f);
-                    v[e] = hv * 0.5f * (1.0f + er);
-                    const float d = 0.5f * (1.0f + er) + hv * (expf(-0.5f * hv * hv) * 0.39894228040143267794f);
-                    if (e < 4) d0[e] = d; else d1[e - 4] = d;
-                }
-                float* cp = g.c + (int64_t)row * g.ldc + col;
-                *reinterpret_cast<f32x4*>(cp) = d0; *reinterpret_cast<f32x4*>(cp + 4) = d1;
-            } else {
-                const float* xp = g.aux + (int64_t)row * g.ldaux + col;
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp), x1 = *reinterpret_cast<const f32x4*>(xp + 4);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= e < 4 ? x0[e] : x1[e - 4];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        }
-        if (ACT == 6) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) csum[hf][e] += v[e];
-        }
-        x3_image_chunk_store(img, tm, tn, g.img_nkb, row_t, c8, v);
-    }
-    if (ACT == 6 && g.cs) {
-        __syncthreads();                                    // every thread is done reading the tile: `red` may alias it
-        x3_tile_colsum(csum, red, tid, g.cs + (int64_t)tm * g.N, n0, g.N);
-    }
-}
-
-template <int ACT>
-__global__ __launch_bounds__(256, 2) void gemm_f32_planes16_kernel(const GemmF32Args g) {
-    __shared__ __attribute__((aligned(1024))) float smem[P_SLOTS * P_STAGE_B / 4];      // 72 KiB
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    typedef const __attribute__((address_space(1))) void* glb_vp;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c16 = lane & 15, gq = lane >> 4, wm = wave >> 1, wn = wave & 1;
-    const int ntile = g.tiles_launch;
-    const int t0 = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
-    const int split = t0 / ntile, tt = g.tile0 + (t0 - split * ntile);
-    int tm, tn;
-    tile_coords(tt, g.tiles_m, g.tiles_n, tm, tn);
-    const int m0 = tm * F_BM, n0 = tn * F_BN;
-    const int zs = split / g.ksplit;
-    const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);
-    const int nkb = g.K / P_BK;
-    const char* __restrict__ pw = (wave < 2 ? reinterpret_cast<const char*>(g.a) + ((int64_t)tm * nkb + kbeg / P_BK) * (3 * P_TILE_B)
-                                            : reinterpret_cast<const char*>(g.b) + ((int64_t)tn * nkb + kbeg / P_BK) * (3 * P_TILE_B)) +
-                                  (wave & 1) * (6 * 1024) + lane * 16;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nst = (kend - kbeg) / P_BK;
-    char* sm = reinterpret_cast<char*>(smem);
-    auto dma1 = [&](int st, int slot, int i) {
-        __builtin_amdgcn_global_load_lds((glb_vp)(pw + (int64_t)st * (3 * P_TILE_B) + i * 1024), (lds_vp)(sm + slot * P_STAGE_B + (wave * 6 + i) * 1024), 16, 0, 0);
-    };
-    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)sm;
-    // lane (c16, g = 2 q + hh): row / column c16 of a 16-block, stage half hh (swapped for rows 8-15), plane pair element q
-    const uint32_t q = gq >> 1, hx = ((gq & 1) ^ ((c16 >> 3) & 1)) * 16;
-    const uint32_t rowa = lbase + (wm * 64 + c16) * 32 + hx, rowb = lbase + 3 * P_TILE_B + (wn * 64 + c16) * 32 + hx;
-    const uint32_t fX = rowa + (q ? 1 : 0) * P_TILE_B;      // X = (a0 | a1)
-    const uint32_t fY = rowa + (q ? 0 : 1) * P_TILE_B;      // Y = (a1 | a0)
-    const uint32_t fZ = rowa + (q ? 0 : 2) * P_TILE_B;      // Z = (a2 | a0)
-    const uint32_t fU = rowb + (q ? 1 : 0) * P_TILE_B;      // U = (b0 | b1)
-    const uint32_t fV = rowb + (q ? 2 : 0) * P_TILE_B;      // V = (b0 | b2)
-#pragma unroll
-    for (int i = 0; i < 6; ++i) dma1(0, 0, i);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) dma1(min(1, nst - 1), 1, i);
-    bf16x8 fa[2][3], fbU[2][4], fbV[2][4];                  // A: [set][X, Y, Z] of one row block; B: [set][column block]
-#define P16_MF(I, J, A_, B_) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, acc[I][J], 0, 0, 0);
-#define P16_ROWBLOCK(I, AS, BS)                                                                                          \
-    P16_MF(I, 0, fa[AS][2], fbV[BS][0]) P16_MF(I, 1, fa[AS][2], fbV[BS][1]) P16_MF(I, 2, fa[AS][2], fbV[BS][2]) P16_MF(I, 3, fa[AS][2], fbV[BS][3]) \
-    P16_MF(I, 0, fa[AS][1], fbU[BS][0]) P16_MF(I, 1, fa[AS][1], fbU[BS][1]) P16_MF(I, 2, fa[AS][1], fbU[BS][2]) P16_MF(I, 3, fa[AS][1], fbU[BS][3]) \
-    P16_MF(I, 0, fa[AS][0], fbU[BS][0]) P16_MF(I, 1, fa[AS][0], fbU[BS][1]) P16_MF(I, 2, fa[AS][0], fbU[BS][2]) P16_MF(I, 3, fa[AS][0], fbU[BS][3])
-#define P16_RDA(AS, I, SO)                                                                                               \
-    PL_RD(fa[AS][0], fX + (SO), (I) * 512); PL_RD(fa[AS][1], fY + (SO), (I) * 512); PL_RD(fa[AS][2], fZ + (SO), (I) * 512);
-#define P16_WAITA(AS, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(fa[AS][0]), "+v"(fa[AS][1]), "+v"(fa[AS][2]))
-    // step st (slot st % 3, B set BS): behind the barrier the B fragments and the first A row block of stage st are read while
-    // row block 3 of stage st - 1 (A set 1, B set BS ^ 1) runs; then row blocks 0..2 of stage st, each behind the read of the next
-    auto step = [&](int st, int slot, auto bs_tag, auto first_tag) {
-        constexpr int BS = decltype(bs_tag)::value;
-        constexpr bool FIRST = decltype(first_tag)::value;
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        acr_barrier_nofence();
-        const int rslot = slot == 0 ? 2 : slot - 1;
-        const int rst = min(st + 2, nst - 1);
-        const uint32_t so = slot * P_STAGE_B;
-        PL_RD(fbU[BS][0], fU + so, 0); PL_RD(fbU[BS][1], fU + so, 512); PL_RD(fbU[BS][2], fU + so, 1024); PL_RD(fbU[BS][3], fU + so, 1536);
-        PL_RD(fbV[BS][0], fV + so, 0); PL_RD(fbV[BS][1], fV + so, 512); PL_RD(fbV[BS][2], fV + so, 1024); PL_RD(fbV[BS][3], fV + so, 1536);
-        P16_RDA(0, 0, so)
-        dma1(rst, rslot, 0); dma1(rst, rslot, 1);
-        if (!FIRST) { P16_ROWBLOCK(3, 1, BS ^ 1) }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(fbU[BS][0]), "+v"(fbU[BS][1]), "+v"(fbU[BS][2]), "+v"(fbU[BS][3]), "+v"(fbV[BS][0]), "+v"(fbV[BS][1]), "+v"(fbV[BS][2]),
-                       "+v"(fbV[BS][3]), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]));
-        P16_RDA(1, 1, so)
-        dma1(rst, rslot, 2); dma1(rst, rslot, 3);
-        P16_ROWBLOCK(0, 0, BS)
-        __builtin_amdgcn_sched_barrier(0);
-        P16_WAITA(1, 0);
-        P16_RDA(0, 2, so)
-        dma1(rst, rslot, 4); dma1(rst, rslot, 5);
-        P16_ROWBLOCK(1, 1, BS)
-        __builtin_amdgcn_sched_barrier(0);
-        P16_WAITA(0, 0);
-        P16_RDA(1, 3, so)
-        P16_ROWBLOCK(2, 0, BS)
-        __builtin_amdgcn_sched_barrier(0);
-        P16_WAITA(1, 0);
-    };
-    step(0, 0, std::integral_constant<int, 0>{}, std::true_type{});
-    int slot = 1;
-    for (int st = 1; st < nst; st += 2) {
-        step(st, slot, std::integral_constant<int, 1>{}, std::false_type{});
-        slot = slot == 2 ? 0 : slot + 1;
-        if (st + 1 < nst) {
-            step(st + 1, slot, std::integral_constant<int, 0>{}, std::false_type{});
-            slot = slot == 2 ? 0 : slot + 1;
-        }
-    }
-    if (nst & 1) { P16_ROWBLOCK(3, 1, 0) } else { P16_ROWBLOCK(3, 1, 1) }
-#undef P16_ROWBLOCK
-#undef P16_MF
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end
-    __syncthreads();                                        // every wave is done with the ring: the finish reuses it
-    float* tl = smem;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tl[(wm * 64 + i * 16 + 4 * gq + e) * X3E_PITCH + wn * 64 + j * 16 + c16] = acc[i][j][e];
-    __syncthreads();
-    x3_rowmajor_finish<ACT>(g, tl, tl, split, tt, tm, tn, m0, n0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1530,131 +1229,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wimg_kernel(const GemmF32Args
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end
     __syncthreads();
     gemm_f32_finish<true, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, 0.f, false);
-}
-
-// The weight gradient the same way (16x16x32, two terms per MFMA): fragments read transposed from the [16 tokens][16 features]
-// chunks -- lane group g = 2 q + hh takes plane-pair element q and the 8 tokens 8 hh .. 8 hh + 7 of its feature (two
-// ds_read_b64_tr_b16, 128 bytes apart), a 16-feature block is exactly one chunk.
-#define P16_RDTR(l_, h_, addr, OFF)                                                                     \
-    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"          \
-                 : "=&v"(l_), "=&v"(h_) : "v"(addr), "i"(OFF), "i"((OFF) + 128))
-__global__ __launch_bounds__(256, 2) void gemm_f32_planes16_tn_kernel(const GemmF32Args g) {
-    __shared__ __attribute__((aligned(1024))) float smem[P_SLOTS * P_STAGE_B / 4];      // 72 KiB
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    typedef const __attribute__((address_space(1))) void* glb_vp;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c16 = lane & 15, gq = lane >> 4, wm = wave >> 1, wn = wave & 1;
-    const int ntile = g.tiles_launch;
-    const int t0 = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
-    const int split = t0 / ntile, tt = g.tile0 + (t0 - split * ntile);
-    const int tm = tt / g.tiles_n, tn = tt - tm * g.tiles_n;
-    const int m0 = tm * F_BM, n0 = tn * F_BN;
-    const int kbeg = split * g.k_zs, kend = min(g.K, kbeg + g.kps);
-    const int nkb = wave < 2 ? g.nkb_a : g.nkb_b;
-    const int f0 = (wave < 2 ? tm : tn) * 8;
-    const char* __restrict__ pw = reinterpret_cast<const char*>(wave < 2 ? g.a : g.b);
-    int offd[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int qq = (wave & 1) * 6 + i, pl = qq >> 2, fs = min(f0 + 2 * (qq & 3) + (lane >> 5), nkb - 1);
-        offd[i] = (fs * 3 + pl) * P_TILE_B + (lane & 31) * 16;
-    }
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nst = (kend - kbeg) / P_BK;
-    char* sm = reinterpret_cast<char*>(smem);
-    auto dma1 = [&](int st, int slot, int i) {
-        const int tk = kbeg + st * P_BK;
-        const char* src = pw + ((int64_t)(tk >> 7) * nkb) * (3 * P_TILE_B) + (tk & 127) * 32;
-        const int qq = (wave & 1) * 6 + i;
-        __builtin_amdgcn_global_load_lds((glb_vp)(src + offd[i]), (lds_vp)(sm + slot * P_STAGE_B + (wave >> 1) * (3 * P_TILE_B) + (qq >> 2) * P_TILE_B + (qq & 3) * 1024),
-                                         16, 0, 0);
-    };
-    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)sm;
-    const uint32_t q = gq >> 1, hh = gq & 1;
-    // this lane's piece of a transposed read: token row 8 hh + (c16 >> 2), features 4 (c16 & 3) .. + 3 (halves swapped for rows 8-15)
-    const uint32_t tro = (8 * hh + (c16 >> 2)) * 32 + ((((c16 & 3) >> 1) ^ hh) << 4) + 8 * (c16 & 1);
-    const uint32_t rowa = lbase + (wm * 4) * 512 + tro, rowb = lbase + 3 * P_TILE_B + (wn * 4) * 512 + tro;
-    const uint32_t fX = rowa + (q ? 1 : 0) * P_TILE_B, fY = rowa + (q ? 0 : 1) * P_TILE_B, fZ = rowa + (q ? 0 : 2) * P_TILE_B;
-    const uint32_t fU = rowb + (q ? 1 : 0) * P_TILE_B, fV = rowb + (q ? 2 : 0) * P_TILE_B;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) dma1(0, 0, i);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) dma1(min(1, nst - 1), 1, i);
-    bf16x4 al[2][3], ah[2][3], ul[2][4], uh[2][4], vl[2][4], vh[2][4];
-#define T16_J(l_, h_) __builtin_shufflevector(l_, h_, 0, 1, 2, 3, 4, 5, 6, 7)
-#define T16_MF(I, J, AL, AH, BL, BH) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T16_J(AL, AH), T16_J(BL, BH), acc[I][J], 0, 0, 0);
-#define T16_ROWBLOCK(I, AS, BS)                                                                                          \
-    T16_MF(I, 0, al[AS][2], ah[AS][2], vl[BS][0], vh[BS][0]) T16_MF(I, 1, al[AS][2], ah[AS][2], vl[BS][1], vh[BS][1])   \
-    T16_MF(I, 2, al[AS][2], ah[AS][2], vl[BS][2], vh[BS][2]) T16_MF(I, 3, al[AS][2], ah[AS][2], vl[BS][3], vh[BS][3])   \
-    T16_MF(I, 0, al[AS][1], ah[AS][1], ul[BS][0], uh[BS][0]) T16_MF(I, 1, al[AS][1], ah[AS][1], ul[BS][1], uh[BS][1])   \
-    T16_MF(I, 2, al[AS][1], ah[AS][1], ul[BS][2], uh[BS][2]) T16_MF(I, 3, al[AS][1], ah[AS][1], ul[BS][3], uh[BS][3])   \
-    T16_MF(I, 0, al[AS][0], ah[AS][0], ul[BS][0], uh[BS][0]) T16_MF(I, 1, al[AS][0], ah[AS][0], ul[BS][1], uh[BS][1])   \
-    T16_MF(I, 2, al[AS][0], ah[AS][0], ul[BS][2], uh[BS][2]) T16_MF(I, 3, al[AS][0], ah[AS][0], ul[BS][3], uh[BS][3])
-#define T16_RDA(AS, I, SO)                                                                                               \
-    P16_RDTR(al[AS][0], ah[AS][0], fX + (SO), (I) * 512); P16_RDTR(al[AS][1], ah[AS][1], fY + (SO), (I) * 512); P16_RDTR(al[AS][2], ah[AS][2], fZ + (SO), (I) * 512);
-#define T16_WAITA(AS) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[AS][0]), "+v"(al[AS][1]), "+v"(al[AS][2]), "+v"(ah[AS][0]), "+v"(ah[AS][1]), "+v"(ah[AS][2]))
-    auto step = [&](int st, int slot, auto bs_tag, auto first_tag) {
-        constexpr int BS = decltype(bs_tag)::value;
-        constexpr bool FIRST = decltype(first_tag)::value;
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        acr_barrier_nofence();
-        const int rslot = slot == 0 ? 2 : slot - 1;
-        const int rst = min(st + 2, nst - 1);
-        const uint32_t so = slot * P_STAGE_B;
-        P16_RDTR(ul[BS][0], uh[BS][0], fU + so, 0); P16_RDTR(ul[BS][1], uh[BS][1], fU + so, 512); P16_RDTR(ul[BS][2], uh[BS][2], fU + so, 1024); P16_RDTR(ul[BS][3], uh[BS][3], fU + so, 1536);
-        P16_RDTR(vl[BS][0], vh[BS][0], fV + so, 0); P16_RDTR(vl[BS][1], vh[BS][1], fV + so, 512); P16_RDTR(vl[BS][2], vh[BS][2], fV + so, 1024); P16_RDTR(vl[BS][3], vh[BS][3], fV + so, 1536);
-        T16_RDA(0, 0, so)
-        dma1(rst, rslot, 0); dma1(rst, rslot, 1);
-        if (!FIRST) { T16_ROWBLOCK(3, 1, BS ^ 1) }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ul[BS][0]), "+v"(ul[BS][1]), "+v"(ul[BS][2]), "+v"(ul[BS][3]), "+v"(uh[BS][0]), "+v"(uh[BS][1]), "+v"(uh[BS][2]), "+v"(uh[BS][3]),
-                       "+v"(vl[BS][0]), "+v"(vl[BS][1]), "+v"(vl[BS][2]), "+v"(vl[BS][3]), "+v"(vh[BS][0]), "+v"(vh[BS][1]), "+v"(vh[BS][2]), "+v"(vh[BS][3]),
-                       "+v"(al[0][0]), "+v"(al[0][1]), "+v"(al[0][2]), "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[0][2]));
-        T16_RDA(1, 1, so)
-        dma1(rst, rslot, 2); dma1(rst, rslot, 3);
-        T16_ROWBLOCK(0, 0, BS)
-        __builtin_amdgcn_sched_barrier(0);
-        T16_WAITA(1);
-        T16_RDA(0, 2, so)
-        dma1(rst, rslot, 4); dma1(rst, rslot, 5);
-        T16_ROWBLOCK(1, 1, BS)
-        __builtin_amdgcn_sched_barrier(0);
-        T16_WAITA(0);
-        T16_RDA(1, 3, so)
-        T16_ROWBLOCK(2, 0, BS)
-        __builtin_amdgcn_sched_barrier(0);
-        T16_WAITA(1);
-    };
-    step(0, 0, std::integral_constant<int, 0>{}, std::true_type{});
-    int slot = 1;
-    for (int st = 1; st < nst; st += 2) {
-        step(st, slot, std::integral_constant<int, 1>{}, std::false_type{});
-        slot = slot == 2 ? 0 : slot + 1;
-        if (st + 1 < nst) {
-            step(st + 1, slot, std::integral_constant<int, 0>{}, std::false_type{});
-            slot = slot == 2 ? 0 : slot + 1;
-        }
-    }
-    if (nst & 1) { T16_ROWBLOCK(3, 1, 0) } else { T16_ROWBLOCK(3, 1, 1) }
-#undef T16_ROWBLOCK
-#undef T16_MF
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    float* tl = smem;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tl[(wm * 64 + i * 16 + 4 * gq + e) * X3E_PITCH + wn * 64 + j * 16 + c16] = acc[i][j][e];
-    __syncthreads();
-    x3_rowmajor_finish<3>(g, tl, tl, split, tt, tm, tn, m0, n0, tid);
 }
 
 // ---- the split passes (HBM-bound: 4 bytes read, 6 written per element) ----------------------------------------------------------
@@ -2015,7 +1589,6 @@ extern "C" int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const 
     g.a_zs = g.b_zs = g.c_zs = g.aux_zs = 0; g.k_zs = g.kps; g.ksplit = 1 << 30;
     g.tile0 = 0; g.tiles_launch = g.tiles_m * g.tiles_n;
     g.nkb_a = (M + P_BK - 1) / P_BK; g.nkb_b = (N + P_BK - 1) / P_BK;
-    const bool mfma16 = acr_opt(ACR_OPT_GEMM_X3_MFMA16) != 0;      // A/B: 16x16x32 MFMAs, two split terms each (measured: no faster, below)
     if (mode == ACR_GEMM_TN) {                              // a_img = image of a[K][M], b_img = image of b[K][N] (rows = the K tokens)
         ACR_CHECK_ARG(act == 0 && !bias && !aux, "acr_gemm_x3: TN takes no epilogue");
         ACR_CHECK_ARG(ws, "acr_gemm_x3: TN needs the acr_gemm_x3_ws_floats workspace");
@@ -2023,8 +1596,7 @@ extern "C" int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const 
         const TnPlan p = tn_plan(M, N, K);
         g.nsplit = p.nsplit; g.kps = p.kps; g.k_zs = p.kps;
         g.c = ws; g.ldc = N;
-        if (mfma16) hipLaunchKernelGGL(gemm_f32_planes16_tn_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL(gemm_f32_planes_tn_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(gemm_f32_planes_tn_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n * p.nsplit)), dim3(256), 0, st, g);
         const int64_t n4 = (int64_t)M * N / 4;
         hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.nsplit, n4, c);
         return acr_check_launch("acr_gemm_x3(TN)");
@@ -2040,13 +1612,7 @@ extern "C" int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const 
     g.tiles_launch -= tp.ntail;
     if (g.tiles_launch > 0) {
         const dim3 grid((unsigned)g.tiles_launch);
-        if (mfma16) {
-            if (act == 0) hipLaunchKernelGGL((gemm_f32_planes16_kernel<0>), grid, dim3(256), 0, st, g);
-            else if (act == 1) hipLaunchKernelGGL((gemm_f32_planes16_kernel<1>), grid, dim3(256), 0, st, g);
-            else if (act == 2) hipLaunchKernelGGL((gemm_f32_planes16_kernel<2>), grid, dim3(256), 0, st, g);
-            else if (act == 3) hipLaunchKernelGGL((gemm_f32_planes16_kernel<5>), grid, dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((gemm_f32_planes16_kernel<6>), grid, dim3(256), 0, st, g);
-        } else if (act == 0) hipLaunchKernelGGL((gemm_f32_planes_kernel<0>), grid, dim3(256), 0, st, g);
+        if (act == 0) hipLaunchKernelGGL((gemm_f32_planes_kernel<0>), grid, dim3(256), 0, st, g);
         else if (act == 1) hipLaunchKernelGGL((gemm_f32_planes_kernel<1>), grid, dim3(256), 0, st, g);
         else if (act == 2) hipLaunchKernelGGL((gemm_f32_planes_kernel<2>), grid, dim3(256), 0, st, g);
         else if (act == 3) hipLaunchKernelGGL((gemm_f32_planes_kernel<5>), grid, dim3(256), 0, st, g);
@@ -2055,8 +1621,7 @@ extern "C" int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const 
     if (tp.ntail) {                                         // the tail tiles, K-split into slabs, and their epilogue (gemm_tail_plan)
         GemmF32Args gt = g;
         gt.tile0 = g.tiles_launch; gt.tiles_launch = tp.ntail; gt.nsplit = tp.nsplit; gt.kps = tp.kps; gt.k_zs = tp.kps; gt.c = ws;
-        if (mfma16) hipLaunchKernelGGL((gemm_f32_planes16_kernel<4>), dim3((unsigned)(tp.ntail * tp.nsplit)), dim3(256), 0, st, gt);
-        else hipLaunchKernelGGL((gemm_f32_planes_kernel<4>), dim3((unsigned)(tp.ntail * tp.nsplit)), dim3(256), 0, st, gt);
+        hipLaunchKernelGGL((gemm_f32_planes_kernel<4>), dim3((unsigned)(tp.ntail * tp.nsplit)), dim3(256), 0, st, gt);
         GemmF32Args ge = g;
         ge.tile0 = gt.tile0;
         const dim3 egrid((unsigned)(tp.ntail * 16));

@@ -37,44 +37,98 @@ __device__ __forceinline__ float gnf_block_sum(float v, float* sh) {
     return t;
 }
 
+// Work decomposition inside a workgroup (round 5).  The first version walked a (sample, group) with all NT threads in lockstep: ONE
+// 16-byte load in flight per thread (`s_waitcnt vmcnt(0)` in every iteration, found in the ISA), the channel of every vector by an
+// integer division, and -- in the backward -- two block reductions (four barriers) per CHANNEL: 3.0 TB/s, half of what the HBM
+// gives.  Now the group is cut into UNITS = (channel, segment of the channel's pixels); a wave owns whole units (no barrier while
+// it streams them), keeps FOUR independent 16-byte loads per lane in flight, takes gamma / beta of its unit's channel as
+// wave-uniform scalars, and the per-unit sums meet in LDS once per pass, where they are added in unit order (deterministic).
+#define GNF_MAXU 64                      // units per (sample, group): max(channels per group, waves) <= 64
+struct GnfUnits { int S, segv, units; };                    // segments per channel, vectors per segment, cg * S
+__device__ __forceinline__ float gnf_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+// body(v, a) for every vector v of [v0, v1) of this lane (stride 64), four loads in flight; LD = how the vectors are loaded
+#define GNF_FOR4(xv, v0, v1, lane, LDM, BODY)                                                     \
+    {                                                                                              \
+        int v_ = (v0) + (lane);                                                                    \
+        for (; v_ + 192 < (v1); v_ += 256) {                                                       \
+            const f32x4 a0_ = LDM((xv)[v_]), a1_ = LDM((xv)[v_ + 64]), a2_ = LDM((xv)[v_ + 128]), a3_ = LDM((xv)[v_ + 192]); \
+            BODY(v_, a0_) BODY(v_ + 64, a1_) BODY(v_ + 128, a2_) BODY(v_ + 192, a3_)              \
+        }                                                                                          \
+        for (; v_ < (v1); v_ += 64) { const f32x4 a0_ = LDM((xv)[v_]); BODY(v_, a0_) }             \
+    }
+#define GNF_LD1(p) (p)
+
 template <int NT, int ACT>
 __global__ __launch_bounds__(NT) void gnf_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ y, float* __restrict__ stats, int C, int HW, int cg, float eps) {
-    __shared__ float sh[NT / 64];
+                                                     float* __restrict__ y, float* __restrict__ stats, int C, int HW, int cg, float eps,
+                                                     GnfUnits un) {
+    constexpr int NW = NT / 64;
+    __shared__ float sh[2 * NW];
     const int g = blockIdx.x % GNF_GROUPS, n = blockIdx.x / GNF_GROUPS;
     const int64_t base = ((int64_t)n * C + (int64_t)g * cg) * HW;
-    const int nvec = (cg * HW) >> 2, vpc = HW >> 2;
+    const int vpc = HW >> 2;
     const float inv_n = 1.f / (float)(cg * HW);
-    const int tid = threadIdx.x;
-    const f32x4* xv = reinterpret_cast<const f32x4*>(x + base);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float x0 = x[base];
     float s1 = 0.f, s2 = 0.f;
-    for (int v = tid; v < nvec; v += NT) {
-        const f32x4 a = xv[v];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = a[e] - x0; s1 += d; s2 = fmaf(d, d, s2); }
+    for (int u = wave; u < un.units; u += NW) {
+        const int cl = u / un.S, seg = u - cl * un.S;
+        const int v0 = seg * un.segv, v1 = min(vpc, v0 + un.segv);
+        const f32x4* xv = reinterpret_cast<const f32x4*>(x + base + (int64_t)cl * HW);
+#define GNF_B1(v, a) { _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float d = a[e] - x0; s1 += d; s2 = fmaf(d, d, s2); } }
+        GNF_FOR4(xv, v0, v1, lane, GNF_LD1, GNF_B1)
+#undef GNF_B1
     }
-    const float m1 = gnf_block_sum<NT>(s1, sh) * inv_n;
-    const float m2 = gnf_block_sum<NT>(s2, sh) * inv_n;
+    s1 = gnf_wave_sum(s1);
+    s2 = gnf_wave_sum(s2);
+    if (lane == 0) { sh[wave] = s1; sh[NW + wave] = s2; }
+    __syncthreads();
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { t1 += sh[w]; t2 += sh[NW + w]; }      // wave order, every thread alike
+    const float m1 = t1 * inv_n, m2 = t2 * inv_n;
     const float mean = x0 + m1;
     const float rstd = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + eps);
-    const f32x4* rv = reinterpret_cast<const f32x4*>(res + (ACT == GNF_ADD_RELU ? base : 0));
-    f32x4* yv = reinterpret_cast<f32x4*>(y + base);
-    for (int v = tid; v < nvec; v += NT) {
-        const int c = g * cg + v / vpc;
+    for (int u = wave; u < un.units; u += NW) {
+        const int cl = u / un.S, seg = u - cl * un.S;
+        const int v0 = seg * un.segv, v1 = min(vpc, v0 + un.segv);
+        const int c = g * cg + cl;                          // wave-uniform: gamma / beta are scalar loads
         const float ga = gamma[c] * rstd;
         const float be = beta[c] - mean * ga;
-        const f32x4 a = GNF_LD2(xv[v]);
-        f32x4 o;
+        const f32x4* xv = reinterpret_cast<const f32x4*>(x + base + (int64_t)cl * HW);
+        const f32x4* rv = reinterpret_cast<const f32x4*>(res + (ACT == GNF_ADD_RELU ? base + (int64_t)cl * HW : 0));
+        f32x4* yv = reinterpret_cast<f32x4*>(y + base + (int64_t)cl * HW);
+        auto fin = [&](int v, const f32x4& a, const f32x4& r) {
+            f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = fmaf(a[e], ga, be);
-        if (ACT == GNF_ADD_RELU) o += rv[v];
-        if (ACT != GNF_NONE) {
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(a[e], ga, be);
+            if (ACT == GNF_ADD_RELU) o += r;
+            if (ACT != GNF_NONE) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+            }
+            GNF_ST(yv[v], o);
+        };
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        int v = v0 + lane;
+        for (; v + 192 < v1; v += 256) {
+            const f32x4 a0 = GNF_LD2(xv[v]), a1 = GNF_LD2(xv[v + 64]), a2 = GNF_LD2(xv[v + 128]), a3 = GNF_LD2(xv[v + 192]);
+            f32x4 r0 = z4, r1 = z4, r2 = z4, r3 = z4;
+            if (ACT == GNF_ADD_RELU) { r0 = rv[v]; r1 = rv[v + 64]; r2 = rv[v + 128]; r3 = rv[v + 192]; }
+            fin(v, a0, r0); fin(v + 64, a1, r1); fin(v + 128, a2, r2); fin(v + 192, a3, r3);
         }
-        GNF_ST(yv[v], o);
+        for (; v < v1; v += 64) {
+            const f32x4 a0 = GNF_LD2(xv[v]);
+            f32x4 r0 = z4;
+            if (ACT == GNF_ADD_RELU) r0 = rv[v];
+            fin(v, a0, r0);
+        }
     }
     if (tid == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
 }
@@ -84,13 +138,17 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ res, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const float* __restrict__ stats,
                                                      float* __restrict__ dx, float* __restrict__ dres,
-                                                     float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int C, int HW, int cg) {
-    __shared__ float sh[NT / 64];
+                                                     float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int C, int HW, int cg,
+                                                     GnfUnits un) {
+    constexpr int NW = NT / 64;
+    __shared__ float shu[2 * GNF_MAXU];                     // per unit: sum(dy'), sum(dy' * xhat)
+    __shared__ float shc[2];
     const int g = blockIdx.x % GNF_GROUPS, n = blockIdx.x / GNF_GROUPS;
     const int64_t base = ((int64_t)n * C + (int64_t)g * cg) * HW;
     const int vpc = HW >> 2;
     const float inv_n = 1.f / (float)(cg * HW);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
     // the forward's exact expression decides the ReLU mask, so it is the one forward applied
     auto masked = [&](const f32x4& gy, const f32x4& a, const f32x4& r, float ga, float be) {
@@ -105,33 +163,59 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
         }
         return o;
     };
-    float s1 = 0.f, s2 = 0.f;                               // group sums of gamma * dy' and gamma * dy' * xhat
-    for (int cl = 0; cl < cg; ++cl) {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int u = wave; u < un.units; u += NW) {
+        const int cl = u / un.S, seg = u - cl * un.S;
+        const int v0 = seg * un.segv, v1 = min(vpc, v0 + un.segv);
         const int c = g * cg + cl;
         const float gam = gamma[c], ga = gam * rstd, be = beta[c] - mean * ga;
         const f32x4* xv = reinterpret_cast<const f32x4*>(x + base + (int64_t)cl * HW);
         const f32x4* gv = reinterpret_cast<const f32x4*>(dy + base + (int64_t)cl * HW);
         const f32x4* rv = reinterpret_cast<const f32x4*>(res + (ACT == GNF_ADD_RELU ? base + (int64_t)cl * HW : 0));
         float db = 0.f, dg = 0.f;
-        for (int v = tid; v < vpc; v += NT) {
-            const f32x4 a = xv[v];
-            f32x4 r = {0.f, 0.f, 0.f, 0.f};
-            if (ACT == GNF_ADD_RELU) r = rv[v];
-            const f32x4 gy = masked(gv[v], a, r, ga, be);
+        auto acc = [&](const f32x4& a, const f32x4& gy0, const f32x4& r) {
+            const f32x4 gy = masked(gy0, a, r, ga, be);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { db += gy[e]; dg = fmaf(gy[e], (a[e] - mean) * rstd, dg); }
+        };
+        int v = v0 + lane;
+        for (; v + 64 < v1; v += 128) {                     // two vectors of each of the (up to) three streams in flight
+            const f32x4 a0 = xv[v], a1 = xv[v + 64], y0 = gv[v], y1 = gv[v + 64];
+            f32x4 r0 = z4, r1 = z4;
+            if (ACT == GNF_ADD_RELU) { r0 = rv[v]; r1 = rv[v + 64]; }
+            acc(a0, y0, r0); acc(a1, y1, r1);
         }
-        db = gnf_block_sum<NT>(db, sh);
-        dg = gnf_block_sum<NT>(dg, sh);
-        if (tid == 0) {
+        for (; v < v1; v += 64) {
+            const f32x4 a0 = xv[v], y0 = gv[v];
+            f32x4 r0 = z4;
+            if (ACT == GNF_ADD_RELU) r0 = rv[v];
+            acc(a0, y0, r0);
+        }
+        db = gnf_wave_sum(db);
+        dg = gnf_wave_sum(dg);
+        if (lane == 0) { shu[2 * u] = db; shu[2 * u + 1] = dg; }
+    }
+    __syncthreads();
+    if (tid == 0) {                                         // channel sums in segment order, group sums in channel order
+        float s1 = 0.f, s2 = 0.f;
+        for (int cl = 0; cl < cg; ++cl) {
+            float db = 0.f, dg = 0.f;
+            for (int sg = 0; sg < un.S; ++sg) { db += shu[2 * (cl * un.S + sg)]; dg += shu[2 * (cl * un.S + sg) + 1]; }
+            const int c = g * cg + cl;
             dgamma_part[(int64_t)n * C + c] = dg;
             dbeta_part[(int64_t)n * C + c] = db;
+            const float gam = gamma[c];
+            s1 = fmaf(db, gam, s1);
+            s2 = fmaf(dg, gam, s2);
         }
-        s1 = fmaf(db, gam, s1);
-        s2 = fmaf(dg, gam, s2);
+        shc[0] = s1 * inv_n;
+        shc[1] = s2 * inv_n;
     }
-    const float c1 = s1 * inv_n, c2 = s2 * inv_n;
-    for (int cl = 0; cl < cg; ++cl) {
+    __syncthreads();
+    const float c1 = shc[0], c2 = shc[1];
+    for (int u = wave; u < un.units; u += NW) {
+        const int cl = u / un.S, seg = u - cl * un.S;
+        const int v0 = seg * un.segv, v1 = min(vpc, v0 + un.segv);
         const int c = g * cg + cl;
         const float gam = gamma[c], ga = gam * rstd, be = beta[c] - mean * ga;
         const f32x4* xv = reinterpret_cast<const f32x4*>(x + base + (int64_t)cl * HW);
@@ -139,18 +223,243 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
         const f32x4* rv = reinterpret_cast<const f32x4*>(res + (ACT == GNF_ADD_RELU ? base + (int64_t)cl * HW : 0));
         f32x4* ov = reinterpret_cast<f32x4*>(dx + base + (int64_t)cl * HW);
         f32x4* dv = reinterpret_cast<f32x4*>(dres + (ACT == GNF_ADD_RELU ? base + (int64_t)cl * HW : 0));
-        for (int v = tid; v < vpc; v += NT) {
-            const f32x4 a = GNF_LD2(xv[v]);
-            f32x4 r = {0.f, 0.f, 0.f, 0.f};
-            if (ACT == GNF_ADD_RELU) r = GNF_LD2(rv[v]);
-            const f32x4 gy = masked(GNF_LD2(gv[v]), a, r, ga, be);
+        auto fin = [&](int vv, const f32x4& a, const f32x4& gy0, const f32x4& r) {
+            const f32x4 gy = masked(gy0, a, r, ga, be);
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rstd * (fmaf(gy[e], gam, -c1) - (a[e] - mean) * rstd * c2);
-            GNF_ST(ov[v], o);
-            if (ACT == GNF_ADD_RELU) GNF_ST(dv[v], gy);
+            GNF_ST(ov[vv], o);
+            if (ACT == GNF_ADD_RELU) GNF_ST(dv[vv], gy);
+        };
+        int v = v0 + lane;
+        for (; v + 64 < v1; v += 128) {
+            const f32x4 a0 = GNF_LD2(xv[v]), a1 = GNF_LD2(xv[v + 64]), y0 = GNF_LD2(gv[v]), y1 = GNF_LD2(gv[v + 64]);
+            f32x4 r0 = z4, r1 = z4;
+            if (ACT == GNF_ADD_RELU) { r0 = GNF_LD2(rv[v]); r1 = GNF_LD2(rv[v + 64]); }
+            fin(v, a0, y0, r0); fin(v + 64, a1, y1, r1);
+        }
+        for (; v < v1; v += 64) {
+            const f32x4 a0 = GNF_LD2(xv[v]), y0 = GNF_LD2(gv[v]);
+            f32x4 r0 = z4;
+            if (ACT == GNF_ADD_RELU) r0 = GNF_LD2(rv[v]);
+            fin(v, a0, y0, r0);
         }
     }
+}
+
+// ---- register-resident variant: groups of at most 8 vectors per lane (stage 2 and the small maps: 40 of the step's 52 norms) --------
+// A (sample, group) of up to NT * 32 floats is read ONCE: every lane keeps its (up to) eight 16-byte vectors of x -- in the
+// backward also of dy and of the residual -- in registers across the reduction, all loads of the group in flight at once (the
+// streamed kernels above re-read the group for their second pass and, on these small groups, spend their time in load latency:
+// 1.1-1.6 TB/s on the 28 x 28 maps).  Same units, same shifted sums; slot i of a lane = (unit wave + NW (i / ch), 64-vector chunk
+// i % ch of that unit), wave-uniform; per-slot wave sums meet in LDS and are added in (channel, segment, chunk) order.
+#define GNF_RV 8
+// Slots of a wave, walked in order without divisions (all wave-uniform, scalar unit): slot = (unit wave + NW k, chunk j of it)
+struct GnfWalk {
+    int k, j, cl, seg, dq, dr;
+    __device__ __forceinline__ GnfWalk(int wave, int NW, const GnfUnits& un) {
+        k = 0; j = 0;
+        cl = wave / un.S; seg = wave - cl * un.S;
+        dq = NW / un.S; dr = NW - dq * un.S;
+    }
+    __device__ __forceinline__ bool valid(int wave, int NW, const GnfUnits& un, int upw) const { return k < upw && wave + k * NW < un.units; }
+    __device__ __forceinline__ void next(const GnfUnits& un, int ch) {
+        if (++j == ch) {
+            j = 0; ++k;
+            cl += dq; seg += dr;
+            if (seg >= un.S) { seg -= un.S; ++cl; }
+        }
+    }
+    // the lane's vector index inside the channel, -1 past the segment's end
+    __device__ __forceinline__ int vector(int lane, const GnfUnits& un, int vpc) const {
+        const int v0 = seg * un.segv, v1 = min(vpc, v0 + un.segv);
+        const int v = v0 + j * 64 + lane;
+        return v < v1 ? v : -1;
+    }
+};
+#define GNF_AT(T, p, boff) (*reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<float*>(p)) + (boff)))
+
+template <int NT, int ACT>
+__global__ __launch_bounds__(NT) void gnf_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ y, float* __restrict__ stats, int C, int HW, int cg, float eps,
+                                                         GnfUnits un, int upw, int ch) {
+    constexpr int NW = NT / 64;
+    __shared__ float sh[2 * NW];
+    const int g = blockIdx.x % GNF_GROUPS, n = blockIdx.x / GNF_GROUPS;
+    const int64_t base = ((int64_t)n * C + (int64_t)g * cg) * HW;
+    const int vpc = HW >> 2;
+    const float inv_n = 1.f / (float)(cg * HW);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* xb = x + base;                             // wave-uniform bases + one 32-bit byte offset per slot
+    const float* rb = res + (ACT == GNF_ADD_RELU ? base : 0);
+    float* yb = y + base;
+    const float x0 = xb[0];
+    f32x4 xr[GNF_RV];
+    uint32_t off[GNF_RV];
+    uint32_t okm = 0;
+    GnfWalk wk(wave, NW, un);
+#pragma unroll
+    for (int i = 0; i < GNF_RV; ++i, wk.next(un, ch)) {
+        if (!wk.valid(wave, NW, un, upw)) break;
+        const int cl = wk.cl;
+        const int v = wk.vector(lane, un, vpc);
+        okm |= (v >= 0 ? 1u : 0u) << i;
+        off[i] = (uint32_t)(cl * HW + 4 * max(v, 0)) * 4u;   // a lane past its segment re-reads a valid vector and ignores it
+        xr[i] = GNF_LD2(GNF_AT(const f32x4, xb, off[i]));
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < GNF_RV; ++i) {
+        if ((okm >> i) & 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = xr[i][e] - x0; s1 += d; s2 = fmaf(d, d, s2); }
+        }
+    }
+    s1 = gnf_wave_sum(s1);
+    s2 = gnf_wave_sum(s2);
+    if (lane == 0) { sh[wave] = s1; sh[NW + wave] = s2; }
+    __syncthreads();
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { t1 += sh[w]; t2 += sh[NW + w]; }
+    const float m1 = t1 * inv_n, m2 = t2 * inv_n;
+    const float mean = x0 + m1;
+    const float rstd = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + eps);
+    wk = GnfWalk(wave, NW, un);
+#pragma unroll
+    for (int i = 0; i < GNF_RV; ++i, wk.next(un, ch)) {
+        if (!wk.valid(wave, NW, un, upw)) break;
+        const int cl = wk.cl;
+        const int c = g * cg + cl;
+        const float ga = gamma[c] * rstd;
+        const float be = beta[c] - mean * ga;
+        if ((okm >> i) & 1) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(xr[i][e], ga, be);
+            if (ACT == GNF_ADD_RELU) o += GNF_LD2(GNF_AT(const f32x4, rb, off[i]));
+            if (ACT != GNF_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+            }
+            GNF_ST(GNF_AT(f32x4, yb, off[i]), o);
+        }
+    }
+    if (tid == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+}
+
+template <int NT, int ACT>
+__global__ __launch_bounds__(NT) void gnf_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ res, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ stats,
+                                                         float* __restrict__ dx, float* __restrict__ dres,
+                                                         float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int C, int HW,
+                                                         int cg, GnfUnits un, int upw, int ch) {
+    constexpr int NW = NT / 64;
+    __shared__ float shp[NW * GNF_RV * 2];                  // [wave][slot]: sum(dy'), sum(dy' * xhat)
+    __shared__ float shc[2];
+    const int g = blockIdx.x % GNF_GROUPS, n = blockIdx.x / GNF_GROUPS;
+    const int64_t base = ((int64_t)n * C + (int64_t)g * cg) * HW;
+    const int vpc = HW >> 2;
+    const float inv_n = 1.f / (float)(cg * HW);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
+    const float* xb = x + base;
+    const float* gb = dy + base;
+    const float* rb = res + (ACT == GNF_ADD_RELU ? base : 0);
+    float* ob = dx + base;
+    float* db_ = dres + (ACT == GNF_ADD_RELU ? base : 0);
+    f32x4 xr[GNF_RV], gr[GNF_RV];
+    uint32_t off[GNF_RV];
+    uint32_t okm = 0;
+    GnfWalk wk(wave, NW, un);
+#pragma unroll
+    for (int i = 0; i < GNF_RV; ++i, wk.next(un, ch)) {
+        if (!wk.valid(wave, NW, un, upw)) break;
+        const int cl = wk.cl;
+        const int v = wk.vector(lane, un, vpc);
+        okm |= (v >= 0 ? 1u : 0u) << i;
+        off[i] = (uint32_t)(cl * HW + 4 * max(v, 0)) * 4u;
+        xr[i] = GNF_LD2(GNF_AT(const f32x4, xb, off[i]));
+        gr[i] = GNF_LD2(GNF_AT(const f32x4, gb, off[i]));
+    }
+    // the forward's exact expression decides the ReLU mask; the masked gradient replaces dy in the registers
+    wk = GnfWalk(wave, NW, un);
+#pragma unroll
+    for (int i = 0; i < GNF_RV; ++i, wk.next(un, ch)) {
+        if (!wk.valid(wave, NW, un, upw)) break;
+        const int cl = wk.cl;
+        const int c = g * cg + cl;
+        const float gam = gamma[c], ga = gam * rstd, be = beta[c] - mean * ga;
+        float db = 0.f, dg = 0.f;
+        if (ACT != GNF_NONE) {
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (ACT == GNF_ADD_RELU) r = GNF_LD2(GNF_AT(const f32x4, rb, off[i]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pre = fmaf(xr[i][e], ga, be);
+                if (ACT == GNF_ADD_RELU) pre += r[e];
+                if (!(pre > 0.f)) gr[i][e] = 0.f;
+            }
+        }
+        if ((okm >> i) & 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { db += gr[i][e]; dg = fmaf(gr[i][e], (xr[i][e] - mean) * rstd, dg); }
+        }
+        db = gnf_wave_sum(db);
+        dg = gnf_wave_sum(dg);
+        if (lane == 0) { shp[(wave * GNF_RV + i) * 2] = db; shp[(wave * GNF_RV + i) * 2 + 1] = dg; }
+    }
+    __syncthreads();
+    if (tid == 0) {                                         // channel sums in (segment, chunk) order, group sums in channel order
+        float s1 = 0.f, s2 = 0.f;
+        for (int cl = 0; cl < cg; ++cl) {
+            float db = 0.f, dg = 0.f;
+            for (int sg = 0; sg < un.S; ++sg) {
+                const int u = cl * un.S + sg, w = u % NW, k = u / NW;
+                for (int j = 0; j < ch; ++j) { db += shp[(w * GNF_RV + k * ch + j) * 2]; dg += shp[(w * GNF_RV + k * ch + j) * 2 + 1]; }
+            }
+            const int c = g * cg + cl;
+            dgamma_part[(int64_t)n * C + c] = dg;
+            dbeta_part[(int64_t)n * C + c] = db;
+            const float gam = gamma[c];
+            s1 = fmaf(db, gam, s1);
+            s2 = fmaf(dg, gam, s2);
+        }
+        shc[0] = s1 * inv_n;
+        shc[1] = s2 * inv_n;
+    }
+    __syncthreads();
+    const float c1 = shc[0], c2 = shc[1];
+    wk = GnfWalk(wave, NW, un);
+#pragma unroll
+    for (int i = 0; i < GNF_RV; ++i, wk.next(un, ch)) {
+        if (!wk.valid(wave, NW, un, upw)) break;
+        const int cl = wk.cl;
+        const float gam = gamma[g * cg + cl];
+        if ((okm >> i) & 1) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rstd * (fmaf(gr[i][e], gam, -c1) - (xr[i][e] - mean) * rstd * c2);
+            GNF_ST(GNF_AT(f32x4, ob, off[i]), o);
+            if (ACT == GNF_ADD_RELU) GNF_ST(GNF_AT(f32x4, db_, off[i]), gr[i]);
+        }
+    }
+}
+
+// units of a (sample, group) for NW waves: every channel cut into S segments so that there are at least NW units, segment lengths
+// multiples of 64 vectors (a wave's loads stay whole KiB)
+static GnfUnits gnf_units(int cg, int HW, int nwaves) {
+    GnfUnits u;
+    const int vpc = HW >> 2;
+    u.S = cg >= nwaves ? 1 : (nwaves + cg - 1) / cg;
+    u.segv = ((vpc + u.S - 1) / u.S + 63) / 64 * 64;
+    u.S = (vpc + u.segv - 1) / u.segv;
+    u.units = cg * u.S;
+    return u;
 }
 
 // ---- small launches (CAM generation: two views of one image = 64 (sample, group) pairs on 256 CUs) ---------------------------------
@@ -252,18 +561,45 @@ static int gnf_check(const char* who, int N, int C, int HW, int act) {
     ACR_CHECK_ARG(N > 0 && C > 0 && (C % GNF_GROUPS) == 0, "%s: C=%d must be a multiple of 32", who, C);
     ACR_CHECK_ARG(HW > 0 && (HW % 4) == 0, "%s: H*W=%d must be a multiple of 4 (16-byte vectors per channel)", who, HW);
     ACR_CHECK_ARG(act >= 0 && act <= 2, "%s: unknown act %d", who, act);
+    ACR_CHECK_ARG(C / GNF_GROUPS <= GNF_MAXU / 2, "%s: C=%d: at most %d channels per group", who, C, GNF_MAXU / 2);
     return ACR_OK;
 }
 
+// register-resident plan: threads per workgroup, units, units per wave, chunks per unit; ok = every lane holds <= GNF_RV vectors
+struct GnfRegPlan { bool ok; int nt; GnfUnits un; int upw, ch; };
+static GnfRegPlan gnf_reg_plan(int cg, int HW) {
+    GnfRegPlan p;
+    const int nvec = cg * (HW >> 2);
+    p.nt = nvec > 2048 ? 1024 : 256;
+    const int nw = p.nt / 64;
+    p.un = gnf_units(cg, HW, nw);
+    p.ch = (p.un.segv + 63) / 64;
+    p.upw = (p.un.units + nw - 1) / nw;
+    p.ok = p.upw * p.ch <= GNF_RV && p.un.units <= GNF_MAXU;
+    return p;
+}
+#define GNF_DISPATCH_REG(KERNEL, P, ...)                                                                          \
+    if ((P).nt == 1024) {                                                                                         \
+        if (act == 0) hipLaunchKernelGGL((KERNEL<1024, 0>), grid, dim3(1024), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);        \
+        else if (act == 1) hipLaunchKernelGGL((KERNEL<1024, 1>), grid, dim3(1024), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);   \
+        else hipLaunchKernelGGL((KERNEL<1024, 2>), grid, dim3(1024), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);                 \
+    } else {                                                                                                      \
+        if (act == 0) hipLaunchKernelGGL((KERNEL<256, 0>), grid, dim3(256), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);          \
+        else if (act == 1) hipLaunchKernelGGL((KERNEL<256, 1>), grid, dim3(256), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);     \
+        else hipLaunchKernelGGL((KERNEL<256, 2>), grid, dim3(256), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);                   \
+    }
+
 #define GNF_DISPATCH(KERNEL, ...)                                                                                \
     if (big) {                                                                                                    \
-        if (act == 0) hipLaunchKernelGGL((KERNEL<1024, 0>), grid, dim3(1024), 0, st, __VA_ARGS__);               \
-        else if (act == 1) hipLaunchKernelGGL((KERNEL<1024, 1>), grid, dim3(1024), 0, st, __VA_ARGS__);          \
-        else hipLaunchKernelGGL((KERNEL<1024, 2>), grid, dim3(1024), 0, st, __VA_ARGS__);                        \
+        const GnfUnits un = gnf_units(cg, HW, 16);                                                                \
+        if (act == 0) hipLaunchKernelGGL((KERNEL<1024, 0>), grid, dim3(1024), 0, st, __VA_ARGS__, un);           \
+        else if (act == 1) hipLaunchKernelGGL((KERNEL<1024, 1>), grid, dim3(1024), 0, st, __VA_ARGS__, un);      \
+        else hipLaunchKernelGGL((KERNEL<1024, 2>), grid, dim3(1024), 0, st, __VA_ARGS__, un);                    \
     } else {                                                                                                      \
-        if (act == 0) hipLaunchKernelGGL((KERNEL<256, 0>), grid, dim3(256), 0, st, __VA_ARGS__);                 \
-        else if (act == 1) hipLaunchKernelGGL((KERNEL<256, 1>), grid, dim3(256), 0, st, __VA_ARGS__);            \
-        else hipLaunchKernelGGL((KERNEL<256, 2>), grid, dim3(256), 0, st, __VA_ARGS__);                          \
+        const GnfUnits un = gnf_units(cg, HW, 4);                                                                 \
+        if (act == 0) hipLaunchKernelGGL((KERNEL<256, 0>), grid, dim3(256), 0, st, __VA_ARGS__, un);             \
+        else if (act == 1) hipLaunchKernelGGL((KERNEL<256, 1>), grid, dim3(256), 0, st, __VA_ARGS__, un);        \
+        else hipLaunchKernelGGL((KERNEL<256, 2>), grid, dim3(256), 0, st, __VA_ARGS__, un);                      \
     }
 
 extern "C" int acr_groupnorm_fwd_f32(const float* x, const float* resid, const float* gamma, const float* beta, float* y, float* stats,
@@ -286,6 +622,11 @@ extern "C" int acr_groupnorm_fwd_f32(const float* x, const float* resid, const f
         else hipLaunchKernelGGL((gnf_apply_kernel<2>), pgrid, dim3(256), 0, st, x, resid, gamma, beta, (const float*)ws, y, stats, C, HW, cg, P, vper, eps);
         return acr_check_launch("acr_groupnorm_fwd_f32(parts)");
     }
+    const GnfRegPlan rp = gnf_reg_plan(cg, HW);
+    if (rp.ok) {                                            // the group fits the workgroup's registers: one read
+        GNF_DISPATCH_REG(gnf_fwd_reg_kernel, rp, x, resid, gamma, beta, y, stats, C, HW, cg, eps)
+        return acr_check_launch("acr_groupnorm_fwd_f32(reg)");
+    }
     GNF_DISPATCH(gnf_fwd_kernel, x, resid, gamma, beta, y, stats, C, HW, cg, eps)
     return acr_check_launch("acr_groupnorm_fwd_f32");
 }
@@ -303,7 +644,12 @@ extern "C" int acr_groupnorm_bwd_f32(const float* dy, const float* x, const floa
     const bool big = (int64_t)HW >= 4096;                    // per-channel loops: 1024 threads only when a channel feeds them
     const dim3 grid(N * GNF_GROUPS);
     hipStream_t st = (hipStream_t)stream;
-    GNF_DISPATCH(gnf_bwd_kernel, dy, x, resid, gamma, beta, stats, dx, dresid, dgamma_part, dbeta_part, C, HW, cg)
+    const GnfRegPlan rp = gnf_reg_plan(cg, HW);
+    if (rp.ok) {
+        GNF_DISPATCH_REG(gnf_bwd_reg_kernel, rp, dy, x, resid, gamma, beta, stats, dx, dresid, dgamma_part, dbeta_part, C, HW, cg)
+    } else {
+        GNF_DISPATCH(gnf_bwd_kernel, dy, x, resid, gamma, beta, stats, dx, dresid, dgamma_part, dbeta_part, C, HW, cg)
+    }
     if (dgamma && dbeta)
         hipLaunchKernelGGL(gnf_param_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, (const float*)dgamma_part,
                            (const float*)dbeta_part, N, C, dgamma, dbeta);

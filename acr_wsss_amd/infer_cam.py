@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
+from .backbone import pass_graph
 
 
 _STREAMS = {}
@@ -128,25 +129,32 @@ def launch_cam_images(model, imgs, labels, out_hws, start_layer=10, func="grad",
                 for flips in passes:
                     inp = torch.cat([base.flip(-1) if f else base for f in flips], dim=0)       # sample index = fi * B + i
                     patch_items, cam_items = [], []
-                    with torch.enable_grad():
-                        cls_pred, _, attn, patch_cam = model.forward_cam(inp)
-                        pc = patch_cam.detach().float()
-                        for fi, flipped in enumerate(flips):
-                            for i in range(B):
-                                patch_items.append((pc[fi * B + i], i, flipped, ph, pw))
-                        # one backward per class rank k serves the k-th positive class of every sample of the pass; the GETAM
-                        # rows of ALL samples come from one launch per layer (ACR.getam_all) and the affinity product of all
-                        # samples and classes from one more
-                        nf = len(flips)
-                        rows = []
-                        for k in range(kmax):
-                            tgt = (cls_pred.float() * (mask2[k] if nf == 2 else mask1[k])).sum()
-                            if truncate:
-                                torch.autograd.grad(tgt, vit.trunc_input, retain_graph=True)
-                            else:
-                                model.zero_grad()
-                                tgt.backward(retain_graph=True)
-                            rows.append(model.getam_all(start_layer=start_layer, func=func))       # (nf * B, N)
+                    nf = len(flips)
+                    masks = mask2 if nf == 2 else mask1
+                    # the whole pass -- forward_cam + one class-logit backward / GETAM read-out per class rank -- as captured
+                    # hipGraphs for this geometry (backbone.PassGraph), else launch by launch
+                    pg = pass_graph(model, inp, start_layer, func) if truncate else None
+                    if pg is not None:
+                        pc, attn, rows = pg.run(model, inp, [masks[k] for k in range(kmax)])
+                    else:
+                        with torch.enable_grad():
+                            cls_pred, _, attn, patch_cam = model.forward_cam(inp)
+                            pc = patch_cam.detach().float()
+                            # one backward per class rank k serves the k-th positive class of every sample of the pass; the
+                            # GETAM rows of ALL samples come from one launch per layer (ACR.getam_all) and the affinity product
+                            # of all samples and classes from one more
+                            rows = []
+                            for k in range(kmax):
+                                tgt = (cls_pred.float() * masks[k]).sum()
+                                if truncate:
+                                    torch.autograd.grad(tgt, vit.trunc_input, retain_graph=True)
+                                else:
+                                    model.zero_grad()
+                                    tgt.backward(retain_graph=True)
+                                rows.append(model.getam_all(start_layer=start_layer, func=func))       # (nf * B, N)
+                    for fi, flipped in enumerate(flips):
+                        for i in range(B):
+                            patch_items.append((pc[fi * B + i], i, flipped, ph, pw))
                     if kmax:
                         cams_all = torch.stack(rows, dim=1)                                          # (nf * B, kmax, N)
                         if aff:                                                                      # patch_aff @ cam (:164-165,183-184)

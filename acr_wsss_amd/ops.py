@@ -943,36 +943,12 @@ class Conv1x1Fn(Function):
         return dx, dw, None, None
 
 
-CONV3X3_PAD = 512          # include/acr_hip.h ACR_CONV3X3_PAD: floats of readable memory acr_conv3x3_* want on either side of x
-
-
-def empty_with_margin(like):
-    """torch.empty_like(like) (contiguous) inside an allocation with CONV3X3_PAD elements of slack before and behind it: the
-    shifted tap reads of acr_conv3x3_f32 leave the tensor by up to a tile + a row at its two ends (values masked, the
-    addresses must be mapped)."""
-    if like.dtype != torch.float32:
-        return torch.empty_like(like)
-    n = like.numel()
-    buf = torch.empty(n + 2 * CONV3X3_PAD, dtype=like.dtype, device=like.device)
-    return buf[CONV3X3_PAD:CONV3X3_PAD + n].view(like.shape)
-
-
-def _with_margin(t):
-    """t itself when its storage has the margin acr_conv3x3_* ask for, else a copy that has."""
-    if (t.is_contiguous() and t.storage_offset() >= CONV3X3_PAD
-            and t.untyped_storage().nbytes() >= (t.storage_offset() + t.numel() + CONV3X3_PAD) * t.element_size()):
-        return t
-    out = empty_with_margin(t)
-    out.copy_(t)
-    return out
-
-
 def conv3x3_fusable(x, weight, stride, math):
     """fp32 NCHW 3x3 stride-1 convolution with split products that acr_conv3x3_{f32,wgrad_f32} cover (the stem's conv2s)."""
     return (math == 1 and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and stride == 1
             and tuple(weight.shape[2:]) == (3, 3) and x.is_contiguous() and not torch.is_autocast_enabled()
             and x.shape[1] % 16 == 0 and weight.shape[0] % 16 == 0 and x.shape[3] % 4 == 0 and x.shape[3] >= 16
-            and (x.shape[2] * x.shape[3]) % 16 == 0 and x.shape[3] + 129 <= CONV3X3_PAD)     # the margin bound the entry points enforce
+            and (x.shape[2] * x.shape[3]) % 16 == 0)
 
 
 def _conv3x3_launch(wp, x, y, N, co, ci, H, W):
@@ -990,7 +966,6 @@ class Conv3x3Fn(Function):
     def forward(ctx, x, weight):
         N, C, H, W = x.shape
         co = weight.shape[0]
-        x = _with_margin(x)
         wp = weight.permute(0, 2, 3, 1).reshape(co, 9 * C).contiguous()
         y = torch.empty((N, co, H, W), dtype=torch.float32, device=x.device)
         _conv3x3_launch(wp, x, y, N, co, C, H, W)
@@ -1003,7 +978,7 @@ class Conv3x3Fn(Function):
         N, C, H, W = x.shape
         co = weight.shape[0]
         lib = L.load()
-        dy = _with_margin(dy if dy.dtype == torch.float32 else dy.float())
+        dy = (dy if dy.dtype == torch.float32 else dy.float()).contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
             wd = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * co).contiguous()
@@ -1128,7 +1103,7 @@ class GroupNormActFn(Function):
     def forward(ctx, x, weight, bias, resid, act, eps):
         N, C, H, W = x.shape
         lib = L.load()
-        y = empty_with_margin(x)                          # a 3x3 convolution reads it next (Conv3x3Fn)
+        y = torch.empty_like(x)
         stats = torch.empty(N * 32 * 2, dtype=torch.float32, device=x.device)
         if x.dtype == torch.float32:
             # gradient-free passes (CAM generation) of a few samples: the (sample, group) pairs are cut into parts (two launches)
@@ -1150,7 +1125,7 @@ class GroupNormActFn(Function):
         lib = L.load()
         if not dy.is_contiguous() or dy.dtype != x.dtype:
             dy = dy.to(x.dtype).contiguous()
-        dx = empty_with_margin(x)                         # the gradient a 3x3 convolution's input-gradient launch reads
+        dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.act == 2 else None
         part = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
         dgb = torch.empty((2, C), dtype=x.dtype, device=x.device)             # summed over samples inside the call

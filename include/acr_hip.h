@@ -85,9 +85,8 @@ typedef enum acr_option {
     ACR_OPT_WGRAD_WAVES = 4,    /* 4 or 8 waves per 256x256 workgroup */
     ACR_OPT_DQ_VARIANT = 5,     /* acr_attn_bwd (bf16) dQ sweep: 0 = by presence of G, 2 = 2-wave, 4 = 4-wave */
     ACR_OPT_GEMM_F32_REGSTAGE = 6, /* 1: acr_gemm_f32 always takes the register-staged kernel (A/B of the LDS-DMA kernel) */
-    ACR_OPT_GEMM_X3_MFMA16 = 7, /* 1: acr_gemm_x3 on v_mfma_f32_16x16x32_bf16 (two split terms per MFMA) instead of 32x32x16 (A/B: measured no faster).
-                                   (Option 7 was ACR_OPT_ATTN_F32_GEN1 in ABI 1: those sweeps left the library, lab flag -DACR_LAB_ATTN_GEN1.) */
-    ACR_OPT_ATTN_F32_NW = 8,    /* acr_attn_fwd_scores: 5 = five 32-query blocks (waves) per forward workgroup instead of four (A/B: slower) */
+    ACR_OPT_RESERVED_7 = 7,      /* was ACR_OPT_GEMM_X3_MFMA16 (16x16x32 image products: a tested negative result, out of the library since round 5) */
+    ACR_OPT_RESERVED_8 = 8,      /* was ACR_OPT_ATTN_F32_NW (five-wave forward workgroups: measured slower, out of the library since round 5) */
     ACR_OPT_GEMM_F32_NOTAIL = 9, /* 1: acr_gemm_f32 NT / NN never K-splits the tiles beyond the last whole half-round (A/B) */
     ACR_OPT_ATTN_F32_NOSPLITTAIL = 10, /* 1: resident-score attention keeps the leftover 32-row block as an ordinary (1 live wave) workgroup (A/B) */
     ACR_OPT_GEMM_X3_INKERNEL = 11, /* 1: split-product acr_gemm_f32 splits operand tiles inside the GEMM kernel instead of once per product into bf16 planes (A/B) */
@@ -281,11 +280,10 @@ int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const float* b_im
  * w_packed = w.flip(2,3).permute(1,2,3,0) as (cin, 9*cout).  cin %% 16 == 0, H*W %% 4 == 0, 16-byte aligned pointers.
  * ws: acr_conv3x3_ws_floats(...) floats or NULL (0 for launches that fill the chip: only small ones -- CAM generation on one image --
  * are split along the contraction into slabs, summed in a fixed order).
- * The shifted tap reads leave x at its two ends (values masked, addresses dereferenced): the caller guarantees
- * ACR_CONV3X3_PAD floats of readable device memory before x and behind its last element (contents irrelevant).
+ * No byte outside [x, x + nsamp*cin*H*W) is addressed: the workgroups whose shifted tap windows touch the tensor's two ends clamp
+ * their reads into it (ABI 2 rounds 3-4 asked the caller for ACR_CONV3X3_PAD floats of readable slack there; that contract is gone).
  * acr_conv3x3_wgrad_f32: dw_packed (cout, 9*cin) = sum_n sum_p dy[n][co][p] * x[n][ci][p + off_t]; ws: fp32 slabs of
  * acr_conv3x3_wgrad_ws_floats(...) floats, summed in a fixed order (deterministic). */
-#define ACR_CONV3X3_PAD 512
 size_t acr_conv3x3_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W);
 int acr_conv3x3_f32(int32_t math, const float* w_packed, const float* x, float* y, int32_t nsamp, int32_t cout, int32_t cin,
                     int32_t H, int32_t W, float* ws, void* stream);

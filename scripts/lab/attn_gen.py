@@ -21,7 +21,6 @@ gpm = gst[:, :, :T]
 res = {}
 for gen in ("recompute", "scores nw4", "split x3 notail", "split x3"):
     ops.ATTN_F32_SCORES = gen != "recompute"
-    _lib.set_option("attn_f32_nw", 5 if gen.endswith("5") else 4)
     _lib.set_option("attn_f32_nosplittail", 1 if gen.endswith("notail") else 0)
     stack = ops.MeanStack(B, 1, T, dev)
     def run():

@@ -7,7 +7,7 @@ dev = "cuda:0"
 torch.manual_seed(0)
 m = ACR(20, "vitb_hybrid", use_pretrain=False).to(dev).eval()
 vit = m.pretrained.model
-vit.graph_prefix = False
+vit.graph_prefix = False; vit.graph_pass = False
 for p in m.parameters():
     p.requires_grad_(False)
 for blk in vit.blocks:

@@ -907,18 +907,8 @@ def test_groupnorm_f32_small_launch_parts(N, C, H, W, act):
     assert (y - y1).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.fixture
-def x3_mfma(request):
-    """acr_gemm_x3 on its default 32x32x16 MFMAs or on the 16x16x32 A/B kernels (two split terms per MFMA, LDS-staged finish)."""
-    from acr_wsss_amd import _lib
-    _lib.set_option("gemm_x3_mfma16", 1 if request.param == "mfma16" else 0)
-    yield request.param
-    _lib.set_option("gemm_x3_mfma16", 0)
-
-
-@pytest.mark.parametrize("x3_mfma", ["mfma32", "mfma16"], indirect=True)
 @pytest.mark.parametrize("M,N,K", [(300, 200, 100), (128, 128, 16), (1000, 768, 772), (2500, 64, 3072), (37, 260, 40)])
-def test_gemm_x3_images(M, N, K, x3_mfma):
+def test_gemm_x3_images(M, N, K):
     """The split-product image API (acr_x3_image / acr_x3_image_t / acr_gemm_x3): NT with bias + residual, the input-gradient form
     through the transposed image of the weight, TN on the SAME images of dy and x the other two products read (transposed LDS
     reads), column sums of dy from the image pass -- vs float64 at the fp32 GEMM tests' tolerance; shapes with partial row
@@ -962,9 +952,8 @@ def test_gemm_x3_images(M, N, K, x3_mfma):
         assert torch.equal(dw, dw3)                          # fixed slab order
 
 
-@pytest.mark.parametrize("x3_mfma", ["mfma32", "mfma16"], indirect=True)
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 3072, 768), (25120, 3072, 768), (2100, 520, 96)])
-def test_gemm_x3_image_epilogues(M, N, K, x3_mfma):
+def test_gemm_x3_image_epilogues(M, N, K):
     """acr_gemm_x3 act 3 / 4: the product's output leaves the kernel as the next product's image.  The image equals, bit for bit,
     the image pass run over the fp32 result of act 1 / 2 (same erf form, same split), the fp32 GELU' of act 3 equals act 1's, and
     act 4's column sums equal the image pass's (same summation order); covers the K-split tail tiles (1000 x 3072: 192 tiles, all
@@ -1058,8 +1047,7 @@ def test_conv3x3_split(N, cin, cout, H, W):
     kernel, flipped taps) and weight gradient vs fp64 conv2d at the fp32 GEMM tests' tolerance.  Covers cout = 64 (half a tile
     row), pixel tiles that run past H*W and whose rows straddle image rows (W = 20, 28, 36), H != W, 9 cin not a multiple of the
     tile (cin = 16, 32, 64), several pixel parts in the weight gradient (112 x 112), the K-split small launches of CAM generation
-    (two views at 24 x 24 and 48 x 48: 20 / 72 workgroups split 7 ways into slabs), a full-size training launch -- and inputs
-    WITHOUT the margin the entry point asks for (ops copies them into a buffer that has it)."""
+    (two views at 24 x 24 and 48 x 48: 20 / 72 workgroups split 7 ways into slabs), a full-size training launch."""
     from acr_wsss_amd import ops
     import torch.nn.functional as F
     dev = _dev()
@@ -1092,18 +1080,47 @@ def test_conv3x3_split(N, cin, cout, H, W):
     assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad) and torch.equal(w2.grad, w.grad)
 
 
-def test_conv3x3_margin_contract():
-    """acr_conv3x3_* read up to ACR_CONV3X3_PAD floats outside x (masked): ops hands them tensors whose storage has that slack --
-    the GroupNorm outputs are allocated with it, anything else is copied."""
-    from acr_wsss_amd import ops
+def test_conv3x3_reads_nothing_outside_its_input():
+    """acr_conv3x3_f32 / acr_conv3x3_wgrad_f32 used to dereference addresses up to ACR_CONV3X3_PAD floats outside x
+    (shifted tap windows, values masked) and asked the caller for readable slack.  Now the workgroups at the tensor's two ends
+    clamp their reads into it.  The input here IS a whole device allocation: 16 MiB, a multiple of the caching allocator's 2 MiB
+    granule and above its 10 MiB small-block limit, so the tensor starts at the first and ends at the last byte of its own
+    hipMalloc block -- called straight through the C ABI on exactly those pointers, forward (as x) and both backward launches (as
+    dy / x), against fp64 conv2d.  (A read outside the block is a GPU memory fault, not a wrong value: the masked lanes never
+    showed up in results, which is why the old contract could not be tested from the outside.)"""
+    from acr_wsss_amd import _lib as L
+    import torch.nn.functional as F
     dev = _dev()
-    x = torch.randn(2, 32, 16, 16, device=dev)
-    assert ops._with_margin(x) is not x and torch.equal(ops._with_margin(x), x)
-    m = ops.empty_with_margin(x)
-    assert ops._with_margin(m) is m and m.is_contiguous() and m.data_ptr() % 16 == 0
-    assert m.storage_offset() == ops.CONV3X3_PAD and m.untyped_storage().nbytes() == (x.numel() + 2 * ops.CONV3X3_PAD) * 4
-    y = ops.groupnorm_act(x, torch.ones(32, device=dev), torch.zeros(32, device=dev), "relu")
-    assert ops._with_margin(y) is y
+    lib = L.load()
+    N, C, H, W = 4, 64, 128, 128
+    g = torch.Generator(device="cpu").manual_seed(5)
+    pool = torch.cuda.MemPool()                             # a private pool: nothing cached in it, so the request below is a fresh hipMalloc
+    with torch.cuda.use_mem_pool(pool):
+        x = torch.empty(N * C * H * W, dtype=torch.float32, device=dev)              # its own 16 MiB segment
+    assert x.untyped_storage().nbytes() == 16 << 20 and x.storage_offset() == 0
+    seg = [b for b in torch.cuda.memory_snapshot() if b["address"] <= x.data_ptr() < b["address"] + b["total_size"]]
+    assert seg and seg[0]["address"] == x.data_ptr() and seg[0]["total_size"] == 16 << 20, "the tensor must fill its hipMalloc block"
+    x.copy_(torch.randn(N * C * H * W, generator=g))
+    x = x.view(N, C, H, W)
+    w = (torch.randn(C, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(dev)
+    wp = w.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()
+    y = torch.empty(N, C, H, W, device=dev)
+    L.check(lib.acr_conv3x3_f32(1, L.ptr(wp), L.ptr(x), L.ptr(y), N, C, C, H, W, None, L.stream_ptr()), "acr_conv3x3_f32")
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    assert (y.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    # the same block as dy of the input gradient and as x of the weight gradient (dy: another exact-fit block)
+    wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * C).contiguous()
+    dx = torch.empty(N, C, H, W, device=dev)
+    L.check(lib.acr_conv3x3_f32(1, L.ptr(wd), L.ptr(x), L.ptr(dx), N, C, C, H, W, None, L.stream_ptr()), "acr_conv3x3_f32 (dX)")
+    refdx = F.conv_transpose2d(x.double(), w.double(), padding=1)
+    assert (dx.double() - refdx).abs().max() <= 1e-5 * refdx.abs().max()
+    dy = torch.randn(N, C, H, W, generator=g).to(dev)
+    ws = torch.empty(lib.acr_conv3x3_wgrad_ws_floats(N, C, C, H, W), device=dev)
+    dwp = torch.empty(C, 3, 3, C, device=dev)
+    L.check(lib.acr_conv3x3_wgrad_f32(1, L.ptr(dy), L.ptr(x), N, C, C, H, W, L.ptr(ws), L.ptr(dwp), L.stream_ptr()), "acr_conv3x3_wgrad_f32")
+    wdbl = w.double().requires_grad_(True)
+    (F.conv2d(x.double(), wdbl, padding=1) * dy.double()).sum().backward()
+    assert (dwp.permute(0, 3, 1, 2).double() - wdbl.grad).abs().max() <= 1e-5 * wdbl.grad.abs().max()
 
 
 @pytest.mark.parametrize("dtype,math", [(torch.float32, 0), (torch.float32, 1), (torch.bfloat16, 0)])
