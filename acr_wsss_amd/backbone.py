@@ -584,8 +584,10 @@ def pass_graph(model, inp, start_layer, func):
         try:
             g = PassGraph(model, inp, start_layer, func)
         except RuntimeError as e:              # an op that cannot be captured on this build: stay on eager launches
+            import traceback
             import warnings
-            warnings.warn("hipGraph capture of the GETAM pass failed (%s); running it eagerly" % str(e).splitlines()[0])
+            where = [l.strip() for l in traceback.format_exc().splitlines() if l.strip().startswith("File")][-3:]
+            warnings.warn("hipGraph capture of the GETAM pass failed (%s; %s); running it eagerly" % (str(e).splitlines()[0], " <- ".join(reversed(where))))
             torch.cuda.synchronize()
             g = False
         finally:

@@ -229,6 +229,157 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const Conv3Args g
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The same product with the packed weight given as a split-product IMAGE (acr_x3_image of w_packed: tiled bf16 planes, tiny, made
+// once per weight version): only the shifted activation tile is split in registers -- half the vector work per MFMA of the kernel
+// above, which is bound by exactly that work (round 5; the 1x1 convolutions made the same move in round 4, gemm_f32_wimg_kernel,
+// whose ring this is: 3 slots x [A planes 12 KiB | B fp32 8 KiB], DMA two stages ahead, 3 + 2 pieces per wave and stage, counted
+// vmcnt, fence-free barrier).  B tile, tap shift, validity masks, careful edge path and K-split slabs are the kernel's above.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define C3W_PLANE_B 4096                  // one plane of a 128-row x 16-deep A stage in the tiled image
+#define C3W_STAGE_B (3 * C3W_PLANE_B + C3_TILE * 4)        // 20 KiB
+#define C3W_SLOTS 3
+#define C3W_RD128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
+#define C3W_RD32(dst, addr, OFF) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
+__global__ __launch_bounds__(256, 2) void conv3x3_wimg_kernel(const Conv3Args g) {
+    __shared__ __attribute__((aligned(1024))) char smem[C3W_SLOTS * C3W_STAGE_B];       // 60 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int t1 = acr_xcd_remap(blockIdx.x, ntile * g.nsamp * g.ksplit);
+    const int part = t1 / (ntile * g.nsamp), t0 = t1 - part * (ntile * g.nsamp);
+    const int sample = t0 / ntile, tt = t0 - sample * ntile;
+    const int tn = tt / g.tiles_m, tm = tt - tn * g.tiles_m;
+    const int sbeg = part * g.sps;
+    const int m0 = tm * C3_BM, n0 = tn * C3_BN;
+    const int nkb = 9 * g.C / C3_BK;                        // stages per row block of the weight image
+    const char* __restrict__ pa = reinterpret_cast<const char*>(g.w) + ((int64_t)tm * nkb + sbeg) * (3 * C3W_PLANE_B) + wave * 3072 + lane * 16;
+    const float* __restrict__ pb = g.x + (int64_t)sample * g.C * g.HW;
+    const bool compute = m0 + wm * 64 < g.M;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int rowb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rowb[i] = ((wave * 2 + i) * 2 + (lane >> 5)) * g.HW;
+    const int pix = n0 + 4 * (lane & 31);
+    const int valid0 = c3_valid9(n0 + wn * 64 + r, g.H, g.W, g.HW), valid1 = c3_valid9(n0 + wn * 64 + 32 + r, g.H, g.W, g.HW);
+    const int nst = min(nkb - sbeg, g.sps);
+    const int64_t total = (int64_t)g.nsamp * g.C * g.HW;
+    const bool edge = (sample == 0 && n0 < g.W + 1) || (sample == g.nsamp - 1 && n0 + C3_BN + g.W + 1 > g.HW);
+    auto issue = [&](int st, int slot) {                    // 3 A pieces (contiguous KiB of the image) + 2 shifted B pieces
+        char* d = smem + slot * C3W_STAGE_B;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds((c3_glb_vp)(pa + (int64_t)st * (3 * C3W_PLANE_B) + i * 1024), (c3_lds_vp)(d + (wave * 3 + i) * 1024), 16, 0, 0);
+        const int k0 = (sbeg + st) * C3_BK;
+        const int tap = k0 / g.C, ci0 = k0 - tap * g.C;
+        const int ty = tap / 3, off = (ty - 1) * g.W + (tap - 3 * ty - 1);
+        float* db = reinterpret_cast<float*>(d + 3 * C3W_PLANE_B);
+        if (edge) {
+            const int64_t i0 = (int64_t)sample * g.C * g.HW + (int64_t)ci0 * g.HW + (pix + off);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) c3_dma_careful(g.x, i0 + rowb[i], total, db + (wave * 2 + i) * 256, lane);
+            return;
+        }
+        const float* xb = pb + (int64_t)ci0 * g.HW + (pix + off);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((c3_glb_vp)(xb + rowb[i]), (c3_lds_vp)(db + (wave * 2 + i) * 256), 16, 0, 0);
+    };
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    const uint32_t fa = lbase + (wm * 64 + r) * 32 + (h ^ ((r >> 3) & 1)) * 16;
+    const uint32_t fb = lbase + 3 * C3W_PLANE_B + ((8 * h) * C3_BN + wn * 64 + r) * 4;
+    issue(0, 0);
+    issue(min(1, nst - 1), 1);
+    bf16x8 ap[2][2][3], bp[2][2][3];                        // [register set][block][plane]
+    float rb[2][8];
+#define C3W_MFMA6(SET, I, J)                                                                                                 \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][2], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][2], bp[SET][J][0], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][1], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][1], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][0], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][0], acc[I][J], 0, 0, 0);
+    auto step = [&](int st, int slot, auto set_tag, auto first_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        // stage st has landed when at most the 5 pieces of stage st + 1 are outstanding; the careful edge path may have issued
+        // more (younger) operations: a count that is too high only makes this wait stricter
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        __syncthreads();                                    // (the edge path publishes plain LDS stores: keep the fence)
+        const int rslot = slot == 0 ? 2 : slot - 1;         // (st + 2) % 3
+        issue(min(st + 2, nst - 1), rslot);                 // past the end: the last stage again, into a slot nobody reads
+        if (!compute) return;
+        const uint32_t fas = fa + slot * C3W_STAGE_B, fbs = fb + slot * C3W_STAGE_B;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            C3W_RD32(rb[j][0], fbs, 0 * C3_BN * 4 + j * 128); C3W_RD32(rb[j][1], fbs, 1 * C3_BN * 4 + j * 128);
+            C3W_RD32(rb[j][2], fbs, 2 * C3_BN * 4 + j * 128); C3W_RD32(rb[j][3], fbs, 3 * C3_BN * 4 + j * 128);
+            C3W_RD32(rb[j][4], fbs, 4 * C3_BN * 4 + j * 128); C3W_RD32(rb[j][5], fbs, 5 * C3_BN * 4 + j * 128);
+            C3W_RD32(rb[j][6], fbs, 6 * C3_BN * 4 + j * 128); C3W_RD32(rb[j][7], fbs, 7 * C3_BN * 4 + j * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            C3W_RD128(ap[SET][i][0], fas, 0 * C3W_PLANE_B + i * 1024); C3W_RD128(ap[SET][i][1], fas, 1 * C3W_PLANE_B + i * 1024);
+            C3W_RD128(ap[SET][i][2], fas, 2 * C3W_PLANE_B + i * 1024);
+        }
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[0][2]), "+v"(rb[0][3]), "+v"(rb[0][4]), "+v"(rb[0][5]), "+v"(rb[0][6]),
+                     "+v"(rb[0][7]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[1][2]), "+v"(rb[1][3]), "+v"(rb[1][4]), "+v"(rb[1][5]), "+v"(rb[1][6]), "+v"(rb[1][7]));
+        __builtin_amdgcn_sched_barrier(0);
+        const int tap = ((sbeg + st) * C3_BK) / g.C;        // uniform
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = (((j ? valid1 : valid0) >> tap) & 1) != 0;
+            f32x4 lo = {rb[j][0], rb[j][1], rb[j][2], rb[j][3]}, hi = {rb[j][4], rb[j][5], rb[j][6], rb[j][7]};
+            if (!ok) { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            c3_split3(lo, hi, bp[SET][j][0], bp[SET][j][1], bp[SET][j][2]);
+        }
+        if (!FIRST) {
+            C3W_MFMA6(SET ^ 1, 0, 0) C3W_MFMA6(SET ^ 1, 0, 1) C3W_MFMA6(SET ^ 1, 1, 0) C3W_MFMA6(SET ^ 1, 1, 1)
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA of stage st - 1
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // four VALU instructions of stage st's split
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ap[SET][0][0]), "+v"(ap[SET][0][1]), "+v"(ap[SET][0][2]), "+v"(ap[SET][1][0]), "+v"(ap[SET][1][1]), "+v"(ap[SET][1][2]));
+    };
+    step(0, 0, std::integral_constant<int, 0>{}, std::true_type{});
+    int slot = 1;
+    for (int st = 1; st < nst; st += 2) {
+        step(st, slot, std::integral_constant<int, 1>{}, std::false_type{});
+        slot = slot == 2 ? 0 : slot + 1;
+        if (st + 1 < nst) {
+            step(st + 1, slot, std::integral_constant<int, 0>{}, std::false_type{});
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end (nobody may leave LDS-DMA in flight)
+    if (!compute) return;
+    if (nst & 1) { C3W_MFMA6(0, 0, 0) C3W_MFMA6(0, 0, 1) C3W_MFMA6(0, 1, 0) C3W_MFMA6(0, 1, 1) }
+    else { C3W_MFMA6(1, 0, 0) C3W_MFMA6(1, 0, 1) C3W_MFMA6(1, 1, 0) C3W_MFMA6(1, 1, 1) }
+#undef C3W_MFMA6
+    float* yb = (g.ksplit > 1 ? g.ws + (int64_t)part * g.nsamp * g.M * g.HW : g.y) + (int64_t)sample * g.M * g.HW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + acr_krow(e, h);
+                if (row < g.M && col < g.HW) yb[(int64_t)row * g.HW + col] = acc[i][j][e];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // weight gradient: c[co][t*C + ci] = sum_p dy[co][p] * x[ci][p + off_t] * valid_t(p) per (sample, pixel part) into fp32 slabs,
 // summed in a fixed order afterwards.  Both operands are contiguous in the contraction index p (gemm_f32.hip's KC images): A rows
 // = dy's channels, B rows = the 9 C (tap, channel) pairs, each an x channel row SHIFTED by its tap's offset (per-lane source
@@ -483,4 +634,29 @@ extern "C" int acr_conv3x3_f32(int32_t math, const float* w_packed, const float*
         hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, g.ksplit, n4, y);
     }
     return acr_check_launch("acr_conv3x3_f32");
+}
+
+// acr_conv3x3_f32 with the packed weight as a split-product image (acr_x3_image of w_packed: rows = cout, cols = 9 cin): same
+// contract, same workspace (acr_conv3x3_ws_floats), conv3x3_wimg_kernel.
+extern "C" int acr_conv3x3_x3(const float* w_img, const float* x, float* y, int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W,
+                              float* ws, void* stream) {
+    ACR_CHECK_ARG(w_img && x && y, "acr_conv3x3_x3: null pointer");
+    ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && (cin % C3_BK) == 0 && H > 0 && W > 0 && ((int64_t)H * W) % 4 == 0 && (int64_t)H * W >= 4,
+                  "acr_conv3x3_x3: need cin %% 16 == 0 and H*W %% 4 == 0 (n=%d co=%d ci=%d %dx%d)", nsamp, cout, cin, H, W);
+    ACR_CHECK_ARG(((uintptr_t)w_img & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "acr_conv3x3_x3: 16-byte alignment");
+    ACR_CHECK_ARG((int64_t)cin * H * W < (1ll << 30), "acr_conv3x3_x3: sample too large for 32-bit offsets");
+    Conv3Args g;
+    g.w = w_img; g.x = x; g.y = y; g.M = cout; g.C = cin; g.H = H; g.W = W; g.HW = H * W; g.nsamp = nsamp;
+    g.tiles_m = (cout + C3_BM - 1) / C3_BM; g.tiles_n = (g.HW + C3_BN - 1) / C3_BN;
+    const int nst = 9 * cin / C3_BK;
+    g.ksplit = (ws && ((uintptr_t)ws & 15) == 0) ? c3_fwd_ksplit(nsamp, cout, cin, g.HW) : 1;
+    g.sps = (nst + g.ksplit - 1) / g.ksplit; g.ws = ws;
+    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp * g.ksplit;
+    ACR_CHECK_ARG(nwg < (1ll << 31), "acr_conv3x3_x3: grid too large");
+    hipLaunchKernelGGL(conv3x3_wimg_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
+    if (g.ksplit > 1) {
+        const int64_t n4 = (int64_t)nsamp * cout * g.HW / 4;
+        hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, g.ksplit, n4, y);
+    }
+    return acr_check_launch("acr_conv3x3_x3");
 }

@@ -951,10 +951,18 @@ def conv3x3_fusable(x, weight, stride, math):
             and (x.shape[2] * x.shape[3]) % 16 == 0)
 
 
+CONV3X3_WIMG = os.environ.get("ACR_CONV3X3_WIMG", "1") != "0"      # A/B: 3x3 convolutions with the packed weight as a split-product image
+
+
 def _conv3x3_launch(wp, x, y, N, co, ci, H, W):
+    """y = conv3x3(x) with the packed weight wp (co, 9 ci): through its split-product image (conv3x3_wimg_kernel: only the
+    activation tile is split in registers) unless switched off."""
     lib = L.load()
     nws = lib.acr_conv3x3_ws_floats(N, co, ci, H, W)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+    if CONV3X3_WIMG:
+        L.check(lib.acr_conv3x3_x3(L.ptr(x3_image(wp)), L.ptr(x), L.ptr(y), N, co, ci, H, W, L.ptr(ws), L.stream_ptr()), "acr_conv3x3_x3")
+        return
     L.check(lib.acr_conv3x3_f32(1, L.ptr(wp), L.ptr(x), L.ptr(y), N, co, ci, H, W, L.ptr(ws), L.stream_ptr()), "acr_conv3x3_f32")
 
 

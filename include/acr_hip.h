@@ -287,6 +287,11 @@ int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const float* b_im
 size_t acr_conv3x3_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W);
 int acr_conv3x3_f32(int32_t math, const float* w_packed, const float* x, float* y, int32_t nsamp, int32_t cout, int32_t cin,
                     int32_t H, int32_t W, float* ws, void* stream);
+/* acr_conv3x3_f32 (math = ACR_MATH_BF16X3) with the packed weight given as a split-product image -- w_img = acr_x3_image of w_packed
+ * (rows = cout, cols = 9*cin; for the input gradient of the flipped / role-swapped pack) --: only the activation tile is split in
+ * registers, half the vector work per MFMA.  Same shapes, same ws (acr_conv3x3_ws_floats). */
+int acr_conv3x3_x3(const float* w_img, const float* x, float* y, int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W, float* ws,
+                   void* stream);
 size_t acr_conv3x3_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W);
 int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W,
                           float* ws, float* dw_packed, void* stream);

@@ -55,6 +55,10 @@ for c, S, cnt in three:
     y = torch.empty(N, c, S, S, device=dev)
     ws = torch.empty(lib.acr_conv3x3_wgrad_ws_floats(N, c, c, S, S), device=dev)
     dwp = torch.empty(c, 3, 3, c, device=dev)
+    ops.CONV3X3_WIMG = False
+    f0 = t(lambda: ops._conv3x3_launch(wp, x, y, N, c, c, S, S))
+    ops.CONV3X3_WIMG = True
+    print("     (both operands split in registers: fwd %.1f us)" % f0)
     f = t(lambda: ops._conv3x3_launch(wp, x, y, N, c, c, S, S))
     b = t(lambda: ops._conv3x3_launch(wd, dy, y, N, c, c, S, S))
     g = t(lambda: L.check(lib.acr_conv3x3_wgrad_f32(1, L.ptr(dy), L.ptr(x), N, c, c, S, S, L.ptr(ws), L.ptr(dwp), L.stream_ptr()), "wg3"))

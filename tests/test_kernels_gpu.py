@@ -1039,17 +1039,21 @@ def test_x3_image_planes_sum_to_the_operand_exactly():
     assert float(full[cols:].abs().max()) == 0.0 and float(full[:, rows:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("wimg", [True, False])
 @pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 64, 16, 16), (1, 16, 48, 12, 20), (2, 128, 128, 28, 28), (1, 64, 64, 112, 112),
                                              (3, 32, 160, 20, 36), (2, 256, 256, 28, 28), (2, 256, 256, 24, 24), (2, 256, 256, 48, 48),
                                              (32, 128, 128, 56, 56)])
-def test_conv3x3_split(N, cin, cout, H, W):
+def test_conv3x3_split(N, cin, cout, H, W, wimg, monkeypatch):
     """3x3 stride-1 SAME convolution with split products as an implicit GEMM (csrc/conv3x3.hip): forward, input gradient (same
     kernel, flipped taps) and weight gradient vs fp64 conv2d at the fp32 GEMM tests' tolerance.  Covers cout = 64 (half a tile
     row), pixel tiles that run past H*W and whose rows straddle image rows (W = 20, 28, 36), H != W, 9 cin not a multiple of the
     tile (cin = 16, 32, 64), several pixel parts in the weight gradient (112 x 112), the K-split small launches of CAM generation
-    (two views at 24 x 24 and 48 x 48: 20 / 72 workgroups split 7 ways into slabs), a full-size training launch."""
+    (two views at 24 x 24 and 48 x 48: 20 / 72 workgroups split 7 ways into slabs), a full-size training launch.  wimg: the
+    forward / input-gradient launches take the packed weight as a split-product image (acr_conv3x3_x3, the default) or as fp32
+    (acr_conv3x3_f32: both operands split in registers)."""
     from acr_wsss_amd import ops
     import torch.nn.functional as F
+    monkeypatch.setattr(ops, "CONV3X3_WIMG", wimg)
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(cin + cout + H)
     x = torch.randn(N, cin, H, W, generator=g).to(dev).requires_grad_(True)
@@ -1104,10 +1108,14 @@ def test_conv3x3_reads_nothing_outside_its_input():
     x = x.view(N, C, H, W)
     w = (torch.randn(C, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(dev)
     wp = w.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()
+    from acr_wsss_amd import ops
     y = torch.empty(N, C, H, W, device=dev)
     L.check(lib.acr_conv3x3_f32(1, L.ptr(wp), L.ptr(x), L.ptr(y), N, C, C, H, W, None, L.stream_ptr()), "acr_conv3x3_f32")
     ref = F.conv2d(x.double(), w.double(), padding=1)
     assert (y.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    y2 = torch.empty(N, C, H, W, device=dev)                # the weight-image kernel: the same windows, the same careful path
+    L.check(lib.acr_conv3x3_x3(L.ptr(ops.x3_image(wp)), L.ptr(x), L.ptr(y2), N, C, C, H, W, None, L.stream_ptr()), "acr_conv3x3_x3")
+    assert (y2.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
     # the same block as dy of the input gradient and as x of the weight gradient (dy: another exact-fit block)
     wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * C).contiguous()
     dx = torch.empty(N, C, H, W, device=dev)
