@@ -201,20 +201,21 @@ class ResNetV2(nn.Module):
             key = (x.dtype,) + tuple((c.weight.data_ptr(), c.weight._version) for c in convs)
             if self._frozen is not None and self._frozen[0] == key:
                 return self._frozen[1], self._frozen[2]
-        # One launch per GROUP of convolutions (stem + stages 0-1 | stage 2), not one for all 52: a group's backward launch runs
-        # when ITS last weight gradient has arrived, so the 42 MB of stage-2 weight gradients (backward reaches that stage
-        # first) leave for their all-reduce ~25 ms before backward ends instead of with its very last kernel (dp.GradSync;
-        # profiles/r04_gradsync_timeline.json: the last two buckets became launchable 0.1 ms before the end)
+        # One launch per GROUP of convolutions (stem + stages 0-1 | last stage), not one for all 52 (see forward)
         w_hats, wts = [None] * len(convs), [None] * len(convs)
         for idx in self._wstd_groups(convs):
-            outs = ops.weight_std_all([convs[i].weight for i in idx], convs[0].eps)
-            outs_t = ops.WeightStdAllFn.last_transposed
-            for j, i in enumerate(idx):
-                w_hats[i], wts[i] = outs[j], outs_t[j]
+            self._standardise_group(convs, idx, w_hats, wts)
         if frozen:
             self._frozen = (key, w_hats, wts)
             self.frozen_generation += 1
         return w_hats, wts
+
+    @staticmethod
+    def _standardise_group(convs, idx, w_hats, wts):
+        outs = ops.weight_std_all([convs[i].weight for i in idx], convs[0].eps)
+        outs_t = ops.WeightStdAllFn.last_transposed
+        for j, i in enumerate(idx):
+            w_hats[i], wts[i] = outs[j], outs_t[j]
 
     def _wstd_groups(self, convs):
         """Index lists into ``convs`` (module order): everything up to and including stage 1, and the last stage."""
@@ -244,8 +245,21 @@ class ResNetV2(nn.Module):
             # one HIP launch standardises all 52 conv weights (and one more in backward) instead of ~10 tiny
             # kernels per convolution and direction
             convs = [m for m in self.modules() if isinstance(m, StdConv2dSame)]
+            late = None
             if all(c.weight.dtype == x.dtype for c in convs):
-                w_hats, wts = self._standardised(convs, x)
+                if any(c.weight.requires_grad for c in convs):
+                    # Training: the weight-standardisation launches are autograd nodes, and the engine runs ready nodes in
+                    # reverse order of their CREATION.  One launch for all 52 weights at the top of the forward therefore ran
+                    # its backward as the very last kernel of the step: every gradient bucket holding a conv weight waited for
+                    # it (profiles/r04_gradsync_timeline.json: 86 MB launchable 0.1 ms before backward ended).  Two groups:
+                    # stem + all stages but the last here, the last stage's (42 of the 48 MB) right before that stage runs --
+                    # its backward launch then follows that stage's backward directly, ~25 ms before the step's end.
+                    groups = self._wstd_groups(convs)
+                    w_hats, wts = [None] * len(convs), [None] * len(convs)
+                    self._standardise_group(convs, groups[0], w_hats, wts)
+                    late = groups[1] if len(groups) > 1 else None
+                else:
+                    w_hats, wts = self._standardised(convs, x)
                 for c, w_hat, wt in zip(convs, w_hats, wts):
                     c._w_hat, c._w_hat_t = w_hat, wt
             else:
@@ -253,6 +267,10 @@ class ResNetV2(nn.Module):
         try:
             x = self.stem(x)
             for i, st in enumerate(self.stages):
+                if convs is not None and late is not None and i == len(self.stages) - 1:
+                    self._standardise_group(convs, late, w_hats, wts)
+                    for j in late:
+                        convs[j]._w_hat, convs[j]._w_hat_t = w_hats[j], wts[j]
                 x = st(x)
                 if taps is not None and i < 2:
                     taps[str(i + 1)] = x           # DPT/vit.py:426-431 forward hooks "1", "2"
@@ -654,10 +672,13 @@ class VisionTransformer(nn.Module):
     def embed_tokens(self, x, taps=None):
         """Stem (hybrid) or patch convolution, class/distillation tokens, position embedding: (B,3,h,w) -> ((B,T,D), stem features)."""
         b, c, h, w = x.shape
-        pos = self._resize_pos_embed(self.pos_embed, h // self.patch_size[1], w // self.patch_size[0])
         if isinstance(self.patch_embed, HybridEmbed):
             x = self.patch_embed.backbone(x, taps)
         res_features = x
+        # (after the stem on purpose: the autograd engine runs ready nodes in reverse order of their creation -- resized before
+        # the stem, the position embedding's gradient was the LAST one of the whole backward to arrive and held its 17 MB
+        # gradient bucket until the step's end, scripts/lab/grad_arrival_order.py)
+        pos = self._resize_pos_embed(self.pos_embed, h // self.patch_size[1], w // self.patch_size[0])
         pe = self.patch_embed.proj
         if (isinstance(self.patch_embed, HybridEmbed) and StdConv2dSame.hip_1x1 and pe.bias is not None
                 and ops.conv1x1_fusable(x, pe.weight, pe.stride[0])):

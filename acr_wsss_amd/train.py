@@ -304,6 +304,8 @@ def refresh_weight_transposes(model):
     own set."""
     from . import ops as _ops
     _ops.invalidate_weight_images(model)                  # split-product images are keyed like the transposes: same blind spot for .data writes
+    if getattr(model, "math", "f32") == "f32_split" and _ops.X3_IMAGES:
+        return                                            # split products multiply by the IMAGE of W^T (ops.weight_image): no fp32 copies to keep
     wt = getattr(model, "_acr_wt_f32", None)
     if wt is None:
         p0 = next(model.parameters(), None)

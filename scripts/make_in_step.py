@@ -22,7 +22,8 @@ GROUPS = {
                   "acr_x3_image": ["planes_tile_kernel", "planes_tile_t_kernel", "planes_colsum_kernel"],
                   "acr_attn_bwd": ["attn_delta_sres_kernel", "attn_bwd_x3_kernel"],
                   "acr_attn_fwd": ["attn_fwd_x3_kernel", "attn_pmean_sres_kernel"],
-                  "acr_conv_stem": ["gemm_f32_split_kernel", "conv3x3_"],
+                  "acr_conv_stem": ["gemm_f32_split_kernel", "gemm_f32_wimg_kernel", "conv3x3_", "conv1x1_ksum"],
+                  "acr_groupnorm": ["gnf_"],
                   "acr_consistency_fwd": ["cons_fwd", "cons_reduce"]},
     "bf16": {"acr_wgrad_bf16": ["gemm_tn_bf16", "wgrad_reduce"],
              "acr_linear_bf16": ["gemm_nt_bf16_wide_kernel<true", "gemm_nt_bf16_dma_kernel<true"],
