@@ -85,6 +85,7 @@ SIGNATURES = {
     "acr_conv1x1_wgrad_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "acr_conv3x3_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "acr_conv3x3_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "acr_x3_image_many": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "acr_conv3x3_x3": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "acr_conv3x3_wgrad_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "acr_conv3x3_wgrad_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,

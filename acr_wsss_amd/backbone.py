@@ -76,11 +76,11 @@ class StdConv2dSame(nn.Conv2d):
             # them as layout transposes + a Tensile GEMM; autograd's slice backward scatters the input gradient back
             xs = x[:, :, ::2, ::2].contiguous()
             if ops.conv1x1_fusable(xs, w_hat, 1):
-                return ops.conv1x1(xs, w_hat, self._w_hat_t, self.acr_math)
+                return ops.conv1x1(xs, w_hat, self._w_hat_t, self.acr_math, self._w_imgs)
         if self.hip_1x1 and ops.conv1x1_fusable(x, w_hat, self.stride[0]):
-            return ops.conv1x1(x, w_hat, self._w_hat_t, self.acr_math)     # NCHW 1x1 conv = per-sample MFMA GEMM, no layout transposes
+            return ops.conv1x1(x, w_hat, self._w_hat_t, self.acr_math, self._w_imgs)   # NCHW 1x1 conv = per-sample MFMA GEMM, no layout transposes
         if self.hip_3x3 and not self.dynamic_pad and ops.conv3x3_fusable(x, w_hat, self.stride[0], self.acr_math):
-            return ops.conv3x3(x, w_hat)                                   # split-product implicit GEMM, no layout transposes
+            return ops.conv3x3(x, w_hat, self._w_imgs)                     # split-product implicit GEMM, no layout transposes
         return F.conv2d(x, w_hat, None, self.stride, self.padding)
 
     def forward_skip(self, x):
@@ -88,7 +88,7 @@ class StdConv2dSame(nn.Conv2d):
         gradient is then added inside the input-gradient GEMM."""
         w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
         if self.hip_1x1 and x.requires_grad and ops.conv1x1_fusable(x, w_hat, self.stride[0]):
-            return ops.conv1x1_skip(x, w_hat, self._w_hat_t, self.acr_math)
+            return ops.conv1x1_skip(x, w_hat, self._w_hat_t, self.acr_math, self._w_imgs)
         return self.forward(x), x
 
     hip_1x1 = True
@@ -98,6 +98,23 @@ class StdConv2dSame(nn.Conv2d):
 
     _w_hat = None           # set for one forward by ResNetV2 when all weights are standardised in one fused launch
     _w_hat_t = None         # bf16 1x1 convolutions: its (cin, cout) copy, written by the same launch
+    _w_imgs = None          # split products: (image for the forward, image for the input gradient) of _w_hat, made by ResNetV2 for
+                            # all convolutions of a group in ONE launch (ops.x3_image_many)
+
+    def image_specs(self, w_hat):
+        """The two strided views of the standardised weight whose split-product images this convolution's forward and input
+        gradient multiply by (ops.x3_image_many) -- or None when it does not run on the image kernels."""
+        if self.acr_math != 1 or w_hat.dtype != torch.float32 or not w_hat.is_cuda:
+            return None
+        co, ci, k, _ = w_hat.shape
+        if k == 1 and self.hip_1x1 and ops.CONV1X1_WIMG and ops.F32_HIP_CONV1X1 and ci % 32 == 0 and co % 32 == 0 and (
+                self.stride[0] == 1 or (self.stride[0] == 2 and self.hip_1x1_strided)):
+            return ((w_hat, 0, co, ci, ci, ci, 0, 1),               # W (co x ci)
+                    (w_hat, 0, ci, co, 1, co, 0, ci))               # W^T (ci x co): the input gradient's operand
+        if k == 3 and self.stride[0] == 1 and not self.dynamic_pad and self.hip_3x3 and ops.CONV3X3_WIMG and ci % 16 == 0 and co % 16 == 0:
+            return ((w_hat, 0, co, 9 * ci, 9 * ci, ci, 1, 9),        # packed w[co][t * ci + c]
+                    (w_hat, 8, ci, 9 * co, 9, co, -1, 9 * ci))       # input-gradient pack w[o][c][8 - t'] as (ci x 9 co)
+        return None
 
 
 class GroupNormAct(nn.GroupNorm):
@@ -198,24 +215,38 @@ class ResNetV2(nn.Module):
         (CAM generation: requires_grad off) they are kept until a weight changes (tensor version or storage)."""
         frozen = not any(c.weight.requires_grad for c in convs)
         if frozen:
-            key = (x.dtype,) + tuple((c.weight.data_ptr(), c.weight._version) for c in convs)
+            key = (x.dtype,) + tuple((c.weight.data_ptr(), c.weight._version, c.acr_math) for c in convs)
             if self._frozen is not None and self._frozen[0] == key:
-                return self._frozen[1], self._frozen[2]
+                return self._frozen[1], self._frozen[2], self._frozen[3]
         # One launch per GROUP of convolutions (stem + stages 0-1 | last stage), not one for all 52 (see forward)
-        w_hats, wts = [None] * len(convs), [None] * len(convs)
+        w_hats, wts, imgs = [None] * len(convs), [None] * len(convs), [None] * len(convs)
         for idx in self._wstd_groups(convs):
-            self._standardise_group(convs, idx, w_hats, wts)
+            self._standardise_group(convs, idx, w_hats, wts, imgs)
         if frozen:
-            self._frozen = (key, w_hats, wts)
+            self._frozen = (key, w_hats, wts, imgs)
             self.frozen_generation += 1
-        return w_hats, wts
+        return w_hats, wts, imgs
 
     @staticmethod
-    def _standardise_group(convs, idx, w_hats, wts):
+    def _standardise_group(convs, idx, w_hats, wts, imgs=None):
         outs = ops.weight_std_all([convs[i].weight for i in idx], convs[0].eps)
         outs_t = ops.WeightStdAllFn.last_transposed
         for j, i in enumerate(idx):
             w_hats[i], wts[i] = outs[j], outs_t[j]
+        if imgs is not None:
+            # split products: the images of the group's standardised weights -- for the forward AND for the input gradient -- in
+            # ONE launch (they were ~130 launches of a few microseconds per step: an image pass and, for the 3x3 weights, a
+            # permute copy per convolution and direction)
+            specs, owners = [], []
+            for i in idx:
+                sp = convs[i].image_specs(w_hats[i].detach())
+                if sp is not None:
+                    specs += list(sp)
+                    owners.append(i)
+            if specs:
+                made = ops.x3_image_many(specs, w_hats[idx[0]].device)
+                for n, i in enumerate(owners):
+                    imgs[i] = (made[2 * n], made[2 * n + 1])
 
     def _wstd_groups(self, convs):
         """Index lists into ``convs`` (module order): everything up to and including stage 1, and the last stage."""
@@ -255,29 +286,29 @@ class ResNetV2(nn.Module):
                     # stem + all stages but the last here, the last stage's (42 of the 48 MB) right before that stage runs --
                     # its backward launch then follows that stage's backward directly, ~25 ms before the step's end.
                     groups = self._wstd_groups(convs)
-                    w_hats, wts = [None] * len(convs), [None] * len(convs)
-                    self._standardise_group(convs, groups[0], w_hats, wts)
+                    w_hats, wts, imgs = [None] * len(convs), [None] * len(convs), [None] * len(convs)
+                    self._standardise_group(convs, groups[0], w_hats, wts, imgs)
                     late = groups[1] if len(groups) > 1 else None
                 else:
-                    w_hats, wts = self._standardised(convs, x)
-                for c, w_hat, wt in zip(convs, w_hats, wts):
-                    c._w_hat, c._w_hat_t = w_hat, wt
+                    w_hats, wts, imgs = self._standardised(convs, x)
+                for c, w_hat, wt, im in zip(convs, w_hats, wts, imgs):
+                    c._w_hat, c._w_hat_t, c._w_imgs = w_hat, wt, im
             else:
                 convs = None
         try:
             x = self.stem(x)
             for i, st in enumerate(self.stages):
                 if convs is not None and late is not None and i == len(self.stages) - 1:
-                    self._standardise_group(convs, late, w_hats, wts)
+                    self._standardise_group(convs, late, w_hats, wts, imgs)
                     for j in late:
-                        convs[j]._w_hat, convs[j]._w_hat_t = w_hats[j], wts[j]
+                        convs[j]._w_hat, convs[j]._w_hat_t, convs[j]._w_imgs = w_hats[j], wts[j], imgs[j]
                 x = st(x)
                 if taps is not None and i < 2:
                     taps[str(i + 1)] = x           # DPT/vit.py:426-431 forward hooks "1", "2"
         finally:
             if convs is not None:
                 for c in convs:
-                    c._w_hat = c._w_hat_t = None
+                    c._w_hat = c._w_hat_t = c._w_imgs = None
         return x
 
 

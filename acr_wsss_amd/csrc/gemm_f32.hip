@@ -1345,6 +1345,55 @@ __global__ __launch_bounds__(256) void planes_tile_t_kernel(const float* __restr
     *reinterpret_cast<bf16x8*>(d1) = p0; *reinterpret_cast<bf16x8*>(d1 + P_TILE_B) = p1; *reinterpret_cast<bf16x8*>(d1 + 2 * P_TILE_B) = p2;
 }
 
+// MANY small images in one launch (round 5): the stem's 52 standardised convolution weights need up to two images each per step
+// (W for the forward, W^T resp. the flipped / role-swapped pack for the input gradient) -- as ~130 launches of a few microseconds
+// (planes_tile / planes_tile_t plus the permute copies that packed the 3x3 weights) they cost more than the passes move.  Every
+// image is described by a strided view of its source: element (r, k) of the rows x K operand is
+//     src[r * sr + (k / kin) * sko + (k % kin) * ski]            (kin % 8 == 0: a chunk of 8 k never straddles an outer index)
+// which covers W (co x ci: sr = ci, kin = K, ski = 1), W^T (sr = 1, ski = ci), the packed 3x3 weight w[co][t * ci + c] of
+// w (co, ci, 3, 3) (sr = 9 ci, kin = ci, sko = 1, ski = 9) and its input-gradient pack w[o][c][8 - t'] as (ci x 9 co)
+// (src + 8, sr = 9, kin = co, sko = -1, ski = 9 ci).  Workgroup = (image, row block, 64 k) as in planes_tile_kernel; `blk` maps a
+// workgroup to its image.  Reads are strided (the weights are a few MB: L2-resident), writes are the image's contiguous chunks.
+struct X3ManyDesc {
+    const float* src;
+    char* dst;
+    int32_t rows, K, sr, kin, sko, ski, wg0, nkb;
+};
+__global__ __launch_bounds__(256) void planes_tile_many_kernel(const X3ManyDesc* __restrict__ descs, const int32_t* __restrict__ blk) {
+    const X3ManyDesc d = descs[blk[blockIdx.x]];
+    const int local = (int)blockIdx.x - d.wg0;
+    const int kq = (d.nkb + 3) >> 2;
+    const int rb = local / kq, k0 = (local - rb * kq) << 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = j * 256 + threadIdx.x, rr = c >> 3, k8 = c & 7;
+        const int row = rb * 128 + rr, k = k0 + k8 * 8;
+        if (k >= d.nkb * P_BK) continue;
+        float v[8];
+        if (row < d.rows && k < d.K) {                      // K % 8 == 0 (host): the chunk is whole
+            const int outer = k / d.kin, inner = k - outer * d.kin;
+            const float* sp = d.src + (int64_t)row * d.sr + (int64_t)outer * d.sko + (int64_t)inner * d.ski;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = sp[(int64_t)e * d.ski];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        bf16x8 p0, p1, p2;
+        planes_split8(v, p0, p1, p2);
+        char* dst = d.dst + ((int64_t)rb * d.nkb + (k >> 4)) * (3 * P_TILE_B) + planes_chunk_off(rr, k8 & 1);
+        *reinterpret_cast<bf16x8*>(dst) = p0;
+        *reinterpret_cast<bf16x8*>(dst + P_TILE_B) = p1;
+        *reinterpret_cast<bf16x8*>(dst + 2 * P_TILE_B) = p2;
+    }
+}
+extern "C" int acr_x3_image_many(const void* descs, const int32_t* blk, int32_t nwg, void* stream) {
+    ACR_CHECK_ARG(descs && blk && nwg > 0, "acr_x3_image_many: null table or empty launch");
+    ACR_CHECK_ARG(((uintptr_t)descs & 7) == 0 && ((uintptr_t)blk & 3) == 0, "acr_x3_image_many: table alignment");
+    hipLaunchKernelGGL(planes_tile_many_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, (const X3ManyDesc*)descs, blk);
+    return acr_check_launch("acr_x3_image_many");
+}
+
 // out[i] = sum_s slab[s][i] in split order (deterministic), float4 per thread; n4 = elements / 4
 __global__ __launch_bounds__(256) void gemm_f32_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t n4,
                                                               float* __restrict__ out) {

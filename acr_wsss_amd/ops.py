@@ -568,6 +568,36 @@ def x3_image_t(x2):
     return img
 
 
+def x3_image_many(specs, device):
+    """Split-product images of MANY small operands in one launch (acr_x3_image_many): ``specs`` is a list of
+    (src tensor, element offset, rows, K, sr, kin, sko, ski) -- element (r, k) of the rows x K operand is
+    src[offset + r*sr + (k // kin)*sko + (k % kin)*ski] (include/acr_hip.h).  Returns the images, views of ONE buffer."""
+    import numpy as np
+    lib = L.load()
+    sizes = [int(lib.acr_x3_image_floats(rows, K)) for (_, _, rows, K, _, _, _, _) in specs]
+    buf = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    rec = np.zeros(len(specs), dtype=[("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("K", "<i4"), ("sr", "<i4"), ("kin", "<i4"),
+                                      ("sko", "<i4"), ("ski", "<i4"), ("wg0", "<i4"), ("nkb", "<i4")])
+    blk, wg0, off, imgs = [], 0, 0, []
+    for i, ((src, eoff, rows, K, sr, kin, sko, ski), n) in enumerate(zip(specs, sizes)):
+        assert src.dtype == torch.float32 and K % 8 == 0 and kin % 8 == 0, (K, kin)
+        nkb = (K + 15) // 16
+        nwg = ((rows + 127) // 128) * ((nkb + 3) // 4)
+        rec[i] = (src.data_ptr() + 4 * eoff, buf.data_ptr() + 4 * off, rows, K, sr, kin, sko, ski, wg0, nkb)
+        blk.append(np.full(nwg, i, dtype=np.int32))
+        imgs.append(buf[off:off + n])
+        wg0 += nwg
+        off += n
+    raw = np.concatenate([rec.view(np.uint8), np.concatenate(blk).view(np.uint8)])
+    host = torch.empty(raw.size, dtype=torch.uint8, pin_memory=True)          # pinned + asynchronous: no host-side stream drain
+    host.numpy()[:] = raw
+    table = host.to(device, non_blocking=True)
+    nb = rec.nbytes
+    L.check(lib.acr_x3_image_many(L.ptr(table), L.c_void_p(table.data_ptr() + nb), wg0, L.stream_ptr()), "acr_x3_image_many")
+    buf._acr_keep = table                                   # the launch reads the table asynchronously: keep it with the images
+    return imgs
+
+
 def weight_image(weight, owner=None, transposed=False):
     """Image of a Linear's weight (``transposed``: of W^T, what the input gradient multiplies by), cached on ``owner`` (the
     nn.Linear) per weight version: inference makes each image once, a training step once per forward resp. backward (the
@@ -868,13 +898,14 @@ def conv1x1_fusable(x, weight, stride):
 CONV1X1_WIMG = os.environ.get("ACR_CONV1X1_WIMG", "1") != "0"      # A/B: split-product 1x1 convolutions with the weight as an image
 
 
-def _conv1x1_f32_launch(math, w2, w_transposed, x, addend, y, N, co, ci, hw):
-    """y[n] (co x hw) = W . x[n] (+ addend).  w_transposed = 0: w2 is (co, ci); 1: w2 is the forward's (ci, co) weight (input gradient)."""
+def _conv1x1_f32_launch(math, w2, w_transposed, x, addend, y, N, co, ci, hw, img=None):
+    """y[n] (co x hw) = W . x[n] (+ addend).  w_transposed = 0: w2 is (co, ci); 1: w2 is the forward's (ci, co) weight (input gradient).
+    ``img``: the weight's split-product image when the caller has it already (the stem makes all of them in one launch)."""
     lib = L.load()
     nws = lib.acr_conv1x1_ws_floats(math, N, co, ci, hw)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
     if math == 1 and CONV1X1_WIMG and ci % 32 == 0:
-        wi = x3_image_t(w2) if w_transposed else x3_image(w2)
+        wi = img if img is not None else (x3_image_t(w2) if w_transposed else x3_image(w2))
         L.check(lib.acr_conv1x1_x3(L.ptr(wi), L.ptr(x), L.ptr(addend), L.ptr(y), N, co, ci, hw, L.ptr(ws), L.stream_ptr()), "acr_conv1x1_x3")
         return
     L.check(lib.acr_conv1x1_f32(math, L.ptr(w2), w_transposed, L.ptr(x), L.ptr(addend), L.ptr(y), N, co, ci, hw, L.ptr(ws), L.stream_ptr()),
@@ -888,15 +919,16 @@ class Conv1x1Fn(Function):
     the shortcut is added in the epilogue of the input-gradient GEMM (no separate accumulation pass)."""
 
     @staticmethod
-    def forward(ctx, x, weight, wt=None, math=0):
+    def forward(ctx, x, weight, wt=None, math=0, imgs=None):
         ctx.wt, ctx.math = wt, math                          # wt: (cin, cout) copy of the weight, or None
+        ctx.imgs = imgs                                      # (image of W, image of W^T) under split products, or None
         N, C, H, W = x.shape
         co = weight.shape[0]
         w2 = weight.reshape(co, C)
         y = torch.empty((N, co, H, W), dtype=x.dtype, device=x.device)
         if x.dtype == torch.float32:
             w2 = w2.contiguous()
-            _conv1x1_f32_launch(math, w2, 0, x, None, y, N, co, C, H * W)
+            _conv1x1_f32_launch(math, w2, 0, x, None, y, N, co, C, H * W, imgs[0] if imgs else None)
         else:
             L.check(L.load().acr_conv1x1_bf16(L.ptr(w2), w2.stride(0), L.ptr(x), None, L.ptr(y), N, co, C, H * W, L.stream_ptr()),
                     "acr_conv1x1_bf16")
@@ -911,7 +943,7 @@ class Conv1x1Fn(Function):
         co = weight.shape[0]
         lib = L.load()
         if dy is None:
-            return dskip, None, None, None
+            return dskip, None, None, None, None
         if not dy.is_contiguous():
             dy = dy.contiguous()
         if dskip is not None and (not dskip.is_contiguous() or dskip.dtype != x.dtype):
@@ -923,13 +955,13 @@ class Conv1x1Fn(Function):
             if ctx.needs_input_grad[0]:
                 w2 = weight.reshape(co, C).contiguous()
                 dx = torch.empty_like(x)
-                _conv1x1_f32_launch(ctx.math, w2, 1, dy, dskip, dx, N, C, co, H * W)
+                _conv1x1_f32_launch(ctx.math, w2, 1, dy, dskip, dx, N, C, co, H * W, ctx.imgs[1] if ctx.imgs else None)
             if ctx.needs_input_grad[1]:
                 ws = torch.empty(lib.acr_conv1x1_wgrad_f32_ws_floats(N, co, C, H * W), dtype=torch.float32, device=x.device)
                 dw = torch.empty((co, C, 1, 1), dtype=torch.float32, device=x.device)
                 L.check(lib.acr_conv1x1_wgrad_f32(ctx.math, L.ptr(dy), L.ptr(x), N, co, C, H * W, L.ptr(ws), L.ptr(dw), L.stream_ptr()),
                         "acr_conv1x1_wgrad_f32")
-            return dx, dw, None, None
+            return dx, dw, None, None, None
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if ctx.wt is not None else weight.reshape(co, C).t().contiguous()     # (cin, cout): dX = W^T . dY
             dx = torch.empty_like(x)
@@ -940,7 +972,7 @@ class Conv1x1Fn(Function):
             dw = torch.empty((co, C, 1, 1), dtype=weight.dtype, device=x.device)
             L.check(lib.acr_conv1x1_wgrad_bf16(L.ptr(dy), L.ptr(x), N, co, C, H * W, L.ptr(ws), L.ptr(dw), L.stream_ptr()),
                     "acr_conv1x1_wgrad_bf16")
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 def conv3x3_fusable(x, weight, stride, math):
@@ -954,15 +986,19 @@ def conv3x3_fusable(x, weight, stride, math):
 CONV3X3_WIMG = os.environ.get("ACR_CONV3X3_WIMG", "1") != "0"      # A/B: 3x3 convolutions with the packed weight as a split-product image
 
 
-def _conv3x3_launch(wp, x, y, N, co, ci, H, W):
-    """y = conv3x3(x) with the packed weight wp (co, 9 ci): through its split-product image (conv3x3_wimg_kernel: only the
-    activation tile is split in registers) unless switched off."""
+def _conv3x3_launch(wp, x, y, N, co, ci, H, W, img=None):
+    """y = conv3x3(x) with the packed weight wp (co, 9 ci) -- a callable that packs it on demand --: through its split-product image
+    (conv3x3_wimg_kernel: only the activation tile is split in registers; ``img`` when the caller has it already) unless
+    switched off."""
     lib = L.load()
     nws = lib.acr_conv3x3_ws_floats(N, co, ci, H, W)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
     if CONV3X3_WIMG:
-        L.check(lib.acr_conv3x3_x3(L.ptr(x3_image(wp)), L.ptr(x), L.ptr(y), N, co, ci, H, W, L.ptr(ws), L.stream_ptr()), "acr_conv3x3_x3")
+        wi = img if img is not None else x3_image(wp() if callable(wp) else wp)
+        L.check(lib.acr_conv3x3_x3(L.ptr(wi), L.ptr(x), L.ptr(y), N, co, ci, H, W, L.ptr(ws), L.stream_ptr()), "acr_conv3x3_x3")
         return
+    if callable(wp):
+        wp = wp()
     L.check(lib.acr_conv3x3_f32(1, L.ptr(wp), L.ptr(x), L.ptr(y), N, co, ci, H, W, L.ptr(ws), L.stream_ptr()), "acr_conv3x3_f32")
 
 
@@ -971,13 +1007,13 @@ class Conv3x3Fn(Function):
     gradient (the same kernel on dy with the taps flipped and the channel roles swapped) and weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, imgs=None):
         N, C, H, W = x.shape
         co = weight.shape[0]
-        wp = weight.permute(0, 2, 3, 1).reshape(co, 9 * C).contiguous()
         y = torch.empty((N, co, H, W), dtype=torch.float32, device=x.device)
-        _conv3x3_launch(wp, x, y, N, co, C, H, W)
+        _conv3x3_launch(lambda: weight.permute(0, 2, 3, 1).reshape(co, 9 * C).contiguous(), x, y, N, co, C, H, W, imgs[0] if imgs else None)
         ctx.save_for_backward(x, weight)
+        ctx.imgs = imgs                                      # (image of the packed weight, image of its input-gradient pack) or None
         return y
 
     @staticmethod
@@ -989,31 +1025,32 @@ class Conv3x3Fn(Function):
         dy = (dy if dy.dtype == torch.float32 else dy.float()).contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wd = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * co).contiguous()
             dx = torch.empty_like(x)
-            _conv3x3_launch(wd, dy, dx, N, C, co, H, W)
+            _conv3x3_launch(lambda: weight.flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * co).contiguous(), dy, dx, N, C, co, H, W,
+                            ctx.imgs[1] if ctx.imgs else None)
         if ctx.needs_input_grad[1]:
             ws = torch.empty(lib.acr_conv3x3_wgrad_ws_floats(N, co, C, H, W), dtype=torch.float32, device=x.device)
             dwp = torch.empty((co, 3, 3, C), dtype=torch.float32, device=x.device)
             L.check(lib.acr_conv3x3_wgrad_f32(1, L.ptr(dy), L.ptr(x), N, co, C, H, W, L.ptr(ws), L.ptr(dwp), L.stream_ptr()),
                     "acr_conv3x3_wgrad_f32")
             dw = dwp.permute(0, 3, 1, 2)
-        return dx, dw
+        return dx, dw, None
 
 
-def conv3x3(x, weight):
-    return Conv3x3Fn.apply(x, weight)
+def conv3x3(x, weight, imgs=None):
+    return Conv3x3Fn.apply(x, weight, imgs)
 
 
-def conv1x1(x, weight, wt=None, math=0):
-    return Conv1x1Fn.apply(x, weight, wt, math)[0]
+def conv1x1(x, weight, wt=None, math=0, imgs=None):
+    return Conv1x1Fn.apply(x, weight, wt, math, imgs)[0]
 
 
-def conv1x1_skip(x, weight, wt=None, math=0):
-    """(conv(x), x_skip): see Conv1x1Fn.  ``wt``: the (cin, cout) copy of the weight when the caller already has one."""
+def conv1x1_skip(x, weight, wt=None, math=0, imgs=None):
+    """(conv(x), x_skip): see Conv1x1Fn.  ``wt``: the (cin, cout) copy of the weight when the caller already has one; ``imgs``:
+    its split-product images (W, W^T) likewise."""
     if not SKIP_FUSION:
-        return Conv1x1Fn.apply(x, weight, wt, math)[0], x
-    return Conv1x1Fn.apply(x, weight, wt, math)
+        return Conv1x1Fn.apply(x, weight, wt, math, imgs)[0], x
+    return Conv1x1Fn.apply(x, weight, wt, math, imgs)
 
 
 class LayerNormFn(Function):

@@ -269,6 +269,12 @@ size_t acr_x3_colsum_ws_floats(int32_t rows, int32_t cols);
 int acr_x3_image(const float* x, int64_t ld, int32_t rows, int32_t cols, float* image, float* colsum, float* colsum_ws, void* stream);
 int acr_x3_image_t(const float* x, int64_t ld, int32_t rows, int32_t cols, float* image, void* stream);
 size_t acr_gemm_x3_ws_floats(int32_t mode, int32_t act, int32_t M, int32_t N, int32_t K);
+/* Many small images in ONE launch (the stem's standardised convolution weights: W, W^T and the packed 3x3 forms).  `descs`: device
+ * array of 48-byte records {const float* src; void* dst; int32 rows, K, sr, kin, sko, ski, wg0, nkb}: image `dst`
+ * (acr_x3_image_floats(rows, K) floats) of the rows x K operand whose element (r, k) is src[r*sr + (k/kin)*sko + (k%kin)*ski]
+ * (K, kin multiples of 8; nkb = ceil(K / 16)); record i owns workgroups wg0 .. wg0 + ceil(rows/128) * ceil(nkb/4) - 1 and `blk`
+ * (device, nwg int32) maps every workgroup to its record. */
+int acr_x3_image_many(const void* descs, const int32_t* blk, int32_t nwg, void* stream);
 int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const float* b_img, const float* bias, const float* aux, int64_t ldaux, float* c,
                 int64_t ldc, float* c2, float* colsum, int32_t M, int32_t N, int32_t K, float* ws, void* stream);
 

@@ -11,3 +11,5 @@ for dt in ${2:-f32_split f32 bf16}; do
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$ROOT/gpurun_out/${tag}_pmcW_${dt}" -o p -- python3 "$ROOT/bench.py" --probe-only --dtype $dt > /dev/null 2>&1
   echo "pmc $dt done"
 done
+# the judged summaries: built on the box (the traces are too large to travel), copied where gpurun merges them back from
+cd "$ROOT" && python scripts/make_in_step.py gpurun_out "$tag" && mkdir -p "gpurun_out/profiles_$tag" && cp profiles/${tag}_* "gpurun_out/profiles_$tag/" && for dt in ${2:-f32_split f32 bf16}; do rm -rf "gpurun_out/${tag}_${dt}" "gpurun_out/${tag}_pmcF_${dt}" "gpurun_out/${tag}_pmcW_${dt}"; done
