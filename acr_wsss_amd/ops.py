@@ -623,6 +623,31 @@ def weight_image(weight, owner=None, transposed=False):
     return img
 
 
+def prebuild_weight_images(linears):
+    """The images of W and of W^T of every given nn.Linear in ONE launch (ops.x3_image_many), stored in the per-owner caches
+    weight_image() reads -- a training step calls this once after the optimizer step instead of paying 8 small image launches per
+    block when the forward / backward first ask for them (train.refresh_weight_transposes)."""
+    lins = [m for m in linears if m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()
+            and m.weight.shape[0] % 8 == 0 and m.weight.shape[1] % 8 == 0]
+    if not lins:
+        return 0
+    specs = []
+    for m in lins:
+        n, k = m.weight.shape
+        w = m.weight.detach()
+        specs.append((w, 0, n, k, k, k, 0, 1))              # W (out x in): the forward's B operand
+        specs.append((w, 0, k, n, 1, n, 0, k))              # W^T (in x out): the input gradient's
+    dev = lins[0].weight.device
+    imgs = x3_image_many(specs, dev)
+    cur = torch.cuda.current_stream(dev)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    for i, m in enumerate(lins):
+        m._acr_x3_w_img = (m.weight._version, m.weight.data_ptr(), imgs[2 * i], cur, ev)
+        m._acr_x3_wt_img = (m.weight._version, m.weight.data_ptr(), imgs[2 * i + 1], cur, ev)
+    return len(lins)
+
+
 def invalidate_weight_images(model):
     """Drop every cached split-product weight image under ``model`` (after a weight was written through ``.data``, which moves
     neither the version counter nor the address the cache is keyed on)."""
