@@ -310,8 +310,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wimg_kernel(const Conv3Args g)
         constexpr bool FIRST = decltype(first_tag)::value;
         // stage st has landed when at most the 5 pieces of stage st + 1 are outstanding; the careful edge path may have issued
         // more (younger) operations: a count that is too high only makes this wait stricter
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        __syncthreads();                                    // (the edge path publishes plain LDS stores: keep the fence)
+        asm volatile("s_waitcnt vmcnt(5)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");    // (lgkmcnt: the edge path's plain LDS stores)
+        acr_barrier_nofence();                              // __syncthreads()'s fence would drain the stages in flight (vmcnt(0))
         const int rslot = slot == 0 ? 2 : slot - 1;         // (st + 2) % 3
         issue(min(st + 2, nst - 1), rslot);                 // past the end: the last stage again, into a slot nobody reads
         if (!compute) return;
