@@ -380,6 +380,150 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wimg_kernel(const Conv3Args g)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The same kernel for at most 64 output channels (stage 0 of the stem, and CAM generation's large maps): a 128-row tile would
+// leave the lower wave row without outputs (two of four waves only feed the DMA), so the tile is 64 rows x 256 PIXELS and all four
+// waves compute 64 x 64 on their own 64 pixels; the A stage is the upper half of the image's 128-row block (3 planes x 2 KiB).
+// Ring: 3 slots x [A 6 KiB | B fp32 16 KiB]; per wave and stage 2 A pieces (wave 3 re-fetches pieces 4, 5: identical bytes to
+// the same place -- keeps the count uniform) + 4 B pieces (one channel row of 256 pixels each) = 6.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define C3N_BN 256
+#define C3N_A_B (3 * 2048)
+#define C3N_STAGE_B (C3N_A_B + C3_BK * C3N_BN * 4)          // 22 KiB
+__global__ __launch_bounds__(256, 2) void conv3x3_wimg64_kernel(const Conv3Args g) {
+    __shared__ __attribute__((aligned(1024))) char smem[C3W_SLOTS * C3N_STAGE_B];       // 66 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, wn = wave;
+    const int ntile = g.tiles_n;                            // one tile row
+    const int t1 = acr_xcd_remap(blockIdx.x, ntile * g.nsamp * g.ksplit);
+    const int part = t1 / (ntile * g.nsamp), t0 = t1 - part * (ntile * g.nsamp);
+    const int sample = t0 / ntile, tn = t0 - sample * ntile;
+    const int sbeg = part * g.sps;
+    const int n0 = tn * C3N_BN;
+    const int nkb = 9 * g.C / C3_BK;
+    const int qa = wave < 3 ? 2 * wave : 4;                 // this wave's two A pieces: qa, qa + 1 (plane q >> 1, KiB q & 1 of its upper half)
+    const char* __restrict__ pa = reinterpret_cast<const char*>(g.w) + (int64_t)sbeg * (3 * C3W_PLANE_B) + lane * 16;
+    const float* __restrict__ pb = g.x + (int64_t)sample * g.C * g.HW;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int pix = n0 + 4 * lane;
+    const int valid0 = c3_valid9(n0 + wn * 64 + r, g.H, g.W, g.HW), valid1 = c3_valid9(n0 + wn * 64 + 32 + r, g.H, g.W, g.HW);
+    const int nst = min(nkb - sbeg, g.sps);
+    const int64_t total = (int64_t)g.nsamp * g.C * g.HW;
+    const bool edge = (sample == 0 && n0 < g.W + 1) || (sample == g.nsamp - 1 && n0 + C3N_BN + g.W + 1 > g.HW);
+    auto issue = [&](int st, int slot) {
+        char* d = smem + slot * C3N_STAGE_B;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = qa + i;
+            __builtin_amdgcn_global_load_lds((c3_glb_vp)(pa + (int64_t)st * (3 * C3W_PLANE_B) + (q >> 1) * C3W_PLANE_B + (q & 1) * 1024),
+                                             (c3_lds_vp)(d + q * 1024), 16, 0, 0);
+        }
+        const int k0 = (sbeg + st) * C3_BK;
+        const int tap = k0 / g.C, ci0 = k0 - tap * g.C;
+        const int ty = tap / 3, off = (ty - 1) * g.W + (tap - 3 * ty - 1);
+        float* db = reinterpret_cast<float*>(d + C3N_A_B);
+        if (edge) {
+            const int64_t i0 = (int64_t)sample * g.C * g.HW + (int64_t)ci0 * g.HW + (pix + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c3_dma_careful(g.x, i0 + (int64_t)(4 * wave + i) * g.HW, total, db + (4 * wave + i) * C3N_BN, lane);
+            return;
+        }
+        const float* xb = pb + (int64_t)ci0 * g.HW + (pix + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((c3_glb_vp)(xb + (int64_t)(4 * wave + i) * g.HW), (c3_lds_vp)(db + (4 * wave + i) * C3N_BN), 16, 0, 0);
+    };
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    const uint32_t fa = lbase + r * 32 + (h ^ ((r >> 3) & 1)) * 16;
+    const uint32_t fb = lbase + C3N_A_B + ((8 * h) * C3N_BN + wn * 64 + r) * 4;
+    issue(0, 0);
+    issue(min(1, nst - 1), 1);
+    bf16x8 ap[2][2][3], bp[2][2][3];
+    float rb[2][8];
+#define C3N_MFMA6(SET, I, J)                                                                                                 \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][2], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][2], bp[SET][J][0], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][1], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][1], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][0], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][0], acc[I][J], 0, 0, 0);
+    auto step = [&](int st, int slot, auto set_tag, auto first_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // younger: the 6 pieces of stage st + 1
+        acr_barrier_nofence();
+        const int rslot = slot == 0 ? 2 : slot - 1;
+        issue(min(st + 2, nst - 1), rslot);
+        const uint32_t fas = fa + slot * C3N_STAGE_B, fbs = fb + slot * C3N_STAGE_B;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            C3W_RD32(rb[j][0], fbs, 0 * C3N_BN * 4 + j * 128); C3W_RD32(rb[j][1], fbs, 1 * C3N_BN * 4 + j * 128);
+            C3W_RD32(rb[j][2], fbs, 2 * C3N_BN * 4 + j * 128); C3W_RD32(rb[j][3], fbs, 3 * C3N_BN * 4 + j * 128);
+            C3W_RD32(rb[j][4], fbs, 4 * C3N_BN * 4 + j * 128); C3W_RD32(rb[j][5], fbs, 5 * C3N_BN * 4 + j * 128);
+            C3W_RD32(rb[j][6], fbs, 6 * C3N_BN * 4 + j * 128); C3W_RD32(rb[j][7], fbs, 7 * C3N_BN * 4 + j * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            C3W_RD128(ap[SET][i][0], fas, 0 * 2048 + i * 1024); C3W_RD128(ap[SET][i][1], fas, 1 * 2048 + i * 1024);
+            C3W_RD128(ap[SET][i][2], fas, 2 * 2048 + i * 1024);
+        }
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[0][2]), "+v"(rb[0][3]), "+v"(rb[0][4]), "+v"(rb[0][5]), "+v"(rb[0][6]),
+                     "+v"(rb[0][7]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[1][2]), "+v"(rb[1][3]), "+v"(rb[1][4]), "+v"(rb[1][5]), "+v"(rb[1][6]), "+v"(rb[1][7]));
+        __builtin_amdgcn_sched_barrier(0);
+        const int tap = ((sbeg + st) * C3_BK) / g.C;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = (((j ? valid1 : valid0) >> tap) & 1) != 0;
+            f32x4 lo = {rb[j][0], rb[j][1], rb[j][2], rb[j][3]}, hi = {rb[j][4], rb[j][5], rb[j][6], rb[j][7]};
+            if (!ok) { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            c3_split3(lo, hi, bp[SET][j][0], bp[SET][j][1], bp[SET][j][2]);
+        }
+        if (!FIRST) {
+            C3N_MFMA6(SET ^ 1, 0, 0) C3N_MFMA6(SET ^ 1, 0, 1) C3N_MFMA6(SET ^ 1, 1, 0) C3N_MFMA6(SET ^ 1, 1, 1)
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ap[SET][0][0]), "+v"(ap[SET][0][1]), "+v"(ap[SET][0][2]), "+v"(ap[SET][1][0]), "+v"(ap[SET][1][1]), "+v"(ap[SET][1][2]));
+    };
+    step(0, 0, std::integral_constant<int, 0>{}, std::true_type{});
+    int slot = 1;
+    for (int st = 1; st < nst; st += 2) {
+        step(st, slot, std::integral_constant<int, 1>{}, std::false_type{});
+        slot = slot == 2 ? 0 : slot + 1;
+        if (st + 1 < nst) {
+            step(st + 1, slot, std::integral_constant<int, 0>{}, std::false_type{});
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nst & 1) { C3N_MFMA6(0, 0, 0) C3N_MFMA6(0, 0, 1) C3N_MFMA6(0, 1, 0) C3N_MFMA6(0, 1, 1) }
+    else { C3N_MFMA6(1, 0, 0) C3N_MFMA6(1, 0, 1) C3N_MFMA6(1, 1, 0) C3N_MFMA6(1, 1, 1) }
+#undef C3N_MFMA6
+    float* yb = (g.ksplit > 1 ? g.ws + (int64_t)part * g.nsamp * g.M * g.HW : g.y) + (int64_t)sample * g.M * g.HW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i * 32 + acr_krow(e, h);
+                if (row < g.M && col < g.HW) yb[(int64_t)row * g.HW + col] = acc[i][j][e];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // weight gradient: c[co][t*C + ci] = sum_p dy[co][p] * x[ci][p + off_t] * valid_t(p) per (sample, pixel part) into fp32 slabs,
 // summed in a fixed order afterwards.  Both operands are contiguous in the contraction index p (gemm_f32.hip's KC images): A rows
 // = dy's channels, B rows = the 9 C (tap, channel) pairs, each an x channel row SHIFTED by its tap's offset (per-lane source
@@ -594,8 +738,8 @@ extern "C" int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float*
 
 // Small launches (CAM generation: two views of one image, 20-72 workgroups walking 144 stages each) are split along the
 // contraction into up to 512 workgroups' worth of parts of at least 8 stages; the parts' slabs are summed in part order.
-static int c3_fwd_ksplit(int nsamp, int cout, int cin, int HW) {
-    const int tiles = ((cout + C3_BM - 1) / C3_BM) * ((HW + C3_BN - 1) / C3_BN) * nsamp;
+static int c3_fwd_ksplit(int nsamp, int cout, int cin, int HW, bool wide64 = false) {
+    const int tiles = wide64 ? ((HW + 255) / 256) * nsamp : ((cout + C3_BM - 1) / C3_BM) * ((HW + C3_BN - 1) / C3_BN) * nsamp;
     const int nst = 9 * cin / C3_BK;
     if (tiles >= 192) return 1;
     int ks = 512 / tiles;
@@ -605,7 +749,8 @@ static int c3_fwd_ksplit(int nsamp, int cout, int cin, int HW) {
     return (nst + sps - 1) / sps;
 }
 extern "C" size_t acr_conv3x3_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W) {
-    const int ks = c3_fwd_ksplit(nsamp, cout, cin, H * W);
+    int ks = c3_fwd_ksplit(nsamp, cout, cin, H * W);
+    if (cout <= 64) ks = max(ks, c3_fwd_ksplit(nsamp, cout, cin, H * W, true));      // acr_conv3x3_x3's 64 x 256 tiling
     return ks > 1 ? (size_t)ks * nsamp * cout * H * W : 0;
 }
 extern "C" int acr_conv3x3_f32(int32_t math, const float* w_packed, const float* x, float* y, int32_t nsamp, int32_t cout, int32_t cin,
@@ -647,13 +792,15 @@ extern "C" int acr_conv3x3_x3(const float* w_img, const float* x, float* y, int3
     ACR_CHECK_ARG((int64_t)cin * H * W < (1ll << 30), "acr_conv3x3_x3: sample too large for 32-bit offsets");
     Conv3Args g;
     g.w = w_img; g.x = x; g.y = y; g.M = cout; g.C = cin; g.H = H; g.W = W; g.HW = H * W; g.nsamp = nsamp;
-    g.tiles_m = (cout + C3_BM - 1) / C3_BM; g.tiles_n = (g.HW + C3_BN - 1) / C3_BN;
+    const bool wide64 = cout <= 64;                         // 64 x 256 tiles: all four waves compute (conv3x3_wimg64_kernel)
+    g.tiles_m = wide64 ? 1 : (cout + C3_BM - 1) / C3_BM; g.tiles_n = wide64 ? (g.HW + 255) / 256 : (g.HW + C3_BN - 1) / C3_BN;
     const int nst = 9 * cin / C3_BK;
-    g.ksplit = (ws && ((uintptr_t)ws & 15) == 0) ? c3_fwd_ksplit(nsamp, cout, cin, g.HW) : 1;
+    g.ksplit = (ws && ((uintptr_t)ws & 15) == 0) ? c3_fwd_ksplit(nsamp, cout, cin, g.HW, wide64) : 1;
     g.sps = (nst + g.ksplit - 1) / g.ksplit; g.ws = ws;
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp * g.ksplit;
     ACR_CHECK_ARG(nwg < (1ll << 31), "acr_conv3x3_x3: grid too large");
-    hipLaunchKernelGGL(conv3x3_wimg_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
+    if (wide64) hipLaunchKernelGGL(conv3x3_wimg64_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(conv3x3_wimg_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
     if (g.ksplit > 1) {
         const int64_t n4 = (int64_t)nsamp * cout * g.HW / 4;
         hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, g.ksplit, n4, y);

@@ -1231,6 +1231,138 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wimg_kernel(const GemmF32Args
     gemm_f32_finish<true, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, 0.f, false);
 }
 
+// The same product for at most 64 output channels (the stem's 1x1 convolutions into / out of the 64-channel maps at 112 x 112, and
+// CAM generation's large maps): with a 128-row tile the lower wave row has no outputs -- two of four waves only feed the DMA.
+// Tile = 64 rows x 256 PIXELS, all four waves compute 64 x 64 on their own 64 pixels; the A stage is the upper half of the
+// image's 128-row block (3 planes x 2 KiB).  Ring 3 slots x [A 6 KiB | B fp32 16 KiB]; per wave and stage 2 A pieces (wave 3
+// re-fetches pieces 4, 5: identical bytes to the same place, the count stays uniform) + 4 B pieces (one k row of 256 pixels).
+#define W64_BN 256
+#define W64_A_B (3 * 2048)
+#define W64_STAGE_B (W64_A_B + P_BK * W64_BN * 4)          // 22 KiB
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_f32_wimg64_kernel(const GemmF32Args g) {
+    __shared__ __attribute__((aligned(1024))) char sm[P_SLOTS * W64_STAGE_B];            // 66 KiB
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, wn = wave;
+    const int ntile = g.tiles_n;                            // one tile row (M <= 64)
+    const int t0 = acr_xcd_remap(blockIdx.x, ntile * g.nsplit);
+    const int split = t0 / ntile, tn = t0 - split * ntile;
+    const int n0 = tn * W64_BN;
+    const int zs = split / g.ksplit;
+    const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);      // host: multiples of 16
+    const int qa = wave < 3 ? 2 * wave : 4;
+    const char* __restrict__ pa = reinterpret_cast<const char*>(g.a) + (int64_t)(kbeg / P_BK) * (3 * P_TILE_B) + lane * 16;
+    const float* __restrict__ pb = g.b + (int64_t)zs * g.b_zs + (int64_t)kbeg * g.ldb + min(n0 + 4 * lane, g.N - 4);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nst = (kend - kbeg) / P_BK;
+    auto issue = [&](int st, int slot) {
+        char* d = sm + slot * W64_STAGE_B;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = qa + i;
+            __builtin_amdgcn_global_load_lds((glb_vp)(pa + (int64_t)st * (3 * P_TILE_B) + (q >> 1) * P_TILE_B + (q & 1) * 1024), (lds_vp)(d + q * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_vp)(pb + (int64_t)(st * P_BK + 4 * wave + i) * g.ldb), (lds_vp)(d + W64_A_B + (4 * wave + i) * 1024), 16, 0, 0);
+    };
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)sm;
+    const uint32_t fa = lbase + r * 32 + (h ^ ((r >> 3) & 1)) * 16;
+    const uint32_t fb = lbase + W64_A_B + ((8 * h) * W64_BN + wn * 64 + r) * 4;
+    issue(0, 0);
+    issue(min(1, nst - 1), 1);
+    bf16x8 ap[2][2][3], bp[2][2][3];
+    float rb[2][8];
+#define W64_MFMA6(SET, I, J)                                                                                                 \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][2], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][2], bp[SET][J][0], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][1], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][1], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][1], bp[SET][J][0], acc[I][J], 0, 0, 0);                   \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[SET][I][0], bp[SET][J][0], acc[I][J], 0, 0, 0);
+#define W64_RD32(dst, addr, OFF) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
+    auto step = [&](int st, int slot, auto set_tag, auto first_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // younger: the 6 pieces of stage st + 1
+        acr_barrier_nofence();
+        const int rslot = slot == 0 ? 2 : slot - 1;
+        issue(min(st + 2, nst - 1), rslot);
+        const uint32_t fas = fa + slot * W64_STAGE_B, fbs = fb + slot * W64_STAGE_B;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            W64_RD32(rb[j][0], fbs, 0 * W64_BN * 4 + j * 128); W64_RD32(rb[j][1], fbs, 1 * W64_BN * 4 + j * 128);
+            W64_RD32(rb[j][2], fbs, 2 * W64_BN * 4 + j * 128); W64_RD32(rb[j][3], fbs, 3 * W64_BN * 4 + j * 128);
+            W64_RD32(rb[j][4], fbs, 4 * W64_BN * 4 + j * 128); W64_RD32(rb[j][5], fbs, 5 * W64_BN * 4 + j * 128);
+            W64_RD32(rb[j][6], fbs, 6 * W64_BN * 4 + j * 128); W64_RD32(rb[j][7], fbs, 7 * W64_BN * 4 + j * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            PL_RD(ap[SET][i][0], fas, 0 * 2048 + i * 1024); PL_RD(ap[SET][i][1], fas, 1 * 2048 + i * 1024); PL_RD(ap[SET][i][2], fas, 2 * 2048 + i * 1024);
+        }
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[0][2]), "+v"(rb[0][3]), "+v"(rb[0][4]), "+v"(rb[0][5]), "+v"(rb[0][6]),
+                     "+v"(rb[0][7]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[1][2]), "+v"(rb[1][3]), "+v"(rb[1][4]), "+v"(rb[1][5]), "+v"(rb[1][6]), "+v"(rb[1][7]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 lo = {rb[j][0], rb[j][1], rb[j][2], rb[j][3]}, hi = {rb[j][4], rb[j][5], rb[j][6], rb[j][7]};
+            split3_bf16(lo, hi, bp[SET][j][0], bp[SET][j][1], bp[SET][j][2]);
+        }
+        if (!FIRST) {
+            W64_MFMA6(SET ^ 1, 0, 0) W64_MFMA6(SET ^ 1, 0, 1) W64_MFMA6(SET ^ 1, 1, 0) W64_MFMA6(SET ^ 1, 1, 1)
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ap[SET][0][0]), "+v"(ap[SET][0][1]), "+v"(ap[SET][0][2]), "+v"(ap[SET][1][0]), "+v"(ap[SET][1][1]), "+v"(ap[SET][1][2]));
+    };
+    step(0, 0, std::integral_constant<int, 0>{}, std::true_type{});
+    int slot = 1;
+    for (int st = 1; st < nst; st += 2) {
+        step(st, slot, std::integral_constant<int, 1>{}, std::false_type{});
+        slot = slot == 2 ? 0 : slot + 1;
+        if (st + 1 < nst) {
+            step(st + 1, slot, std::integral_constant<int, 0>{}, std::false_type{});
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+    if (nst & 1) { W64_MFMA6(0, 0, 0) W64_MFMA6(0, 0, 1) W64_MFMA6(0, 1, 0) W64_MFMA6(0, 1, 1) }
+    else { W64_MFMA6(1, 0, 0) W64_MFMA6(1, 0, 1) W64_MFMA6(1, 1, 0) W64_MFMA6(1, 1, 1) }
+#undef W64_MFMA6
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end
+    if (ACT == 3) {                                         // K-split small launch: raw part sums into slab `split`
+        float* slab = g.c + (int64_t)split * g.M * g.ldc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = i * 32 + acr_krow(e, h);
+                    if (row < g.M && col < g.N) slab[(int64_t)row * g.ldc + col] = acc[i][j][e];
+                }
+            }
+        return;
+    }
+    GemmF32Args gz = g;
+    gz.c += (int64_t)zs * g.c_zs;
+    if (gz.aux) gz.aux += (int64_t)zs * g.aux_zs;
+    epilogue_f32<0, true>(gz, acc, 0, n0 + wn * 64, r, h);
+}
+
 // ---- the split passes (HBM-bound: 4 bytes read, 6 written per element) ----------------------------------------------------------
 __device__ __forceinline__ void planes_split8(const float (&x)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
 #pragma unroll
@@ -1812,8 +1944,8 @@ static void conv_args(GemmF32Args& g, int M, int N, int K) {
 // Small launches (CAM generation: two views of one image, 8-72 workgroups) under split products: the contraction is split into
 // parts of at least 64 channels so that the launch fills the chip; raw part sums go to slabs [sample][part], summed in part
 // order (+ addend) by conv1x1_ksum_kernel.
-static int conv1x1_ksplit(int nsamp, int cout, int cin, int hw, int* kps_out) {
-    const int tiles = ((cout + F_BM - 1) / F_BM) * ((hw + F_BN - 1) / F_BN) * nsamp;
+static int conv1x1_ksplit(int nsamp, int cout, int cin, int hw, int* kps_out, bool wide64 = false) {
+    const int tiles = wide64 ? ((hw + 255) / 256) * nsamp : ((cout + F_BM - 1) / F_BM) * ((hw + F_BN - 1) / F_BN) * nsamp;
     *kps_out = (cin + S_BK - 1) / S_BK * S_BK;
     if (tiles >= 192 || (cin % F_BK) != 0) return 1;
     int ks = 512 / tiles;
@@ -1826,7 +1958,8 @@ static int conv1x1_ksplit(int nsamp, int cout, int cin, int hw, int* kps_out) {
 extern "C" size_t acr_conv1x1_ws_floats(int32_t math, int32_t nsamp, int32_t cout, int32_t cin, int32_t hw) {
     int kps;
     if (math != ACR_MATH_BF16X3) return 0;
-    const int ks = conv1x1_ksplit(nsamp, cout, cin, hw, &kps);
+    int ks = conv1x1_ksplit(nsamp, cout, cin, hw, &kps);
+    if (cout <= 64) ks = max(ks, conv1x1_ksplit(nsamp, cout, cin, hw, &kps, true));      // acr_conv1x1_x3's 64 x 256 tiling
     return ks > 1 ? (size_t)ks * nsamp * cout * hw : 0;
 }
 __global__ __launch_bounds__(256) void conv1x1_ksum_kernel(const float* __restrict__ ws, int ks, int64_t per4, const float* __restrict__ addend,
@@ -1909,17 +2042,22 @@ extern "C" int acr_conv1x1_x3(const float* w_img, const float* x, const float* a
     g.c = y; g.ldc = hw; g.c_zs = (int64_t)cout * hw;
     g.aux = addend; g.ldaux = hw; g.aux_zs = (int64_t)cout * hw;
     g.nsplit = nsamp; g.kps = cin; g.k_zs = 0;
+    const bool wide64 = cout <= 64 && hw >= 4;              // 64 x 256 tiles: all four waves compute (gemm_f32_wimg64_kernel)
+    if (wide64) { g.tiles_m = 1; g.tiles_n = (hw + W64_BN - 1) / W64_BN; g.tiles_launch = g.tiles_n; }
     int kps = 0;
-    const int ks = (ws && al16(ws)) ? conv1x1_ksplit(nsamp, cout, cin, hw, &kps) : 1;
+    const int ks = (ws && al16(ws)) ? conv1x1_ksplit(nsamp, cout, cin, hw, &kps, wide64) : 1;
     if (ks > 1) {                                           // K-split small launch (conv1x1_ksplit): slabs, then the part sum (+ addend)
         g.nsplit = nsamp * ks; g.ksplit = ks; g.kps = kps; g.k_zs = kps;
         g.c = ws; g.aux = nullptr;
+        if (wide64) hipLaunchKernelGGL((gemm_f32_wimg64_kernel<3>), dim3((unsigned)(g.tiles_n * nsamp * ks)), dim3(256), 0, st, g);
+        else
         hipLaunchKernelGGL((gemm_f32_wimg_kernel<3>), dim3((unsigned)(g.tiles_m * g.tiles_n * nsamp * ks)), dim3(256), 0, st, g);
         const int64_t per4 = (int64_t)cout * hw / 4, n4 = per4 * nsamp;
         hipLaunchKernelGGL(conv1x1_ksum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, ks, per4, addend, y, n4);
         return acr_check_launch("acr_conv1x1_x3(K-split)");
     }
-    hipLaunchKernelGGL((gemm_f32_wimg_kernel<0>), dim3((unsigned)(g.tiles_m * g.tiles_n * nsamp)), dim3(256), 0, st, g);
+    if (wide64) hipLaunchKernelGGL((gemm_f32_wimg64_kernel<0>), dim3((unsigned)(g.tiles_n * nsamp)), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_wimg_kernel<0>), dim3((unsigned)(g.tiles_m * g.tiles_n * nsamp)), dim3(256), 0, st, g);
     return acr_check_launch("acr_conv1x1_x3");
 }
 
