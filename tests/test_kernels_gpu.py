@@ -1084,6 +1084,37 @@ def test_conv3x3_split(N, cin, cout, H, W, wimg, monkeypatch):
     assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad) and torch.equal(w2.grad, w.grad)
 
 
+def test_x3_image_many_equals_the_single_image_passes():
+    """acr_x3_image_many (all weight images of a stem group / of the blocks in one launch, sources described as strided views) must
+    write, bit for bit, what the single-image passes write: W and W^T of a Linear / 1x1 convolution (acr_x3_image, acr_x3_image_t),
+    the packed 3x3 weight w[co][t * ci + c] and its input-gradient pack w[o][c][8 - t'] as (ci x 9 co) (acr_x3_image of the
+    permuted copies ops.Conv3x3Fn used to make) -- shapes with partial row blocks and a contraction that is not a multiple of 64."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    w1 = torch.randn(200, 72, generator=g).to(dev)                   # (out, in): rows not a multiple of 128, K = 72
+    w3 = torch.randn(48, 32, 3, 3, generator=g).to(dev)              # (co, ci, 3, 3)
+    co, ci = w3.shape[:2]
+    specs = [(w1, 0, 200, 72, 72, 72, 0, 1), (w1, 0, 72, 200, 1, 200, 0, 72),
+             (w3, 0, co, 9 * ci, 9 * ci, ci, 1, 9), (w3, 8, ci, 9 * co, 9, co, -1, 9 * ci)]
+    got = ops.x3_image_many(specs, dev)
+    wp = w3.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+    wd = w3.flip(2, 3).permute(1, 2, 3, 0).reshape(ci, 9 * co).contiguous()
+    want = [ops.x3_image(w1), ops.x3_image_t(w1), ops.x3_image(wp), ops.x3_image(wd)]
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a.shape == b.shape and torch.equal(a.view(torch.int32), b.view(torch.int32)), i
+    # and the per-owner caches prebuild_weight_images fills are what weight_image would have built
+    lin = torch.nn.Linear(72, 200, bias=False).to(dev)
+    with torch.no_grad():
+        lin.weight.copy_(w1)
+    assert ops.prebuild_weight_images([lin]) == 1
+    a, at = ops.weight_image(lin.weight, lin), ops.weight_image(lin.weight, lin, True)
+    assert torch.equal(a.view(torch.int32), want[0].view(torch.int32)) and torch.equal(at.view(torch.int32), want[1].view(torch.int32))
+    with torch.no_grad():
+        lin.weight.mul_(2.0)                                         # version bump: the cache entry is stale, a fresh image is built
+    assert not torch.equal(ops.weight_image(lin.weight, lin).view(torch.int32), a.view(torch.int32))
+
+
 def test_conv3x3_reads_nothing_outside_its_input():
     """acr_conv3x3_f32 / acr_conv3x3_wgrad_f32 used to dereference addresses up to ACR_CONV3X3_PAD floats outside x
     (shifted tap windows, values masked) and asked the caller for readable slack.  Now the workgroups at the tensor's two ends
