@@ -1,5 +1,6 @@
-"""Summarise a rocprofv3 kernel trace of scripts/lab/infer_busy.py <n> <scale>: GPU-busy vs span per image over the last n images
-(image boundaries = every 2nd aff_refine launch).  usage: infer_trace_summary.py <trace.csv> [n]"""
+"""Summarise a rocprofv3 kernel trace of scripts/lab/infer_busy.py <n> <scale | all>: GPU-busy vs span per image over the last n
+images (image boundaries = every `per`-th aff_refine launch: one per scale-pass, i.e. 1 for a single scale, 4 for `all`).
+usage: infer_trace_summary.py <trace.csv> [n] [top] [per]"""
 import collections
 import csv
 import sys
@@ -8,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("aff_refine_kernel")]
-per = 2
+per = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 first = marks[-per * n - 1] + 1
 last = rows[first:marks[-1] + 1]
 t0, t1 = int(last[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in last)
