@@ -90,6 +90,14 @@ SIGNATURES = {
     "acr_conv3x3_wgrad_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "acr_conv3x3_wgrad_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                         c_void_p]),
+    "acr_space_to_depth2_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "acr_depth_to_space2_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "acr_conv_taps_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "acr_conv_taps_x3": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                   c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "acr_conv_taps_wgrad_ws_floats": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "acr_conv_taps_wgrad_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                          c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "acr_maxpool3x3s2_fwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                             c_int32, c_void_p]),
     "acr_maxpool3x3s2_bwd_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -67,9 +67,13 @@ class StdConv2dSame(nn.Conv2d):
         return (self.weight - mean) / (std + self.eps)
 
     def forward(self, x):
+        w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
+        if self.hip_3x3 and self.stride[0] == 2 and self.kernel_size[0] in (3, 7) and ops.conv_s2_fusable(x, w_hat, 2, self.acr_math):
+            # the stem's 7x7 and the two stride-2 3x3 convolutions under split products: space-to-depth + tap-table implicit GEMM
+            # (SAME padding = the taps' validity masks; no padded copy, no library kernel, no layout transposes)
+            return ops.conv_s2(x, w_hat, self._w_imgs)
         if self.dynamic_pad:
             x = pad_same(x, self.kernel_size[0], self.stride[0])
-        w_hat = self._w_hat if self._w_hat is not None else self.standardized_weight()
         if self.hip_1x1 and self.hip_1x1_strided and self.kernel_size == (1, 1) and self.stride[0] == 2 and x.is_cuda:
             # the two stride-2 1x1 convolutions (the shortcuts of stages 1 and 2; SAME padding is empty for a 1x1 kernel:
             # y[i][j] = W x[2i][2j]): subsample first, then the same NCHW GEMM kernels as every other 1x1 -- the library ran
@@ -114,6 +118,15 @@ class StdConv2dSame(nn.Conv2d):
         if k == 3 and self.stride[0] == 1 and not self.dynamic_pad and self.hip_3x3 and ops.CONV3X3_WIMG and ci % 16 == 0 and co % 16 == 0:
             return ((w_hat, 0, co, 9 * ci, 9 * ci, ci, 1, 9),        # packed w[co][t * ci + c]
                     (w_hat, 8, ci, 9 * co, 9, co, -1, 9 * ci))       # input-gradient pack w[o][c][8 - t'] as (ci x 9 co)
+        if self.stride[0] == 2 and self.hip_3x3 and ops.CONV_S2_HIP and co % 16 == 0:
+            # stride 2 (ops.ConvS2Fn), for inputs of even height and width: the forward pack, and for the 3x3s the four pixel-phase
+            # packs of the input gradient (two small gather / permute copies of the weight first)
+            if k == 3 and ci % 16 == 0:
+                plan = ops.conv_s2_plan(3, ci, 32, 32, w_hat.device)
+                return ((w_hat, 0, co, 9 * ci, 9 * ci, ci, 1, 9),) + plan.dgrad_specs(plan.pack_dgrad(w_hat))
+            if k == 7 and 4 * ci <= 16:
+                w16 = ops.conv_s2_plan(7, ci, 32, 32, w_hat.device).pack(w_hat)
+                return ((w16, 0, co, w16.shape[1], w16.shape[1], w16.shape[1], 0, 1),)
         return None
 
 
@@ -241,12 +254,12 @@ class ResNetV2(nn.Module):
             for i in idx:
                 sp = convs[i].image_specs(w_hats[i].detach())
                 if sp is not None:
+                    owners.append((i, len(specs), len(sp)))
                     specs += list(sp)
-                    owners.append(i)
             if specs:
                 made = ops.x3_image_many(specs, w_hats[idx[0]].device)
-                for n, i in enumerate(owners):
-                    imgs[i] = (made[2 * n], made[2 * n + 1])
+                for i, first, n in owners:
+                    imgs[i] = tuple(made[first:first + n])
 
     def _wstd_groups(self, convs):
         """Index lists into ``convs`` (module order): everything up to and including stage 1, and the last stage."""

@@ -33,6 +33,18 @@
 typedef __attribute__((address_space(3))) void* c3_lds_vp;
 typedef const __attribute__((address_space(1))) void* c3_glb_vp;
 
+// Tap table of the generalised kernels (template argument TAB; the 3x3 stride-1 kernels never read it): the contraction is
+// ntap * C, tap t multiplies the C channel rows tcb[t] .. of x SHIFTED by toff[t] = tdy * W + tdx pixels, zero where
+// (y + tdy, x + tdx) leaves the H x W grid.  That is every strided SAME convolution after a space-to-depth pass (stride 2: the four
+// pixel phases of the input become channel groups of a half-resolution grid, a tap reads ONE phase at a shift of 0 / +-1), its
+// input gradient (one launch per output phase over the taps that feed it) and the 7x7 stem convolution (16 (dy, dx) taps x the
+// 12 phase-channel rows + 4 zero rows).  x and y may be channel slices of larger tensors (xrows / yrows rows per sample).
+#define C3_MAXTAP 16
+struct C3Tab {
+    int ntap, xrows, yrows, maxoff;  // maxoff = max |toff|
+    int toff[C3_MAXTAP], tcb[C3_MAXTAP];
+    int tdydx[C3_MAXTAP];            // (tdy + 8) | (tdx + 8) << 8
+};
 struct Conv3Args {
     const float* w;                  // packed weights (M, 9 * C): w[m][t * C + c]
     const float* x;                  // (nsamp, C, H * W)
@@ -41,6 +53,7 @@ struct Conv3Args {
     int tiles_m, tiles_n;
     int ksplit, sps;                 // K-split of small launches: `ksplit` parts of `sps` stages each into slabs ws[part] (laid out like y)
     float* ws;
+    C3Tab t;
 };
 
 __device__ __forceinline__ void c3_split3(const f32x4& lo4, const f32x4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
@@ -74,6 +87,18 @@ __device__ __forceinline__ int c3_valid9(int p, int H, int W, int HW) {
             const int yy = y + ty - 1, xx = x + tx - 1;
             if (yy >= 0 && yy < H && xx >= 0 && xx < W) m |= 1 << (ty * 3 + tx);
         }
+    return m;
+}
+
+template <bool TAB> __device__ __forceinline__ int c3_valid(const Conv3Args& g, int p) {
+    if (!TAB) return c3_valid9(p, g.H, g.W, g.HW);
+    if (p >= g.HW) return 0;
+    const int y = p / g.W, x = p - y * g.W;
+    int m = 0;
+    for (int t = 0; t < g.t.ntap; ++t) {
+        const int yy = y + (g.t.tdydx[t] & 255) - 8, xx = x + (g.t.tdydx[t] >> 8) - 8;
+        if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) m |= 1 << t;
+    }
     return m;
 }
 
@@ -240,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const Conv3Args g
 #define C3W_SLOTS 3
 #define C3W_RD128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
 #define C3W_RD32(dst, addr, OFF) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF))
-__global__ __launch_bounds__(256, 2) void conv3x3_wimg_kernel(const Conv3Args g) {
+template <bool TAB> __global__ __launch_bounds__(256, 2) void conv3x3_wimg_kernel(const Conv3Args g) {
     __shared__ __attribute__((aligned(1024))) char smem[C3W_SLOTS * C3W_STAGE_B];       // 60 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -252,9 +277,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wimg_kernel(const Conv3Args g)
     const int tn = tt / g.tiles_m, tm = tt - tn * g.tiles_m;
     const int sbeg = part * g.sps;
     const int m0 = tm * C3_BM, n0 = tn * C3_BN;
-    const int nkb = 9 * g.C / C3_BK;                        // stages per row block of the weight image
+    const int nkb = (TAB ? g.t.ntap : 9) * g.C / C3_BK;     // stages per row block of the weight image
+    const int xrows = TAB ? g.t.xrows : g.C, yrows = TAB ? g.t.yrows : g.M, maxoff = TAB ? g.t.maxoff : g.W + 1;
     const char* __restrict__ pa = reinterpret_cast<const char*>(g.w) + ((int64_t)tm * nkb + sbeg) * (3 * C3W_PLANE_B) + wave * 3072 + lane * 16;
-    const float* __restrict__ pb = g.x + (int64_t)sample * g.C * g.HW;
+    const float* __restrict__ pb = g.x + (int64_t)sample * xrows * g.HW;
     const bool compute = m0 + wm * 64 < g.M;
     f32x16 acc[2][2];
 #pragma unroll
@@ -267,21 +293,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wimg_kernel(const Conv3Args g)
 #pragma unroll
     for (int i = 0; i < 2; ++i) rowb[i] = ((wave * 2 + i) * 2 + (lane >> 5)) * g.HW;
     const int pix = n0 + 4 * (lane & 31);
-    const int valid0 = c3_valid9(n0 + wn * 64 + r, g.H, g.W, g.HW), valid1 = c3_valid9(n0 + wn * 64 + 32 + r, g.H, g.W, g.HW);
+    const int valid0 = c3_valid<TAB>(g, n0 + wn * 64 + r), valid1 = c3_valid<TAB>(g, n0 + wn * 64 + 32 + r);
     const int nst = min(nkb - sbeg, g.sps);
-    const int64_t total = (int64_t)g.nsamp * g.C * g.HW;
-    const bool edge = (sample == 0 && n0 < g.W + 1) || (sample == g.nsamp - 1 && n0 + C3_BN + g.W + 1 > g.HW);
+    const int64_t total = (int64_t)g.nsamp * xrows * g.HW;
+    const bool edge = (sample == 0 && n0 < maxoff) || (sample == g.nsamp - 1 && n0 + C3_BN + maxoff > g.HW);
     auto issue = [&](int st, int slot) {                    // 3 A pieces (contiguous KiB of the image) + 2 shifted B pieces
         char* d = smem + slot * C3W_STAGE_B;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             __builtin_amdgcn_global_load_lds((c3_glb_vp)(pa + (int64_t)st * (3 * C3W_PLANE_B) + i * 1024), (c3_lds_vp)(d + (wave * 3 + i) * 1024), 16, 0, 0);
         const int k0 = (sbeg + st) * C3_BK;
-        const int tap = k0 / g.C, ci0 = k0 - tap * g.C;
-        const int ty = tap / 3, off = (ty - 1) * g.W + (tap - 3 * ty - 1);
+        const int tap = k0 / g.C;
+        int ci0 = k0 - tap * g.C, off;
+        if (TAB) { off = g.t.toff[tap]; ci0 += g.t.tcb[tap]; }
+        else { const int ty = tap / 3; off = (ty - 1) * g.W + (tap - 3 * ty - 1); }
         float* db = reinterpret_cast<float*>(d + 3 * C3W_PLANE_B);
         if (edge) {
-            const int64_t i0 = (int64_t)sample * g.C * g.HW + (int64_t)ci0 * g.HW + (pix + off);
+            const int64_t i0 = (int64_t)sample * xrows * g.HW + (int64_t)ci0 * g.HW + (pix + off);
 #pragma unroll
             for (int i = 0; i < 2; ++i) c3_dma_careful(g.x, i0 + rowb[i], total, db + (wave * 2 + i) * 256, lane);
             return;
@@ -365,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wimg_kernel(const Conv3Args g)
     if (nst & 1) { C3W_MFMA6(0, 0, 0) C3W_MFMA6(0, 0, 1) C3W_MFMA6(0, 1, 0) C3W_MFMA6(0, 1, 1) }
     else { C3W_MFMA6(1, 0, 0) C3W_MFMA6(1, 0, 1) C3W_MFMA6(1, 1, 0) C3W_MFMA6(1, 1, 1) }
 #undef C3W_MFMA6
-    float* yb = (g.ksplit > 1 ? g.ws + (int64_t)part * g.nsamp * g.M * g.HW : g.y) + (int64_t)sample * g.M * g.HW;
+    float* yb = g.ksplit > 1 ? g.ws + ((int64_t)part * g.nsamp + sample) * g.M * g.HW : g.y + (int64_t)sample * yrows * g.HW;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -389,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wimg_kernel(const Conv3Args g)
 #define C3N_BN 256
 #define C3N_A_B (3 * 2048)
 #define C3N_STAGE_B (C3N_A_B + C3_BK * C3N_BN * 4)          // 22 KiB
-__global__ __launch_bounds__(256, 2) void conv3x3_wimg64_kernel(const Conv3Args g) {
+template <bool TAB> __global__ __launch_bounds__(256, 2) void conv3x3_wimg64_kernel(const Conv3Args g) {
     __shared__ __attribute__((aligned(1024))) char smem[C3W_SLOTS * C3N_STAGE_B];       // 66 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -400,10 +428,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wimg64_kernel(const Conv3Args 
     const int sample = t0 / ntile, tn = t0 - sample * ntile;
     const int sbeg = part * g.sps;
     const int n0 = tn * C3N_BN;
-    const int nkb = 9 * g.C / C3_BK;
+    const int nkb = (TAB ? g.t.ntap : 9) * g.C / C3_BK;
+    const int xrows = TAB ? g.t.xrows : g.C, yrows = TAB ? g.t.yrows : g.M, maxoff = TAB ? g.t.maxoff : g.W + 1;
     const int qa = wave < 3 ? 2 * wave : 4;                 // this wave's two A pieces: qa, qa + 1 (plane q >> 1, KiB q & 1 of its upper half)
     const char* __restrict__ pa = reinterpret_cast<const char*>(g.w) + (int64_t)sbeg * (3 * C3W_PLANE_B) + lane * 16;
-    const float* __restrict__ pb = g.x + (int64_t)sample * g.C * g.HW;
+    const float* __restrict__ pb = g.x + (int64_t)sample * xrows * g.HW;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -412,10 +441,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wimg64_kernel(const Conv3Args 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int pix = n0 + 4 * lane;
-    const int valid0 = c3_valid9(n0 + wn * 64 + r, g.H, g.W, g.HW), valid1 = c3_valid9(n0 + wn * 64 + 32 + r, g.H, g.W, g.HW);
+    const int valid0 = c3_valid<TAB>(g, n0 + wn * 64 + r), valid1 = c3_valid<TAB>(g, n0 + wn * 64 + 32 + r);
     const int nst = min(nkb - sbeg, g.sps);
-    const int64_t total = (int64_t)g.nsamp * g.C * g.HW;
-    const bool edge = (sample == 0 && n0 < g.W + 1) || (sample == g.nsamp - 1 && n0 + C3N_BN + g.W + 1 > g.HW);
+    const int64_t total = (int64_t)g.nsamp * xrows * g.HW;
+    const bool edge = (sample == 0 && n0 < maxoff) || (sample == g.nsamp - 1 && n0 + C3N_BN + maxoff > g.HW);
     auto issue = [&](int st, int slot) {
         char* d = smem + slot * C3N_STAGE_B;
 #pragma unroll
@@ -425,11 +454,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wimg64_kernel(const Conv3Args 
                                              (c3_lds_vp)(d + q * 1024), 16, 0, 0);
         }
         const int k0 = (sbeg + st) * C3_BK;
-        const int tap = k0 / g.C, ci0 = k0 - tap * g.C;
-        const int ty = tap / 3, off = (ty - 1) * g.W + (tap - 3 * ty - 1);
+        const int tap = k0 / g.C;
+        int ci0 = k0 - tap * g.C, off;
+        if (TAB) { off = g.t.toff[tap]; ci0 += g.t.tcb[tap]; }
+        else { const int ty = tap / 3; off = (ty - 1) * g.W + (tap - 3 * ty - 1); }
         float* db = reinterpret_cast<float*>(d + C3N_A_B);
         if (edge) {
-            const int64_t i0 = (int64_t)sample * g.C * g.HW + (int64_t)ci0 * g.HW + (pix + off);
+            const int64_t i0 = (int64_t)sample * xrows * g.HW + (int64_t)ci0 * g.HW + (pix + off);
 #pragma unroll
             for (int i = 0; i < 4; ++i) c3_dma_careful(g.x, i0 + (int64_t)(4 * wave + i) * g.HW, total, db + (4 * wave + i) * C3N_BN, lane);
             return;
@@ -509,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wimg64_kernel(const Conv3Args 
     if (nst & 1) { C3N_MFMA6(0, 0, 0) C3N_MFMA6(0, 0, 1) C3N_MFMA6(0, 1, 0) C3N_MFMA6(0, 1, 1) }
     else { C3N_MFMA6(1, 0, 0) C3N_MFMA6(1, 0, 1) C3N_MFMA6(1, 1, 0) C3N_MFMA6(1, 1, 1) }
 #undef C3N_MFMA6
-    float* yb = (g.ksplit > 1 ? g.ws + (int64_t)part * g.nsamp * g.M * g.HW : g.y) + (int64_t)sample * g.M * g.HW;
+    float* yb = g.ksplit > 1 ? g.ws + ((int64_t)part * g.nsamp + sample) * g.M * g.HW : g.y + (int64_t)sample * yrows * g.HW;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -537,9 +568,10 @@ struct Conv3WgArgs {
     float* ws;                       // slabs (nsamp * ksplit, M, 9 C)
     int M, C, H, W, HW, nsamp, ksplit, kps;
     int tiles_m, tiles_n;
+    C3Tab t;                         // <true> kernels: B rows = the ntap * C (tap, channel) pairs of the table (yrows unused)
 };
 
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const Conv3WgArgs g) {
+template <bool TAB> __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const Conv3WgArgs g) {
     __shared__ __attribute__((aligned(1024))) float smem[C3_SLOTS * 2 * C3_TILE];      // [slot][A | B], 64 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -551,9 +583,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const Conv3
     const int m0 = tm * C3_BM, n0 = tn * C3_BN;
     const int sample = split / g.ksplit;
     const int kbeg = (split - sample * g.ksplit) * g.kps, kend = min(g.HW, kbeg + g.kps);        // host: (kend - kbeg) % 16 == 0
-    const int N9 = 9 * g.C;
+    const int N9 = (TAB ? g.t.ntap : 9) * g.C;
+    const int xrows = TAB ? g.t.xrows : g.C, maxoff = TAB ? g.t.maxoff : g.W + 1;
     const float* __restrict__ pa = g.dy + (int64_t)sample * g.M * g.HW;
-    const float* __restrict__ pb = g.x + (int64_t)sample * g.C * g.HW;
+    const float* __restrict__ pb = g.x + (int64_t)sample * xrows * g.HW;
     const bool compute = m0 + wm * 64 < g.M && n0 + wn * 64 < N9;
     f32x16 acc[2][2];
 #pragma unroll
@@ -572,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const Conv3
         const int nr = min(n0 + row, N9 - 1);               // (tap, channel) row of B
         const int tap = nr / g.C, ci = nr - tap * g.C;
         const int ty = tap / 3;
-        offb[i] = ci * g.HW + (ty - 1) * g.W + (tap - 3 * ty - 1) + lc4;
+        offb[i] = TAB ? (g.t.tcb[tap] + ci) * g.HW + g.t.toff[tap] + lc4 : ci * g.HW + (ty - 1) * g.W + (tap - 3 * ty - 1) + lc4;
     }
     // the lane's two B fragments: rows n0 + wn*64 + j*32 + r -> their taps
     int tyj[2], txj[2];
@@ -580,14 +613,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const Conv3
     for (int j = 0; j < 2; ++j) {
         const int nr = min(n0 + wn * 64 + j * 32 + r, N9 - 1);
         const int tap = nr / g.C;
-        tyj[j] = tap / 3;
-        txj[j] = tap - 3 * tyj[j];
+        if (TAB) { tyj[j] = (g.t.tdydx[tap] & 255) - 8; txj[j] = (g.t.tdydx[tap] >> 8) - 8; }      // TAB: the shifts themselves
+        else { tyj[j] = tap / 3; txj[j] = tap - 3 * tyj[j]; }
     }
     int xh0 = (kbeg + 8 * h) % g.W, xh1 = (kbeg + 8 * h + 4) % g.W;      // column of the first pixel of the lane's two halves
     const int nst = (kend - kbeg) / C3_BK;
     // the shifted rows of x leave the tensor only in front of sample 0's first pixels and behind the last sample's last ones
-    const int64_t total = (int64_t)g.nsamp * g.C * g.HW;
-    const bool edge = (sample == 0 && kbeg < g.W + 1) || (sample == g.nsamp - 1 && kend + g.W + 1 > g.HW);
+    const int64_t total = (int64_t)g.nsamp * xrows * g.HW;
+    const bool edge = (sample == 0 && kbeg < maxoff) || (sample == g.nsamp - 1 && kend + maxoff > g.HW);
     auto issue = [&](int st) {
         float* d = smem + (st & (C3_SLOTS - 1)) * 2 * C3_TILE;
         const int k0 = kbeg + st * C3_BK;
@@ -595,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const Conv3
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((c3_glb_vp)(pa + k0 + offa[i]), (c3_lds_vp)(d + (wave * 2 + i) * 256), 16, 0, 0);
         if (edge) {                                          // uniform (see c3_dma_careful)
-            const int64_t i0 = (int64_t)sample * g.C * g.HW + k0;
+            const int64_t i0 = (int64_t)sample * xrows * g.HW + k0;
 #pragma unroll
             for (int i = 0; i < 2; ++i) c3_dma_careful(g.x, i0 + offb[i], total, d + C3_TILE + (wave * 2 + i) * 256, lane);
             return;
@@ -635,12 +668,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const Conv3
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int p = p0 + 4 * hf, xc = hf ? xh1 : xh0;
-                const bool yok = tyj[j] == 1 || (tyj[j] == 0 ? p >= g.W : p < g.HW - g.W);
-                const bool kf = txj[j] == 0 && xc == 0, kl = txj[j] == 2 && xc + 4 == g.W;
                 f32x4 v = rb[j][hf];
-                if (!yok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (kf) v[0] = 0.f;
-                if (kl) v[3] = 0.f;
+                if (TAB) {                                   // any shift: the half's row moves as a whole, its columns one by one
+                    const int pr = p + tyj[j] * g.W;
+                    if (pr < 0 || pr >= g.HW) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = xc + e + txj[j];
+                        if (col < 0 || col >= g.W) v[e] = 0.f;
+                    }
+                } else {
+                    const bool yok = tyj[j] == 1 || (tyj[j] == 0 ? p >= g.W : p < g.HW - g.W);
+                    const bool kf = txj[j] == 0 && xc == 0, kl = txj[j] == 2 && xc + 4 == g.W;
+                    if (!yok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (kf) v[0] = 0.f;
+                    if (kl) v[3] = 0.f;
+                }
                 rb[j][hf] = v;
             }
         }
@@ -694,8 +737,8 @@ __global__ __launch_bounds__(256) void conv3x3_reduce_kernel(const float* __rest
     reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
-static int c3_wgrad_ksplit(int nsamp, int cout, int cin, int HW) {
-    const int tiles = ((cout + C3_BM - 1) / C3_BM) * ((9 * cin + C3_BN - 1) / C3_BN) * nsamp;
+static int c3_wgrad_ksplit(int nsamp, int cout, int cin, int HW, int ntap = 9) {
+    const int tiles = ((cout + C3_BM - 1) / C3_BM) * ((ntap * cin + C3_BN - 1) / C3_BN) * nsamp;
     int ks = 512 / tiles;
     const int maxs = HW / 1024;
     if (ks > maxs) ks = maxs;
@@ -729,7 +772,7 @@ extern "C" int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float*
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp * g.ksplit;
     ACR_CHECK_ARG(nwg < (1ll << 31), "acr_conv3x3_wgrad_f32: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv3x3_wgrad_split_kernel, dim3((unsigned)nwg), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, st, g);
     const int64_t n4 = (int64_t)cout * 9 * cin / 4;
     hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsamp * g.ksplit, n4,
                        dw_packed);
@@ -738,9 +781,9 @@ extern "C" int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float*
 
 // Small launches (CAM generation: two views of one image, 20-72 workgroups walking 144 stages each) are split along the
 // contraction into up to 512 workgroups' worth of parts of at least 8 stages; the parts' slabs are summed in part order.
-static int c3_fwd_ksplit(int nsamp, int cout, int cin, int HW, bool wide64 = false) {
+static int c3_fwd_ksplit(int nsamp, int cout, int cin, int HW, bool wide64 = false, int ntap = 9) {
     const int tiles = wide64 ? ((HW + 255) / 256) * nsamp : ((cout + C3_BM - 1) / C3_BM) * ((HW + C3_BN - 1) / C3_BN) * nsamp;
-    const int nst = 9 * cin / C3_BK;
+    const int nst = ntap * cin / C3_BK;
     if (tiles >= 192) return 1;
     int ks = 512 / tiles;
     if (ks > nst / 8) ks = nst / 8;
@@ -799,11 +842,201 @@ extern "C" int acr_conv3x3_x3(const float* w_img, const float* x, float* y, int3
     g.sps = (nst + g.ksplit - 1) / g.ksplit; g.ws = ws;
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp * g.ksplit;
     ACR_CHECK_ARG(nwg < (1ll << 31), "acr_conv3x3_x3: grid too large");
-    if (wide64) hipLaunchKernelGGL(conv3x3_wimg64_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(conv3x3_wimg_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
+    if (wide64) hipLaunchKernelGGL(conv3x3_wimg64_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(conv3x3_wimg_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
     if (g.ksplit > 1) {
         const int64_t n4 = (int64_t)nsamp * cout * g.HW / 4;
         hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, g.ksplit, n4, y);
     }
     return acr_check_launch("acr_conv3x3_x3");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Strided SAME convolutions (the 7x7 stride-2 stem convolution, models/resnetv2.py:337-340; conv2 of the first bottleneck of stages
+// 1 and 2, :196-199 with stride 2) as tap-table products over a space-to-depth copy of the input -- the last library code on the
+// f32_split step.  acr_space_to_depth2_f32: xs[n][(py*2+px)*C + c][y][x] = x[n][c][2y+py][2x+px], zero past the
+// image, H2 = ceil(H/2), W2 = ceil(W/2); channel rows 4C .. xrows-1 of every sample are zero (the 7x7 convolution's stage of 16
+// rows = 12 phase-channels + 4).  acr_depth_to_space2_f32 is its inverse (the input gradient's last step; H even, W % 8 == 0).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool VEC> __global__ __launch_bounds__(256) void c3_s2d_kernel(const float* __restrict__ x, float* __restrict__ xs, int C, int H, int W,
+                                                                          int H2, int W2, int xrows, int64_t nthr) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nthr) return;
+    const int wq = (W2 + 3) >> 2;
+    const int q = (int)(i % wq);
+    int64_t t = i / wq;
+    const int y = (int)(t % H2);
+    t /= H2;
+    const int c = (int)(t % C), n = (int)(t / C);
+    const float* __restrict__ xr = x + ((int64_t)n * C + c) * H * W;
+    float v[2][8];
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+        const int yy = 2 * y + py;
+        if (VEC) {                                           // W % 8 == 0: whole 32-byte groups
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+            if (yy < H) {
+                a = *reinterpret_cast<const f32x4*>(xr + (int64_t)yy * W + 8 * q);
+                b = *reinterpret_cast<const f32x4*>(xr + (int64_t)yy * W + 8 * q + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[py][e] = a[e]; v[py][4 + e] = b[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[py][e] = (yy < H && 8 * q + e < W) ? xr[(int64_t)yy * W + 8 * q + e] : 0.f;
+        }
+    }
+    const int64_t plane = (int64_t)H2 * W2;
+    float* __restrict__ o = xs + ((int64_t)n * xrows + c) * plane + (int64_t)y * W2 + 4 * q;
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            float* d = o + (int64_t)(py * 2 + px) * C * plane;
+            if (VEC) *reinterpret_cast<f32x4*>(d) = f32x4{v[py][px], v[py][px + 2], v[py][px + 4], v[py][px + 6]};
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < W2) d[e] = v[py][px + 2 * e];
+        }
+}
+// rows [r0, xrows) of every sample := 0, float4 per thread (plane % 4 == 0)
+__global__ __launch_bounds__(256) void c3_zero_rows_kernel(float* __restrict__ xs, int xrows, int r0, int64_t plane4, int64_t nthr) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nthr) return;
+    const int64_t per = (int64_t)(xrows - r0) * plane4;
+    const int64_t n = i / per, j = i - n * per;
+    reinterpret_cast<f32x4*>(xs)[(n * xrows + r0) * plane4 + j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__global__ __launch_bounds__(256) void c3_d2s_kernel(const float* __restrict__ xs, float* __restrict__ x, int C, int H, int W, int64_t nthr) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nthr) return;
+    const int H2 = H >> 1, W2 = W >> 1, wq = W2 >> 2;
+    const int q = (int)(i % wq);
+    int64_t t = i / wq;
+    const int y = (int)(t % H2);
+    t /= H2;
+    const int c = (int)(t % C), n = (int)(t / C);
+    const int64_t plane = (int64_t)H2 * W2;
+    const float* __restrict__ s = xs + ((int64_t)n * 4 * C + c) * plane + (int64_t)y * W2 + 4 * q;
+    float* __restrict__ d = x + ((int64_t)n * C + c) * H * W + (int64_t)(2 * y) * W + 8 * q;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s + (int64_t)(py * 2) * C * plane);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(s + (int64_t)(py * 2 + 1) * C * plane);
+        *reinterpret_cast<f32x4*>(d + (int64_t)py * W) = f32x4{a[0], b[0], a[1], b[1]};
+        *reinterpret_cast<f32x4*>(d + (int64_t)py * W + 4) = f32x4{a[2], b[2], a[3], b[3]};
+    }
+}
+
+extern "C" int acr_space_to_depth2_f32(const float* x, float* xs, int32_t nsamp, int32_t C, int32_t H, int32_t W, int32_t xrows, void* stream) {
+    ACR_CHECK_ARG(x && xs, "acr_space_to_depth2_f32: null pointer");
+    ACR_CHECK_ARG(nsamp > 0 && C > 0 && H > 0 && W > 0 && xrows >= 4 * C, "acr_space_to_depth2_f32: bad shape (n=%d C=%d %dx%d rows=%d)", nsamp, C, H, W, xrows);
+    const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    const bool vec = (W % 8) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)xs & 15) == 0;
+    ACR_CHECK_ARG(xrows == 4 * C || ((int64_t)H2 * W2) % 4 == 0 && ((uintptr_t)xs & 15) == 0, "acr_space_to_depth2_f32: zero rows need (H2*W2) %% 4 == 0");
+    const int64_t nthr = (int64_t)nsamp * C * H2 * ((W2 + 3) / 4);
+    ACR_CHECK_ARG((nthr + 255) / 256 < (1ll << 31), "acr_space_to_depth2_f32: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) hipLaunchKernelGGL(c3_s2d_kernel<true>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, xs, C, H, W, H2, W2, xrows, nthr);
+    else hipLaunchKernelGGL(c3_s2d_kernel<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, xs, C, H, W, H2, W2, xrows, nthr);
+    if (xrows > 4 * C) {
+        const int64_t plane4 = (int64_t)H2 * W2 / 4, nz = (int64_t)nsamp * (xrows - 4 * C) * plane4;
+        hipLaunchKernelGGL(c3_zero_rows_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, xs, xrows, 4 * C, plane4, nz);
+    }
+    return acr_check_launch("acr_space_to_depth2_f32");
+}
+extern "C" int acr_depth_to_space2_f32(const float* xs, float* x, int32_t nsamp, int32_t C, int32_t H, int32_t W, void* stream) {
+    ACR_CHECK_ARG(x && xs, "acr_depth_to_space2_f32: null pointer");
+    ACR_CHECK_ARG(nsamp > 0 && C > 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 8) == 0, "acr_depth_to_space2_f32: need H even, W %% 8 == 0 (n=%d C=%d %dx%d)", nsamp, C, H, W);
+    ACR_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)xs & 15) == 0, "acr_depth_to_space2_f32: 16-byte alignment");
+    const int64_t nthr = (int64_t)nsamp * C * (H / 2) * (W / 8);
+    ACR_CHECK_ARG((nthr + 255) / 256 < (1ll << 31), "acr_depth_to_space2_f32: grid too large");
+    hipLaunchKernelGGL(c3_d2s_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xs, x, C, H, W, nthr);
+    return acr_check_launch("acr_depth_to_space2_f32");
+}
+
+static int c3_fill_tab(C3Tab& t, const char* who, int ntap, const int32_t* tdy, const int32_t* tdx, const int32_t* tcb, int cin, int W, int xrows, int yrows) {
+    ACR_CHECK_ARG(ntap > 0 && ntap <= C3_MAXTAP && tdy && tdx && tcb, "%s: need 1 .. %d taps", who, C3_MAXTAP);
+    t.ntap = ntap; t.xrows = xrows; t.yrows = yrows; t.maxoff = 0;
+    for (int i = 0; i < C3_MAXTAP; ++i) { t.toff[i] = 0; t.tcb[i] = 0; t.tdydx[i] = 8 | (8 << 8); }
+    for (int i = 0; i < ntap; ++i) {
+        ACR_CHECK_ARG(tdy[i] >= -7 && tdy[i] <= 7 && tdx[i] >= -7 && tdx[i] <= 7 && tcb[i] >= 0 && tcb[i] + cin <= xrows,
+                      "%s: tap %d (dy=%d dx=%d rows %d..%d of %d) outside what the table encodes", who, i, tdy[i], tdx[i], tcb[i], tcb[i] + cin, xrows);
+        t.toff[i] = tdy[i] * W + tdx[i]; t.tcb[i] = tcb[i]; t.tdydx[i] = (tdy[i] + 8) | ((tdx[i] + 8) << 8);
+        const int a = t.toff[i] < 0 ? -t.toff[i] : t.toff[i];
+        if (a > t.maxoff) t.maxoff = a;
+    }
+    return ACR_OK;
+}
+
+// y[n][yrow][p] = sum_t sum_c w_img[(co, t * cin + c)] * x[n][tcb[t] + c][p + tdy[t] * W + tdx[t]] * inside(p, t) for yrow < cout:
+// the tap-table form of acr_conv3x3_x3 (same kernels, same image layout with 9 -> ntap).  x holds `xrows` channel rows per sample,
+// y `yrows` (y may point into a channel slice of a larger tensor).  tdy / tdx / tcb are HOST arrays of ntap entries.
+extern "C" size_t acr_conv_taps_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W, int32_t ntap) {
+    const int ks = c3_fwd_ksplit(nsamp, cout, cin, H * W, cout <= 64, ntap);
+    return ks > 1 ? (size_t)ks * nsamp * cout * H * W : 0;
+}
+extern "C" int acr_conv_taps_x3(const float* w_img, const float* x, float* y, int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W,
+                                int32_t ntap, const int32_t* tdy, const int32_t* tdx, const int32_t* tcb, int32_t xrows, int32_t yrows, float* ws,
+                                void* stream) {
+    ACR_CHECK_ARG(w_img && x && y, "acr_conv_taps_x3: null pointer");
+    ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && (cin % C3_BK) == 0 && H > 0 && W > 0 && ((int64_t)H * W) % 4 == 0 && yrows >= cout,
+                  "acr_conv_taps_x3: need cin %% 16 == 0, H*W %% 4 == 0, yrows >= cout (n=%d co=%d ci=%d %dx%d)", nsamp, cout, cin, H, W);
+    ACR_CHECK_ARG(((uintptr_t)w_img & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "acr_conv_taps_x3: 16-byte alignment");
+    ACR_CHECK_ARG((int64_t)xrows * H * W < (1ll << 30), "acr_conv_taps_x3: sample too large for 32-bit offsets");
+    Conv3Args g;
+    const int rc = c3_fill_tab(g.t, "acr_conv_taps_x3", ntap, tdy, tdx, tcb, cin, W, xrows, yrows);
+    if (rc != ACR_OK) return rc;
+    g.w = w_img; g.x = x; g.y = y; g.M = cout; g.C = cin; g.H = H; g.W = W; g.HW = H * W; g.nsamp = nsamp;
+    const bool wide64 = cout <= 64;
+    g.tiles_m = wide64 ? 1 : (cout + C3_BM - 1) / C3_BM; g.tiles_n = wide64 ? (g.HW + 255) / 256 : (g.HW + C3_BN - 1) / C3_BN;
+    const int nst = ntap * cin / C3_BK;
+    g.ksplit = (ws && ((uintptr_t)ws & 15) == 0 && yrows == cout) ? c3_fwd_ksplit(nsamp, cout, cin, g.HW, wide64, ntap) : 1;
+    g.sps = (nst + g.ksplit - 1) / g.ksplit; g.ws = ws;
+    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp * g.ksplit;
+    ACR_CHECK_ARG(nwg < (1ll << 31), "acr_conv_taps_x3: grid too large");
+    if (wide64) hipLaunchKernelGGL(conv3x3_wimg64_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(conv3x3_wimg_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
+    if (g.ksplit > 1) {
+        const int64_t n4 = (int64_t)nsamp * cout * g.HW / 4;
+        hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, g.ksplit, n4, y);
+    }
+    return acr_check_launch("acr_conv_taps_x3");
+}
+
+// dw_packed[co][t * cin + c] = sum_n sum_p dy[n][co][p] * x[n][tcb[t] + c][p + tdy[t] * W + tdx[t]] * inside(p, t): the tap-table form
+// of acr_conv3x3_wgrad_f32 (same kernel, slabs summed in a fixed order).
+extern "C" size_t acr_conv_taps_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W, int32_t ntap) {
+    return (size_t)nsamp * c3_wgrad_ksplit(nsamp, cout, cin, H * W, ntap) * cout * ntap * cin;
+}
+extern "C" int acr_conv_taps_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W,
+                                       int32_t ntap, const int32_t* tdy, const int32_t* tdx, const int32_t* tcb, int32_t xrows, float* ws,
+                                       float* dw_packed, void* stream) {
+    ACR_CHECK_ARG(dy && x && ws && dw_packed, "acr_conv_taps_wgrad_f32: null pointer");
+    if (math != ACR_MATH_BF16X3) {
+        acr_set_error("acr_conv_taps_wgrad_f32: built for ACR_MATH_BF16X3 only");
+        return ACR_ERR_UNSUPPORTED;
+    }
+    const int HW = H * W;
+    ACR_CHECK_ARG(nsamp > 0 && cout > 0 && cin > 0 && (cout % 4) == 0 && (cin % 4) == 0 && H > 0 && W > 0 && (W % 4) == 0 && W >= C3_BK &&
+                      (HW % C3_BK) == 0,
+                  "acr_conv_taps_wgrad_f32: need cout, cin %% 4 == 0, W %% 4 == 0, W >= 16, H*W %% 16 == 0 (n=%d co=%d ci=%d %dx%d)", nsamp, cout, cin, H, W);
+    ACR_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)dw_packed & 15) == 0,
+                  "acr_conv_taps_wgrad_f32: 16-byte alignment");
+    ACR_CHECK_ARG((int64_t)cout * HW < (1ll << 30) && (int64_t)xrows * HW < (1ll << 30), "acr_conv_taps_wgrad_f32: operand too large for 32-bit offsets");
+    Conv3WgArgs g;
+    const int rc = c3_fill_tab(g.t, "acr_conv_taps_wgrad_f32", ntap, tdy, tdx, tcb, cin, W, xrows, 0);
+    if (rc != ACR_OK) return rc;
+    g.dy = dy; g.x = x; g.ws = ws; g.M = cout; g.C = cin; g.H = H; g.W = W; g.HW = HW; g.nsamp = nsamp;
+    g.ksplit = c3_wgrad_ksplit(nsamp, cout, cin, HW, ntap);
+    g.kps = ((HW + g.ksplit - 1) / g.ksplit + 31) / 32 * 32;
+    g.tiles_m = (cout + C3_BM - 1) / C3_BM; g.tiles_n = (ntap * cin + C3_BN - 1) / C3_BN;
+    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp * g.ksplit;
+    ACR_CHECK_ARG(nwg < (1ll << 31), "acr_conv_taps_wgrad_f32: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, st, g);
+    const int64_t n4 = (int64_t)cout * ntap * cin / 4;
+    hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsamp * g.ksplit, n4, dw_packed);
+    return acr_check_launch("acr_conv_taps_wgrad_f32");
 }

@@ -1066,6 +1066,179 @@ def conv3x3(x, weight, imgs=None):
     return Conv3x3Fn.apply(x, weight, imgs)
 
 
+# ---- stride-2 SAME convolutions (7x7 stem convolution, the two stride-2 3x3s) on the tap-table kernels -------------------------
+CONV_S2_HIP = os.environ.get("ACR_CONV_S2_HIP", "1") != "0"      # A/B: strided convolutions under f32_split on csrc/conv3x3.hip vs MIOpen
+
+
+class _S2Plan:
+    """Everything a k x k stride-2 TF-SAME convolution of a C-channel H x W input needs on the space-to-depth grid
+    (include/acr_hip.h, acr_conv_taps_x3): input row u = 2*o + ky - pb (pb = the SAME padding in front) is row o + dy of pixel
+    phase py with py = (ky - pb) mod 2, dy = (ky - pb - py) / 2.
+
+    C % 16 == 0 (the 3x3s): tap t = (ky, kx) reads the C rows of ONE phase; the packed weight is the stride-1 one
+    (w[co][t*C + c]).  The input gradient is one launch per pixel phase of dx over the taps that feed it, shifts negated.
+    4C <= 16 (the stem's 7x7 on 3 channels): a tap is a (dy, dx) pair over all 4C phase-channel rows (+ zero rows up to 16);
+    the packed weight is a gather of the 147 columns (``gather``; column 147 = zero), its gradient the inverse gather."""
+
+    def __init__(self, k, C, H, W, device):
+        import ctypes
+        arr = lambda v: (ctypes.c_int32 * len(v))(*v)
+
+        def split(kk, n):
+            pb = max((-(-n // 2) - 1) * 2 + k - n, 0) // 2
+            py = (kk - pb) % 2
+            return py, (kk - pb - py) // 2
+
+        self.k, self.C = k, C
+        self.H2, self.W2 = (H + 1) // 2, (W + 1) // 2
+        ys, xs = [split(ky, H) for ky in range(k)], [split(kx, W) for kx in range(k)]
+        if C % 16 == 0:
+            self.cin, self.xrows, self.gather = C, 4 * C, None
+            tdy = [ys[t // k][1] for t in range(k * k)]
+            tdx = [xs[t % k][1] for t in range(k * k)]
+            phase = [ys[t // k][0] * 2 + xs[t % k][0] for t in range(k * k)]
+            self.ntap = k * k
+            self.fwd = (arr(tdy), arr(tdx), arr([p * C for p in phase]))
+            self.order, self.phases = [], []                 # input gradient: (phase, first tap slot, ntap, tables)
+            for p in range(4):
+                taps = [t for t in range(k * k) if phase[t] == p]
+                self.phases.append((p, len(self.order), len(taps), (arr([-tdy[t] for t in taps]), arr([-tdx[t] for t in taps]), arr([0] * len(taps)))))
+                self.order += taps
+            self.order_t = torch.tensor(self.order, device=device)
+        else:
+            assert 4 * C <= 16
+            self.cin, self.xrows, self.phases = 16, 16, None
+            dys, dxs = sorted(set(d for _, d in ys)), sorted(set(d for _, d in xs))
+            self.ntap = len(dys) * len(dxs)
+            assert self.ntap <= 16
+            kyof = {(py, d): ky for ky, (py, d) in enumerate(ys)}
+            kxof = {(px, d): kx for kx, (px, d) in enumerate(xs)}
+            gather = []
+            for d in dys:
+                for e in dxs:
+                    for row in range(16):
+                        py, px, c = row // (2 * C), (row // C) % 2, row % C
+                        ky, kx = kyof.get((py, d)), kxof.get((px, e))
+                        gather.append(c * k * k + ky * k + kx if row < 4 * C and ky is not None and kx is not None else C * k * k)
+            self.fwd = (arr([d for d in dys for _ in dxs]), arr([e for _ in dys for e in dxs]), arr([0] * self.ntap))
+            self.gather = torch.tensor(gather, device=device)
+            inv = [0] * (C * k * k)
+            for j, g in enumerate(gather):
+                if g < C * k * k:
+                    inv[g] = j
+            self.scatter = torch.tensor(inv, device=device)
+
+    def pack(self, w):
+        """(cout, ntap*cin) operand of the forward product."""
+        co = w.shape[0]
+        if self.gather is None:
+            return w.permute(0, 2, 3, 1).reshape(co, self.k * self.k * self.C).contiguous()
+        return torch.cat([w.reshape(co, -1), w.new_zeros(co, 1)], 1).index_select(1, self.gather)
+
+    def pack_dgrad(self, w):
+        """(cin, 9, cout) with the taps grouped by the pixel phase they feed: phase p's operand is rows x [first*cout, (first+n)*cout)."""
+        co, ci = w.shape[0], w.shape[1]
+        return w.reshape(co, ci, self.k * self.k).index_select(2, self.order_t).permute(1, 2, 0).contiguous()
+
+    def dgrad_specs(self, wd):
+        ci, _, co = wd.shape
+        return tuple((wd, first * co, ci, n * co, self.k * self.k * co, n * co, 0, 1) for _, first, n, _ in self.phases)
+
+    def unpack_grad(self, dwp, shape):
+        co, ci = shape[0], shape[1]
+        if self.gather is None:
+            return dwp.view(co, self.k, self.k, ci).permute(0, 3, 1, 2)
+        return dwp.index_select(1, self.scatter).view(shape)
+
+
+_S2_PLANS = {}
+
+
+def conv_s2_plan(k, C, H, W, device):
+    key = (k, C, H % 2, W % 2, H, W, str(device))
+    p = _S2_PLANS.get(key)
+    if p is None:
+        p = _S2_PLANS[key] = _S2Plan(k, C, H, W, device)
+    return p
+
+
+def conv_s2_fusable(x, weight, stride, math):
+    """fp32 NCHW k x k stride-2 SAME convolution with split products that the tap-table kernels cover (k = 3 on C % 16 == 0 channels,
+    k = 7 on <= 4): forward always; with gradients only on the shapes the weight-gradient kernel and the depth-to-space pass take."""
+    if not (CONV_S2_HIP and math == 1 and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and stride == 2
+            and x.is_contiguous() and not torch.is_autocast_enabled() and weight.shape[2] == weight.shape[3]):
+        return False
+    k, C, (H, W) = weight.shape[2], x.shape[1], x.shape[2:]
+    if not ((k == 3 and C % 16 == 0 and weight.shape[0] % 16 == 0) or (k == 7 and 4 * C <= 16 and weight.shape[0] % 16 == 0)):
+        return False
+    H2, W2 = (H + 1) // 2, (W + 1) // 2
+    if (H2 * W2) % 4 != 0:
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return H % 2 == 0 and W % 8 == 0 and W2 >= 16 and (H2 * W2) % 16 == 0
+    return True
+
+
+def _conv_taps(wi, x, y, y_ptr, N, co, ci, H, W, ntap, tab, xrows, yrows):
+    lib = L.load()
+    nws = lib.acr_conv_taps_ws_floats(N, co, ci, H, W, ntap) if yrows == co else 0
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+    L.check(lib.acr_conv_taps_x3(L.ptr(wi), L.ptr(x), y_ptr, N, co, ci, H, W, ntap, tab[0], tab[1], tab[2], xrows, yrows, L.ptr(ws), L.stream_ptr()),
+            "acr_conv_taps_x3")
+
+
+class ConvS2Fn(Function):
+    """k x k stride-2 SAME convolution in NCHW fp32 with split products (csrc/conv3x3.hip, tap-table kernels): a space-to-depth
+    copy of the input, then forward / input gradient (one launch per pixel phase + depth-to-space) / weight gradient as implicit
+    GEMMs -- what the reference runs as F.pad + F.conv2d (models/layers/std_conv.py:56-65).  ``imgs``: (forward image, the four
+    phase images of the input gradient) of the weight for EVEN H, W, or None (built here)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, imgs=None):
+        N, C, H, W = x.shape
+        co, k = weight.shape[0], weight.shape[2]
+        lib = L.load()
+        plan = conv_s2_plan(k, C, H, W, x.device)
+        if imgs is not None and (H % 2 or W % 2):
+            imgs = None                                      # the cached images are those of the even-size tap layout
+        xs = torch.empty((N, plan.xrows, plan.H2, plan.W2), dtype=torch.float32, device=x.device)
+        L.check(lib.acr_space_to_depth2_f32(L.ptr(x), L.ptr(xs), N, C, H, W, plan.xrows, L.stream_ptr()), "acr_space_to_depth2_f32")
+        wi = imgs[0] if imgs else x3_image(plan.pack(weight.detach()))
+        y = torch.empty((N, co, plan.H2, plan.W2), dtype=torch.float32, device=x.device)
+        _conv_taps(wi, xs, y, L.ptr(y), N, co, plan.cin, plan.H2, plan.W2, plan.ntap, plan.fwd, plan.xrows, co)
+        ctx.save_for_backward(xs, weight)
+        ctx.plan, ctx.imgs, ctx.xshape = plan, imgs, (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, weight = ctx.saved_tensors
+        plan, (N, C, H, W) = ctx.plan, ctx.xshape
+        co = weight.shape[0]
+        lib = L.load()
+        dy = (dy if dy.dtype == torch.float32 else dy.float()).contiguous()
+        H2, W2 = plan.H2, plan.W2
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            pim = ctx.imgs[1:] if ctx.imgs else x3_image_many(plan.dgrad_specs(plan.pack_dgrad(weight.detach())), dy.device)
+            dxs = torch.empty((N, 4 * C, H2, W2), dtype=torch.float32, device=dy.device)
+            for (p, _, n, tab), im in zip(plan.phases, pim):
+                _conv_taps(im, dy, dxs, L.c_void_p(dxs.data_ptr() + 4 * p * C * H2 * W2), N, C, co, H2, W2, n, tab, co, 4 * C)
+            dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+            L.check(lib.acr_depth_to_space2_f32(L.ptr(dxs), L.ptr(dx), N, C, H, W, L.stream_ptr()), "acr_depth_to_space2_f32")
+        if ctx.needs_input_grad[1]:
+            ws = torch.empty(lib.acr_conv_taps_wgrad_ws_floats(N, co, plan.cin, H2, W2, plan.ntap), dtype=torch.float32, device=dy.device)
+            dwp = torch.empty((co, plan.ntap * plan.cin), dtype=torch.float32, device=dy.device)
+            L.check(lib.acr_conv_taps_wgrad_f32(1, L.ptr(dy), L.ptr(xs), N, co, plan.cin, H2, W2, plan.ntap, plan.fwd[0], plan.fwd[1], plan.fwd[2],
+                                                plan.xrows, L.ptr(ws), L.ptr(dwp), L.stream_ptr()), "acr_conv_taps_wgrad_f32")
+            dw = plan.unpack_grad(dwp, weight.shape)
+        return dx, dw, None
+
+
+def conv_s2(x, weight, imgs=None):
+    return ConvS2Fn.apply(x, weight, imgs)
+
+
 def conv1x1(x, weight, wt=None, math=0, imgs=None):
     return Conv1x1Fn.apply(x, weight, wt, math, imgs)[0]
 

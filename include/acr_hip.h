@@ -302,6 +302,29 @@ size_t acr_conv3x3_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int
 int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W,
                           float* ws, float* dw_packed, void* stream);
 
+/* ---- strided SAME convolutions of the stem under split products: the 7x7 stride-2 stem convolution (models/resnetv2.py:337-340 via
+ * models/layers/std_conv.py:40-65) and conv2 of the first bottleneck of stages 1 and 2 (3x3 stride 2, resnetv2.py:196-199), which the
+ * reference hands to cuDNN through F.conv2d on a padded copy.  Here: one space-to-depth pass, then the 3x3 kernels driven by a TAP TABLE.
+ * acr_space_to_depth2_f32: xs[n][(py*2+px)*C + c][y][x] = x[n][c][2y+py][2x+px] (zero past the image), a half-resolution grid of
+ *   H2 = ceil(H/2) x W2 = ceil(W/2) with `xrows` >= 4C channel rows per sample, rows 4C.. zeroed.  acr_depth_to_space2_f32: the inverse
+ *   (xrows = 4C; H even, W % 8 == 0).
+ * acr_conv_taps_x3: y[n][co][p] = sum_t sum_c W[co][t*cin + c] * x[n][tcb[t] + c][p + tdy[t]*W + tdx[t]], zero where (py + tdy[t], px + tdx[t])
+ *   leaves the H x W grid; w_img = acr_x3_image of W (rows = cout, cols = ntap*cin); x has xrows channel rows per sample, y has yrows
+ *   (>= cout: y may point at a channel slice of a larger tensor -- the input gradient writes one pixel phase per launch);
+ *   tdy / tdx / tcb: HOST arrays of ntap <= 16 entries, |tdy|, |tdx| <= 7.  cin % 16 == 0, H*W % 4 == 0.  ws as acr_conv3x3_x3
+ *   (acr_conv_taps_ws_floats; ignored when yrows != cout).  No byte outside [x, x + nsamp*xrows*H*W) is addressed.
+ * acr_conv_taps_wgrad_f32: dw_packed[co][t*cin + c] = sum_n sum_p dy[n][co][p] * x[n][tcb[t] + c][p + tdy[t]*W + tdx[t]] (same zeros);
+ *   W % 4 == 0, W >= 16, H*W % 16 == 0; ws = acr_conv_taps_wgrad_ws_floats floats (slabs, summed in a fixed order). */
+int acr_space_to_depth2_f32(const float* x, float* xs, int32_t nsamp, int32_t C, int32_t H, int32_t W, int32_t xrows, void* stream);
+int acr_depth_to_space2_f32(const float* xs, float* x, int32_t nsamp, int32_t C, int32_t H, int32_t W, void* stream);
+size_t acr_conv_taps_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W, int32_t ntap);
+int acr_conv_taps_x3(const float* w_img, const float* x, float* y, int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W, int32_t ntap,
+                     const int32_t* tdy, const int32_t* tdx, const int32_t* tcb, int32_t xrows, int32_t yrows, float* ws, void* stream);
+size_t acr_conv_taps_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W, int32_t ntap);
+int acr_conv_taps_wgrad_f32(int32_t math, const float* dy, const float* x, int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W,
+                            int32_t ntap, const int32_t* tdy, const int32_t* tdx, const int32_t* tcb, int32_t xrows, float* ws, float* dw_packed,
+                            void* stream);
+
 /* ---- 3x3 stride-2 max-pool of the stem with TF-SAME -inf padding folded in (models/resnetv2.py:322-328) ----
  * x (nc, h, w) -> y (nc, ho, wo); amax = 1-byte window argmax (i*3+j, first maximum like ATen) kept for the backward,
  * which gathers (no atomics).  Window (ho, wo) starts at (2 ho - pad_top, 2 wo - pad_left). */

@@ -1162,6 +1162,142 @@ def test_conv3x3_reads_nothing_outside_its_input():
     assert (dwp.permute(0, 3, 1, 2).double() - wdbl.grad).abs().max() <= 1e-5 * wdbl.grad.abs().max()
 
 
+def _same_conv_ref(xd, wd, stride):
+    """fp64 TF-SAME convolution as the reference computes it: F.pad (odd pixel right / bottom) + F.conv2d (std_conv.py:56-65)."""
+    import math
+    import torch.nn.functional as F
+    k = wd.shape[2]
+    pads = []
+    for n in (xd.shape[3], xd.shape[2]):
+        t = max((math.ceil(n / stride) - 1) * stride + k - n, 0)
+        pads += [t // 2, t - t // 2]
+    return F.conv2d(F.pad(xd, pads), wd, stride=stride)
+
+
+@pytest.mark.parametrize("N,cin,cout,k,H,W,grads", [(2, 128, 128, 3, 112, 112, True), (2, 256, 256, 3, 56, 56, True), (3, 32, 48, 3, 40, 64, True),
+                                                   (2, 3, 64, 7, 448, 448, True), (2, 3, 64, 7, 64, 96, True), (32, 128, 128, 3, 112, 112, True),
+                                                   (2, 64, 64, 3, 57, 79, False), (2, 32, 32, 3, 58, 79, False), (2, 3, 64, 7, 183, 250, False),
+                                                   (1, 3, 64, 7, 250, 183, False), (2, 3, 64, 7, 24, 40, False)])
+def test_conv_s2_split(N, cin, cout, k, H, W, grads):
+    """The strided SAME convolutions of the stem under split products (ops.ConvS2Fn: space-to-depth + the tap-table forms of the 3x3
+    kernels): the two stride-2 3x3 convolutions at their training shapes (and at the full batch), the 7x7 stem convolution at
+    448 x 448, small and non-square maps; forward, input gradient (four phase launches + depth-to-space) and weight gradient vs
+    fp64 pad + conv2d.  Forward-only cases: odd heights / widths (CAM generation's scales; the SAME padding in front is then 1 resp.
+    3 and the tap table a different one), launches small enough for the K-split slabs."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + H + k)
+    x = torch.randn(N, cin, H, W, generator=g).to(dev).requires_grad_(grads and cin > 3)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (k * k * cin) ** -0.5).to(dev).requires_grad_(grads)
+    with torch.set_grad_enabled(grads):
+        assert ops.conv_s2_fusable(x, w, 2, 1) and not ops.conv_s2_fusable(x, w, 2, 0) and not ops.conv_s2_fusable(x, w, 1, 1)
+        y = ops.conv_s2(x, w)
+    xd, wd = x.detach().double().requires_grad_(x.requires_grad), w.detach().double().requires_grad_(grads)
+    ref = _same_conv_ref(xd, wd, 2)
+    assert y.shape == ref.shape
+    pairs = [("y", y, ref)]
+    if grads:
+        dy = torch.randn(y.shape, generator=g).to(dev)
+        (y * dy).sum().backward()
+        (ref * dy.double()).sum().backward()
+        pairs.append(("dw", w.grad, wd.grad))
+        if x.requires_grad:
+            pairs.append(("dx", x.grad, xd.grad))
+    for n, a, b in pairs:
+        err = (a.double() - b).abs().max() / b.abs().max()
+        assert err <= 1e-5, (n, float(err))
+    # exact zero padding: a one-hot input answers with single kernel entries, zero elsewhere
+    x1 = torch.zeros(1, cin, H, W, device=dev)
+    x1[0, 1, 0, 0] = 1.0
+    x1[0, 2, H - 1, W - 1] = 1.0
+    with torch.no_grad():
+        y1 = ops.conv_s2(x1, w.detach())
+    r1 = _same_conv_ref(x1.double(), w.detach().double(), 2)
+    assert (y1.double() - r1).abs().max() <= 1e-6 * r1.abs().max() and torch.equal(y1 == 0, r1 == 0)
+    if grads:                                               # bitwise reproducible
+        x2 = x.detach().clone().requires_grad_(x.requires_grad)
+        w2 = w.detach().clone().requires_grad_(True)
+        y2 = ops.conv_s2(x2, w2)
+        (y2 * dy).sum().backward()
+        assert torch.equal(y2, y) and torch.equal(w2.grad, w.grad) and (not x.requires_grad or torch.equal(x2.grad, x.grad))
+
+
+def test_conv_s2_group_images_and_exact_fit_block():
+    """(i) The images StdConv2dSame.image_specs describes for the stride-2 convolutions (made with everybody else's in ONE
+    acr_x3_image_many launch) give bit for bit what ops.ConvS2Fn builds for itself.  (ii) The tap-table kernels read nothing outside
+    their input: the space-to-depth tensor IS a whole 16 MiB hipMalloc block (as in test_conv3x3_reads_nothing_outside_its_input),
+    forward and weight gradient called through the C ABI on exactly that pointer; dy of the input-gradient launches likewise."""
+    from acr_wsss_amd import _lib as L, ops
+    from acr_wsss_amd.backbone import StdConv2dSame
+    dev = _dev()
+    lib = L.load()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for k, ci, co, hw in ((3, 32, 48, 32), (7, 3, 64, 64)):
+        conv = StdConv2dSame(ci, co, k, stride=2).to(dev)
+        conv.acr_math = 1
+        w = (torch.randn(co, ci, k, k, generator=g) * 0.1).to(dev).requires_grad_(True)
+        imgs = tuple(ops.x3_image_many(list(conv.image_specs(w.detach())), dev))
+        assert len(imgs) == (5 if k == 3 else 1)
+        x = torch.randn(2, ci, hw, hw, generator=g).to(dev).requires_grad_(k == 3)
+        outs = []
+        for im in (None, imgs):
+            x.grad = w.grad = None
+            y = ops.conv_s2(x, w, im)
+            y.square().sum().backward()
+            outs.append((y.detach(), w.grad.clone(), x.grad.clone() if k == 3 else None))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert k == 7 or torch.equal(outs[0][2], outs[1][2])
+    # (ii) exact-fit blocks
+    N, C, H2, W2 = 2, 64, 128, 64                           # xs: N x 4C x H2 x W2 floats = 16 MiB
+    pool = torch.cuda.MemPool()
+    with torch.cuda.use_mem_pool(pool):
+        xs = torch.empty(N * 4 * C * H2 * W2, dtype=torch.float32, device=dev)
+        dyb = torch.empty(16 << 18, dtype=torch.float32, device=dev)           # dy of the input gradient: co = 256 rows
+    for t in (xs, dyb):
+        seg = [b for b in torch.cuda.memory_snapshot() if b["address"] <= t.data_ptr() < b["address"] + b["total_size"]]
+        assert seg and seg[0]["address"] == t.data_ptr() and seg[0]["total_size"] == 16 << 20, "the tensor must fill its hipMalloc block"
+    x = torch.randn(N, C, 2 * H2, 2 * W2, generator=g).to(dev)
+    L.check(lib.acr_space_to_depth2_f32(L.ptr(x), L.ptr(xs), N, C, 2 * H2, 2 * W2, 4 * C, L.stream_ptr()), "s2d")
+    xs4 = xs.view(N, 4 * C, H2, W2)
+    for py in range(2):
+        for px in range(2):
+            assert torch.equal(xs4[:, (py * 2 + px) * C:(py * 2 + px + 1) * C], x[:, :, py::2, px::2])
+    back = torch.empty_like(x)
+    L.check(lib.acr_depth_to_space2_f32(L.ptr(xs), L.ptr(back), N, C, 2 * H2, 2 * W2, L.stream_ptr()), "d2s")
+    assert torch.equal(back, x)
+    w = (torch.randn(C, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(dev)
+    plan = ops.conv_s2_plan(3, C, 2 * H2, 2 * W2, dev)
+    y = torch.empty(N, C, H2, W2, device=dev)
+    L.check(lib.acr_conv_taps_x3(L.ptr(ops.x3_image(plan.pack(w))), L.ptr(xs), L.ptr(y), N, C, C, H2, W2, 9, plan.fwd[0], plan.fwd[1], plan.fwd[2],
+                                 4 * C, C, None, L.stream_ptr()), "acr_conv_taps_x3")
+    ref = _same_conv_ref(x.double(), w.double(), 2)
+    assert (y.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    dy = torch.randn(N, C, H2, W2, generator=g).to(dev)
+    ws = torch.empty(lib.acr_conv_taps_wgrad_ws_floats(N, C, C, H2, W2, 9), device=dev)
+    dwp = torch.empty(C, 9 * C, device=dev)
+    L.check(lib.acr_conv_taps_wgrad_f32(1, L.ptr(dy), L.ptr(xs), N, C, C, H2, W2, 9, plan.fwd[0], plan.fwd[1], plan.fwd[2], 4 * C, L.ptr(ws), L.ptr(dwp),
+                                        L.stream_ptr()), "acr_conv_taps_wgrad_f32")
+    wdbl = w.double().requires_grad_(True)
+    (_same_conv_ref(x.double(), wdbl, 2) * dy.double()).sum().backward()
+    assert (plan.unpack_grad(dwp, w.shape).double() - wdbl.grad).abs().max() <= 1e-5 * wdbl.grad.abs().max()
+    # input gradient: dy (N x 256 x 64 x 128 floats = 16 MiB exactly) read with negative shifts by the phase launches
+    co2, ci2, hh, wh = 256, 32, 64, 128
+    dy2 = dyb.view(N, co2, hh, wh)
+    dy2.copy_(torch.randn(dy2.shape, generator=g))
+    w2 = (torch.randn(co2, ci2, 3, 3, generator=g) * (9 * ci2) ** -0.5).to(dev)
+    plan2 = ops.conv_s2_plan(3, ci2, 2 * hh, 2 * wh, dev)
+    pim = ops.x3_image_many(plan2.dgrad_specs(plan2.pack_dgrad(w2)), dev)
+    dxs = torch.empty(N, 4 * ci2, hh, wh, device=dev)
+    for (p, _, n, tab), im in zip(plan2.phases, pim):
+        L.check(lib.acr_conv_taps_x3(L.ptr(im), L.ptr(dy2), L.c_void_p(dxs.data_ptr() + 4 * p * ci2 * hh * wh), N, ci2, co2, hh, wh, n, tab[0], tab[1],
+                                     tab[2], co2, 4 * ci2, None, L.stream_ptr()), "acr_conv_taps_x3 (dX)")
+    dx = torch.empty(N, ci2, 2 * hh, 2 * wh, device=dev)
+    L.check(lib.acr_depth_to_space2_f32(L.ptr(dxs), L.ptr(dx), N, ci2, 2 * hh, 2 * wh, L.stream_ptr()), "d2s")
+    xin = torch.zeros(N, ci2, 2 * hh, 2 * wh, dtype=torch.float64, device=dev, requires_grad=True)
+    (_same_conv_ref(xin, w2.double(), 2) * dy2.double()).sum().backward()
+    assert (dx.double() - xin.grad).abs().max() <= 1e-5 * xin.grad.abs().max()
+
+
 @pytest.mark.parametrize("dtype,math", [(torch.float32, 0), (torch.float32, 1), (torch.bfloat16, 0)])
 def test_stem_kernels_full_size_are_per_sample(dtype, math):
     """GroupNorm (+ residual + ReLU) and the NCHW 1x1 convolution at the largest launches of the BASELINE step (32 views, 256 channels
