@@ -725,6 +725,169 @@ template <bool TAB> __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_spli
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The weight gradient for at most 64 output channels (stage 0's 3x3s: cout = 64, 9 C = 576; the 7x7 stem convolution: 64 x 256):
+// in the 128 x 128 tile above the lower wave row has no dy rows and half the workgroup only feeds the DMA.  Here the tile is 64 dy
+// rows x 256 (tap, channel) rows: every wave multiplies the same 64 dy rows by its own 64 B rows.  Ring of 3 slots x [A 4 KiB | B
+// 16 KiB], DMA two stages ahead, 5 pieces per wave and stage (A piece `wave`, B pieces 4 wave ..), counted vmcnt.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define C3G_BN 256
+#define C3G_A (64 * C3_BK)                                   // floats
+#define C3G_STAGE (C3G_A + C3G_BN * C3_BK)                   // 5120 floats = 20 KiB
+template <bool TAB> __global__ __launch_bounds__(256, 2) void conv3x3_wgrad64_kernel(const Conv3WgArgs g) {
+    __shared__ __attribute__((aligned(1024))) float smem[3 * C3G_STAGE];               // 60 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int ntile = g.tiles_n, nsplit = g.nsamp * g.ksplit;
+    const int t0 = acr_xcd_remap(blockIdx.x, ntile * nsplit);
+    const int split = t0 / ntile, tn = t0 - split * ntile;
+    const int n0 = tn * C3G_BN;
+    const int sample = split / g.ksplit;
+    const int kbeg = (split - sample * g.ksplit) * g.kps, kend = min(g.HW, kbeg + g.kps);        // host: (kend - kbeg) % 16 == 0
+    const int N9 = (TAB ? g.t.ntap : 9) * g.C;
+    const int xrows = TAB ? g.t.xrows : g.C, maxoff = TAB ? g.t.maxoff : g.W + 1;
+    const float* __restrict__ pa = g.dy + (int64_t)sample * g.M * g.HW;
+    const float* __restrict__ pb = g.x + (int64_t)sample * xrows * g.HW;
+    const bool compute = n0 + wave * 64 < N9;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // DMA pieces: 16 rows x 64 bytes, lane -> (row = l >> 2, 16-byte chunk l & 3), chunk XOR-swizzled by (row >> 2) & 3 on the source
+    int offa, offb[4];
+    {
+        const int row = wave * 16 + (lane >> 2);
+        offa = min(row, g.M - 1) * g.HW + (((lane & 3) ^ ((row >> 2) & 3)) << 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 16 + (lane >> 2);
+        const int lc4 = ((lane & 3) ^ ((row >> 2) & 3)) << 2;
+        const int nr = min(n0 + row, N9 - 1);               // (tap, channel) row of B
+        const int tap = nr / g.C, ci = nr - tap * g.C;
+        const int ty = tap / 3;
+        offb[i] = TAB ? (g.t.tcb[tap] + ci) * g.HW + g.t.toff[tap] + lc4 : ci * g.HW + (ty - 1) * g.W + (tap - 3 * ty - 1) + lc4;
+    }
+    int tyj[2], txj[2];                                     // the lane's two B fragments: rows n0 + wave*64 + j*32 + r -> their shifts
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nr = min(n0 + wave * 64 + j * 32 + r, N9 - 1);
+        const int tap = nr / g.C;
+        if (TAB) { tyj[j] = (g.t.tdydx[tap] & 255) - 8; txj[j] = (g.t.tdydx[tap] >> 8) - 8; }
+        else { tyj[j] = tap / 3 - 1; txj[j] = tap - 3 * (tap / 3) - 1; }
+    }
+    int xh0 = (kbeg + 8 * h) % g.W, xh1 = (kbeg + 8 * h + 4) % g.W;      // column of the first pixel of the lane's two halves
+    const int nst = (kend - kbeg) / C3_BK;
+    const int64_t total = (int64_t)g.nsamp * xrows * g.HW;
+    const bool edge = (sample == 0 && kbeg < maxoff) || (sample == g.nsamp - 1 && kend + maxoff > g.HW);
+    auto issue = [&](int st, int slot) {
+        float* d = smem + slot * C3G_STAGE;
+        const int k0 = kbeg + st * C3_BK;
+        __builtin_amdgcn_global_load_lds((c3_glb_vp)(pa + k0 + offa), (c3_lds_vp)(d + wave * 256), 16, 0, 0);
+        if (edge) {                                          // uniform (see c3_dma_careful)
+            const int64_t i0 = (int64_t)sample * xrows * g.HW + k0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c3_dma_careful(g.x, i0 + offb[i], total, d + C3G_A + (wave * 4 + i) * 256, lane);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((c3_glb_vp)(pb + k0 + offb[i]), (c3_lds_vp)(d + C3G_A + (wave * 4 + i) * 256), 16, 0, 0);
+    };
+    issue(0, 0);
+    issue(min(1, nst - 1), 1);
+    bf16x8 ap[2][2][3], bp[2][2][3];
+    f32x4 ra[2][2], rb[2][2];
+    auto step = [&](int st, int slot, auto set_tag, auto first_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        // stage st has landed when at most the 5 pieces of stage st + 1 are outstanding (the careful path's extra operations only
+        // make the wait stricter; its plain LDS stores are covered by lgkmcnt)
+        asm volatile("s_waitcnt vmcnt(5)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        acr_barrier_nofence();
+        issue(min(st + 2, nst - 1), slot == 0 ? 2 : slot - 1);      // past the end: the last stage again, into a slot nobody reads
+        if (!compute) return;
+        const float* sa = smem + slot * C3G_STAGE;
+        const float* sb = sa + C3G_A;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 32 + r, sw = (row >> 2) & 3;
+            ra[i][0] = *reinterpret_cast<const f32x4*>(sa + row * C3_BK + (((2 * h) ^ sw) << 2));
+            ra[i][1] = *reinterpret_cast<const f32x4*>(sa + row * C3_BK + (((2 * h + 1) ^ sw) << 2));
+        }
+        const int p0 = kbeg + st * C3_BK + 8 * h;           // first pixel of the lane's fragment
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wave * 64 + j * 32 + r, sw = (row >> 2) & 3;
+            rb[j][0] = *reinterpret_cast<const f32x4*>(sb + row * C3_BK + (((2 * h) ^ sw) << 2));
+            rb[j][1] = *reinterpret_cast<const f32x4*>(sb + row * C3_BK + (((2 * h + 1) ^ sw) << 2));
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int p = p0 + 4 * hf, xc = hf ? xh1 : xh0;
+                f32x4 v = rb[j][hf];
+                const int pr = p + tyj[j] * g.W;             // the half's row moves as a whole, its columns one by one
+                if (pr < 0 || pr >= g.HW) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (TAB) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = xc + e + txj[j];
+                        if (col < 0 || col >= g.W) v[e] = 0.f;
+                    }
+                } else {
+                    if (txj[j] < 0 && xc == 0) v[0] = 0.f;
+                    if (txj[j] > 0 && xc + 4 == g.W) v[3] = 0.f;
+                }
+                rb[j][hf] = v;
+            }
+        }
+        xh0 += C3_BK; if (xh0 >= g.W) xh0 -= g.W;
+        xh1 += C3_BK; if (xh1 >= g.W) xh1 -= g.W;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) c3_split3(ra[i][0], ra[i][1], ap[SET][i][0], ap[SET][i][1], ap[SET][i][2]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c3_split3(rb[j][0], rb[j][1], bp[SET][j][0], bp[SET][j][1], bp[SET][j][2]);
+        if (!FIRST) {
+            C3_ALL(SET ^ 1)
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    step(0, 0, std::integral_constant<int, 0>{}, std::true_type{});
+    int slot = 1;
+    for (int st = 1; st < nst; st += 2) {
+        step(st, slot, std::integral_constant<int, 1>{}, std::false_type{});
+        slot = slot == 2 ? 0 : slot + 1;
+        if (st + 1 < nst) {
+            step(st + 1, slot, std::integral_constant<int, 0>{}, std::false_type{});
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end (nobody may leave LDS-DMA in flight)
+    if (!compute) return;
+    if (nst & 1) { C3_ALL(0) } else { C3_ALL(1) }
+    float* slab = g.ws + (int64_t)split * g.M * N9;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wave * 64 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i * 32 + acr_krow(e, h);
+                if (row < g.M && col < N9) slab[(int64_t)row * N9 + col] = acc[i][j][e];
+            }
+        }
+}
+
 // out[i] = sum_s slab[s][i] in slab order (deterministic), float4 per thread
 __global__ __launch_bounds__(256) void conv3x3_reduce_kernel(const float* __restrict__ ws, int nslab, int64_t n4, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -738,7 +901,7 @@ __global__ __launch_bounds__(256) void conv3x3_reduce_kernel(const float* __rest
 }
 
 static int c3_wgrad_ksplit(int nsamp, int cout, int cin, int HW, int ntap = 9) {
-    const int tiles = ((cout + C3_BM - 1) / C3_BM) * ((ntap * cin + C3_BN - 1) / C3_BN) * nsamp;
+    const int tiles = (cout <= 64 ? (ntap * cin + C3G_BN - 1) / C3G_BN : ((cout + C3_BM - 1) / C3_BM) * ((ntap * cin + C3_BN - 1) / C3_BN)) * nsamp;
     int ks = 512 / tiles;
     const int maxs = HW / 1024;
     if (ks > maxs) ks = maxs;
@@ -768,11 +931,13 @@ extern "C" int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float*
     g.dy = dy; g.x = x; g.ws = ws; g.M = cout; g.C = cin; g.H = H; g.W = W; g.HW = HW; g.nsamp = nsamp;
     g.ksplit = c3_wgrad_ksplit(nsamp, cout, cin, HW);
     g.kps = ((HW + g.ksplit - 1) / g.ksplit + 31) / 32 * 32;
-    g.tiles_m = (cout + C3_BM - 1) / C3_BM; g.tiles_n = (9 * cin + C3_BN - 1) / C3_BN;
+    const bool wide64 = cout <= 64;                         // 64 x 256 tiles: all four waves compute (conv3x3_wgrad64_kernel)
+    g.tiles_m = wide64 ? 1 : (cout + C3_BM - 1) / C3_BM; g.tiles_n = wide64 ? (9 * cin + C3G_BN - 1) / C3G_BN : (9 * cin + C3_BN - 1) / C3_BN;
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp * g.ksplit;
     ACR_CHECK_ARG(nwg < (1ll << 31), "acr_conv3x3_wgrad_f32: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, st, g);
+    if (wide64) hipLaunchKernelGGL(conv3x3_wgrad64_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, st, g);
     const int64_t n4 = (int64_t)cout * 9 * cin / 4;
     hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsamp * g.ksplit, n4,
                        dw_packed);
@@ -1031,11 +1196,13 @@ extern "C" int acr_conv_taps_wgrad_f32(int32_t math, const float* dy, const floa
     g.dy = dy; g.x = x; g.ws = ws; g.M = cout; g.C = cin; g.H = H; g.W = W; g.HW = HW; g.nsamp = nsamp;
     g.ksplit = c3_wgrad_ksplit(nsamp, cout, cin, HW, ntap);
     g.kps = ((HW + g.ksplit - 1) / g.ksplit + 31) / 32 * 32;
-    g.tiles_m = (cout + C3_BM - 1) / C3_BM; g.tiles_n = (ntap * cin + C3_BN - 1) / C3_BN;
+    const bool wide64 = cout <= 64;
+    g.tiles_m = wide64 ? 1 : (cout + C3_BM - 1) / C3_BM; g.tiles_n = wide64 ? (ntap * cin + C3G_BN - 1) / C3G_BN : (ntap * cin + C3_BN - 1) / C3_BN;
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * nsamp * g.ksplit;
     ACR_CHECK_ARG(nwg < (1ll << 31), "acr_conv_taps_wgrad_f32: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, st, g);
+    if (wide64) hipLaunchKernelGGL(conv3x3_wgrad64_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, st, g);
     const int64_t n4 = (int64_t)cout * ntap * cin / 4;
     hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsamp * g.ksplit, n4, dw_packed);
     return acr_check_launch("acr_conv_taps_wgrad_f32");
