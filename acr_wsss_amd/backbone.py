@@ -398,11 +398,11 @@ class Attention(nn.Module):
     acr_math = 0            # _lib.MATH code of the fp32 products: Linears and, in training, the attention core (set_math)
     keep_state_in_training = False      # True: get_attn() / get_attn_gradients() also work after a train()-mode forward
 
-    def forward(self, x, stack=None, layer=0, resid=None):
+    def forward(self, x, stack=None, layer=0, resid=None, x_image=None):
         """Returns proj(attention(qkv(x))) (+ resid when given: the block's residual add is fused into the
-        proj GEMM epilogue on the bf16 path)."""
+        proj GEMM epilogue on the bf16 path).  ``x_image``: x is the output of ops.layer_norm_image (it exists only as that image)."""
         self._override = {}
-        qkv = ops.linear_or_hip(x, self.qkv, None, self.hip_linear, math=self.acr_math)  # packed (B, T, 3*H*64): no permute copy
+        qkv = ops.linear_or_hip(x, self.qkv, None, self.hip_linear, math=self.acr_math, x_image=x_image)  # packed (B, T, 3*H*64): no permute copy
         o, self.last_pm = ops.attention_core(qkv, self.num_heads, stack, layer, self, self.acr_math)
         return ops.linear_or_hip(o, self.proj, resid, self.hip_linear, math=self.acr_math)
 
@@ -451,6 +451,14 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x, stack=None, layer=0):
+        math = self.attn.acr_math
+        if (Attention.hip_linear and Mlp.fused and isinstance(self.mlp.act, nn.GELU) and ops.ln_image_usable(x, self.norm1, self.attn.qkv, math, self.hip_norm)
+                and ops.ln_image_usable(x, self.norm2, self.mlp.fc1, self.mlp.acr_math, self.hip_norm) and ops.mlp_f32_usable(x, self.mlp.fc1, self.mlp.fc2)):
+            # split products: LN(x) is read by one Linear only, as an image -- the LayerNorm writes that image, no fp32 copy
+            h, skip, hi = ops.layer_norm_image(x, self.norm1)
+            x = self.attn(h, stack, layer, resid=skip, x_image=hi)
+            h, skip, hi = ops.layer_norm_image(x, self.norm2)
+            return ops.mlp_f32(h, self.mlp.fc1, self.mlp.fc2, skip, self.mlp.acr_math, hi)
         h, skip = ops.layer_norm_skip(x, self.norm1, self.hip_norm)         # skip aliases x (gradient fused in LN bwd)
         x = self.attn(h, stack, layer, resid=skip)
         h, skip = ops.layer_norm_skip(x, self.norm2, self.hip_norm)

@@ -1718,6 +1718,84 @@ static void launch_planes_tile_t(const float* x, int64_t ld, int R, int C, int n
 }
 
 // ---- the image API: split-product operands made once, used by several products (include/acr_hip.h "split-product images") ------
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LayerNorm whose output LEAVES AS AN IMAGE (models/vision_transformer.py:219-222: norm1 -> attn.qkv, norm2 -> mlp.fc1): in the
+// blocks LN(x) is read by exactly one consumer, a Linear that wants it as a split-product image (and keeps that image for its
+// weight gradient) -- written in fp32 and re-read by an image pass it cost 4 + 4 + 6 bytes per element on top of the 4 read here;
+// now 4 read + 6 written.  Thread mapping = planes_tile_kernel's: 8 lanes per row, lane k8 holds the 8 columns 64 j + 8 k8 .. of
+// every 64-column group j (one 16-byte chunk per plane), 32 rows per workgroup; the row statistics are two-pass sums over the
+// registers, reduced over the row's 8 lanes.  Rows >= M of the last 128-row block are written as zeros (the weight gradient
+// contracts over image rows).  y = fma((x - mean) * rstd, gamma, beta) as ln_fwd_kernel; stats = (mean, rstd) per row.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NC> __global__ __launch_bounds__(256) void ln_image_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                          const float* __restrict__ beta, char* __restrict__ img,
+                                                                          float* __restrict__ stats, int M, int nkb, float eps) {
+    constexpr int C = NC * 64;
+    const int tid = threadIdx.x, rr = tid >> 3, k8 = tid & 7;
+    const int row = blockIdx.x * 32 + rr;
+    const bool live = row < M;
+    float v[NC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+        if (live) {
+            const float* src = x + (int64_t)row * C + j * 64 + k8 * 8;
+            a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 4));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[j][e] = a[e]; v[j][4 + e] = b[e]; }
+        s += (a[0] + a[1] + a[2] + a[3]) + (b[0] + b[1] + b[2] + b[3]);
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    const float mean = s * (1.f / (float)C);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mean; ss = fmaf(d, d, ss); }
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+    const float rstd = rsqrtf(ss * (1.f / (float)C) + eps);
+    const int rb = row >> 7, rt = row & 127;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int k = j * 64 + k8 * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + k), g1 = *reinterpret_cast<const f32x4*>(gamma + k + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + k), b1 = *reinterpret_cast<const f32x4*>(beta + k + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = live ? fmaf((v[j][e] - mean) * rstd, e < 4 ? g0[e] : g1[e - 4], e < 4 ? b0[e] : b1[e - 4]) : 0.f;
+        bf16x8 p0, p1, p2;
+        planes_split8(o, p0, p1, p2);
+        char* dst = img + ((int64_t)rb * nkb + (k >> 4)) * (3 * P_TILE_B) + planes_chunk_off(rt, k8 & 1);
+        *reinterpret_cast<bf16x8*>(dst) = p0;
+        *reinterpret_cast<bf16x8*>(dst + P_TILE_B) = p1;
+        *reinterpret_cast<bf16x8*>(dst + 2 * P_TILE_B) = p2;
+    }
+    if (live && k8 == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+extern "C" int acr_layernorm_image_f32(const float* x, const float* gamma, const float* beta, float* image, float* stats, int32_t M, int32_t C,
+                                       float eps, void* stream) {
+    ACR_CHECK_ARG(x && gamma && beta && image && stats, "acr_layernorm_image_f32: null pointer");
+    ACR_CHECK_ARG(M > 0 && C > 0 && (C % 64) == 0, "acr_layernorm_image_f32: need M > 0, C %% 64 == 0 (M=%d C=%d)", M, C);
+    ACR_CHECK_ARG(al16(x) && al16(gamma) && al16(beta) && al16(image), "acr_layernorm_image_f32: x / gamma / beta / image must be 16-byte aligned");
+    const int nkb = C / P_BK;
+    const dim3 grid((unsigned)(((M + F_BM - 1) / F_BM) * (F_BM / 32)));
+    hipStream_t st = (hipStream_t)stream;
+    char* img = reinterpret_cast<char*>(image);
+#define LNI(NC) case NC: hipLaunchKernelGGL(ln_image_kernel<NC>, grid, dim3(256), 0, st, x, gamma, beta, img, stats, M, nkb, eps); break;
+    switch (C / 64) {
+        LNI(4) LNI(8) LNI(12) LNI(16)
+        default:
+            acr_set_error("acr_layernorm_image_f32: C = %d not instantiated (256, 512, 768, 1024: what acr_layernorm_bwd_f32 takes)", C);
+            return ACR_ERR_UNSUPPORTED;
+    }
+#undef LNI
+    return acr_check_launch("acr_layernorm_image_f32");
+}
+
 extern "C" size_t acr_x3_image_floats(int32_t rows, int32_t cols) {
     if (rows <= 0 || cols <= 0) return 0;
     return (size_t)((rows + F_BM - 1) / F_BM) * ((cols + P_BK - 1) / P_BK) * (3 * P_TILE_B / 4);

@@ -701,21 +701,23 @@ class LinearF32Fn(Function):
     in one TN sweep over dy (models/vision_transformer.py:200,212 and their autograd backward)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, resid, owner=None, math=0):
+    def forward(ctx, x, weight, bias, resid, owner=None, math=0, x_image=None):
         ctx.math = math
         shp = x.shape
-        x2 = x.reshape(-1, shp[-1])
+        x2 = x.reshape(-1, shp[-1]) if x_image is None else None      # x_image: x exists only as its image (layer_norm_image)
         N = weight.shape[0]
         r2 = resid.reshape(-1, N) if resid is not None else None
         if r2 is not None and not r2.is_contiguous():
             r2 = r2.contiguous()
-        y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
+        M = x.numel() // shp[-1]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         ctx.images = math == 1 and X3_IMAGES and _f32_ok(x2, weight, y, r2, bias)
+        assert ctx.images or x_image is None, "a LayerNorm image needs the split-product Linear behind it (ops.ln_image_usable)"
         if ctx.images:                                      # x's image serves this product and the weight gradient
-            xi = x3_image(x2)
+            xi = x_image if x_image is not None else x3_image(x2)
             gemm_x3("nt", xi, weight_image(weight, owner), y, shp[-1], bias=bias, aux=r2)
             ctx.save_for_backward(xi if any(ctx.needs_input_grad[1:3]) else None, weight)
-            ctx.M = x2.shape[0]
+            ctx.M = M
         else:
             gemm_f32_raw("nt", x2, weight, y, bias=bias, aux=r2, math=math)
             ctx.save_for_backward(x2, weight)
@@ -744,7 +746,7 @@ class LinearF32Fn(Function):
             if ctx.needs_input_grad[1]:
                 dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
                 gemm_x3("tn", dyi, xi, dw, ctx.M)
-            return dx, dw, db, (dy if ctx.has_resid else None), None, None
+            return dx, dw, db, (dy if ctx.has_resid else None), None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((dy2.shape[0], K), dtype=torch.float32, device=dy.device)
             _dx_f32(dy2, weight, ctx.owner, dx, math=ctx.math)
@@ -755,7 +757,7 @@ class LinearF32Fn(Function):
             gemm_f32_raw("tn", dy2, x2, dw, colsum=db, math=ctx.math)
         elif want_db:
             db = dy2.sum(0)
-        return dx, dw, db, (dy if ctx.has_resid else None), None, None
+        return dx, dw, db, (dy if ctx.has_resid else None), None, None, None
 
 
 class MlpF32Fn(Function):
@@ -763,11 +765,11 @@ class MlpF32Fn(Function):
     epilogues: fc1 writes h and GELU(h) in one pass; fc2's input gradient comes out multiplied by GELU'(h)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, resid, fc1=None, fc2=None, math=0):
+    def forward(ctx, x, w1, b1, w2, b2, resid, fc1=None, fc2=None, math=0, x_image=None):
         ctx.fc1, ctx.fc2, ctx.math = fc1, fc2, math
         shp = x.shape
-        x2 = x.reshape(-1, shp[-1])
-        M = x2.shape[0]
+        x2 = x.reshape(-1, shp[-1]) if x_image is None else None      # x_image: x exists only as its image (layer_norm_image)
+        M = x.numel() // shp[-1]
         Hd, D = w1.shape[0], w2.shape[0]
         h = torch.empty((M, Hd), dtype=torch.float32, device=x.device)
         r2 = resid.reshape(-1, D) if resid is not None else None
@@ -776,8 +778,9 @@ class MlpF32Fn(Function):
         y = torch.empty((M, D), dtype=torch.float32, device=x.device)
         ctx.images = math == 1 and X3_IMAGES and _f32_ok(x2, w1, w2, r2, b1, b2)
         ctx.has_resid = resid is not None
+        assert ctx.images or x_image is None, "a LayerNorm image needs the split-product MLP behind it (ops.ln_image_usable)"
         if ctx.images:                                      # the images of x and GELU(h) serve the forward and the weight gradients
-            xi = x3_image(x2)
+            xi = x_image if x_image is not None else x3_image(x2)
             ctx.epi = X3_IMAGE_EPILOGUES and Hd % 8 == 0
             if ctx.epi:                                     # GELU(h) leaves fc1 as fc2's operand image; it never exists in fp32
                 ai = x3_image_empty(M, Hd, x.device)
@@ -832,7 +835,7 @@ class MlpF32Fn(Function):
                 dx = torch.empty((M, w1.shape[1]), dtype=torch.float32, device=dev)
                 gemm_x3("nt", dhi, weight_image(w1, ctx.fc1, True), dx, Hd)
                 dx = dx.reshape(*dy.shape[:-1], w1.shape[1])
-            return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None), None, None, None
+            return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None), None, None, None, None
         if need[3]:
             dw2 = torch.empty_like(w2)
             db2 = torch.empty(w2.shape[0], dtype=torch.float32, device=dev) if need[4] else None
@@ -851,7 +854,7 @@ class MlpF32Fn(Function):
             dx = torch.empty_like(x2)
             _dx_f32(dh, w1, ctx.fc1, dx, math=math)
             dx = dx.reshape(*dy.shape[:-1], w1.shape[1])
-        return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None), None, None, None
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_resid else None), None, None, None, None
 
 
 def mlp_f32_usable(x, fc1, fc2):
@@ -859,13 +862,16 @@ def mlp_f32_usable(x, fc1, fc2):
             and fc2.bias is not None and fc2.weight.is_contiguous() and fc2.weight.shape[0] % 4 == 0)
 
 
-def mlp_f32(x, fc1, fc2, resid=None, math=0):
-    return MlpF32Fn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, resid, fc1, fc2, math)
+def mlp_f32(x, fc1, fc2, resid=None, math=0, x_image=None):
+    return MlpF32Fn.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, resid, fc1, fc2, math, x_image)
 
 
-def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hip_fwd=True, math=0):
+def linear_or_hip(x, lin, resid=None, use_hip=True, hip_dx=True, hip_dw=True, hip_fwd=True, math=0, x_image=None):
     """nn.Linear forward; bf16 CUDA tensors with K % 64 == 0 take the hand-written GEMM (resid fused).
-    ``hip_dx`` = False leaves the input gradient on hipBLASLt (shapes where the library kernel is faster)."""
+    ``hip_dx`` = False leaves the input gradient on hipBLASLt (shapes where the library kernel is faster).
+    ``x_image``: x came out of layer_norm_image -- it exists only as that split-product image."""
+    if x_image is not None:
+        return LinearF32Fn.apply(x, lin.weight, lin.bias, resid, lin, math, x_image)
     if (use_hip and x.is_cuda and x.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16
             and lin.weight.shape[1] % 64 == 0 and x.is_contiguous()):
         return LinearBf16Fn.apply(x, lin.weight, lin.bias, resid, hip_dx, hip_dw, hip_fwd, lin)
@@ -1259,25 +1265,34 @@ class LayerNormFn(Function):
     by a separate autograd accumulation pass (blocks: x + f(LN(x)), models/vision_transformer.py:224-226)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, image=False):
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
         M = x2.shape[0]
         lib = L.load()
-        y = torch.empty_like(x2)
         stats = torch.empty(2 * M, dtype=torch.float32, device=x.device)
-        fwd = lib.acr_layernorm_fwd_f32 if x.dtype == torch.float32 else lib.acr_layernorm_fwd_bf16
-        L.check(fwd(L.ptr(x2), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), M, C, eps, L.stream_ptr()), "acr_layernorm_fwd")
         ctx.save_for_backward(x2, weight, stats)
         ctx.set_materialize_grads(False)
+        if image:
+            # LN(x) leaves as the split-product image its one consumer (a Linear) multiplies by and keeps for its weight
+            # gradient; the differentiable output is a PLACEHOLDER of the right shape (one element, expanded: no memory, never
+            # read) that only carries the Linear's input gradient back here
+            img = x3_image_empty(M, C, x.device)
+            L.check(lib.acr_layernorm_image_f32(L.ptr(x2), L.ptr(weight), L.ptr(bias), L.ptr(img), L.ptr(stats), M, C, eps, L.stream_ptr()),
+                    "acr_layernorm_image_f32")
+            ctx.mark_non_differentiable(img)
+            return x.new_empty(1).expand(x.shape), x.view_as(x), img
+        y = torch.empty_like(x2)
+        fwd = lib.acr_layernorm_fwd_f32 if x.dtype == torch.float32 else lib.acr_layernorm_fwd_bf16
+        L.check(fwd(L.ptr(x2), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), M, C, eps, L.stream_ptr()), "acr_layernorm_fwd")
         return y.reshape(x.shape), x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dy, dskip):
+    def backward(ctx, dy, dskip, dimg=None):
         x2, weight, stats = ctx.saved_tensors
         M, C = x2.shape
         if dy is None:
-            return dskip, None, None, None
+            return dskip, None, None, None, None
         lib = L.load()
         dy2 = dy.reshape(M, C)
         if not dy2.is_contiguous() or dy2.dtype != x2.dtype:
@@ -1294,7 +1309,7 @@ class LayerNormFn(Function):
         bwd = lib.acr_layernorm_bwd_f32 if x2.dtype == torch.float32 else lib.acr_layernorm_bwd_bf16
         L.check(bwd(L.ptr(dy2), L.ptr(x2), L.ptr(weight), L.ptr(stats), L.ptr(ds2), L.ptr(dx), L.ptr(ws), L.ptr(dg), L.ptr(db), M, C,
                     L.stream_ptr()), "acr_layernorm_bwd")
-        return dx.reshape(dy.shape), dg, db, None
+        return dx.reshape(dy.shape), dg, db, None, None
 
 
 def layer_norm_fusable(x, ln):
@@ -1306,7 +1321,7 @@ def layer_norm_fusable(x, ln):
 def layer_norm(x, ln, use_hip=True):
     """nn.LayerNorm forward; contiguous bf16 CUDA rows with C % 256 == 0 (<= 1024) take the HIP kernels."""
     if use_hip and layer_norm_fusable(x, ln):
-        return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)[0]
+        return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, False)[0]
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
 
 
@@ -1317,9 +1332,27 @@ def layer_norm_skip(x, ln, use_hip=True):
     """(LN(x), x_skip) -- see LayerNormFn; on the stock path x_skip is x itself."""
     if use_hip and layer_norm_fusable(x, ln):
         if not SKIP_FUSION:
-            return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)[0], x
-        return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
+            return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, False)[0], x
+        return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, False)
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps), x
+
+
+LN_IMAGE = os.environ.get("ACR_LN_IMAGE", "1") != "0"      # A/B: the blocks' LayerNorms write their consumer's operand image directly
+
+
+def ln_image_usable(x, ln, lin, math, use_hip=True):
+    """norm -> Linear pairs of a block under split products where LN(x) can leave as the Linear's operand image (LayerNormFn with
+    image=True + LinearF32Fn / MlpF32Fn with x_image): exactly the conditions under which that Linear takes its image path."""
+    C = x.shape[-1]
+    return (LN_IMAGE and use_hip and math == 1 and X3_IMAGES and F32_HIP_LINEAR and SKIP_FUSION and x.is_cuda and x.dtype == torch.float32
+            and x.is_contiguous() and ln.weight.dtype == torch.float32 and ln.bias is not None and C % 256 == 0 and C <= 1024
+            and not torch.is_autocast_enabled() and lin.weight.dtype == torch.float32 and lin.weight.is_contiguous() and lin.weight.shape[1] == C
+            and lin.weight.shape[0] % 4 == 0 and lin.weight.shape[0] >= 32 and _f32_ok(x, ln.weight, ln.bias, lin.weight, lin.bias))
+
+
+def layer_norm_image(x, ln):
+    """(placeholder for LN(x), x_skip, image of LN(x)) -- see LayerNormFn."""
+    return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, True)
 
 
 GN_ACT = {"none": 0, "relu": 1, "add_relu": 2}

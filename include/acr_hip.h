@@ -386,6 +386,11 @@ int acr_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta,
                           float eps, void* stream);
 int acr_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* stats, const float* dskip, float* dx,
                           float* ws, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream);
+/* LayerNorm whose output leaves as a split-product image (acr_x3_image layout, rows = M, cols = C: the operand of the Linear that
+ * follows -- norm1 -> attn.qkv, norm2 -> mlp.fc1, vision_transformer.py:219-226): no fp32 y is written.  stats as acr_layernorm_fwd_f32
+ * (the backward is acr_layernorm_bwd_f32 on x and stats).  C in {256, 512, 768, 1024}. */
+int acr_layernorm_image_f32(const float* x, const float* gamma, const float* beta, float* image, float* stats, int32_t M, int32_t C, float eps,
+                            void* stream);
 
 /* ---- ResNetV2 stem: fused GroupNorm(32) [+ residual] [+ ReLU], bf16 NCHW ----
  * models/layers/norm_act.py:69-85 (GroupNormAct), models/resnetv2.py:205-215 (norm3 -> act3(x + shortcut)).

@@ -795,6 +795,68 @@ def test_layernorm_f32(M, C):
         assert err <= 2e-5, (n, float(err))
 
 
+@pytest.mark.parametrize("M,C,N", [(2 * 785, 768, 2304), (300, 256, 576), (130, 1024, 256), (64, 512, 96)])
+def test_layernorm_image_f32(M, C, N):
+    """LayerNorm whose output leaves as its consumer's split-product image (acr_layernorm_image_f32 + LinearF32Fn / MlpF32Fn with
+    x_image; what a block runs under f32_split): norm -> Linear forward, input gradient through the LayerNorm backward (with the
+    fused skip gradient), weight / bias gradients of both, against fp64 and against the two-kernel path (LayerNorm in fp32, then the
+    image pass).  Row counts that are not multiples of 32 / 128: the image's padding rows must be ZERO (the weight gradient contracts
+    over them) -- the allocator is primed with NaNs so that unwritten rows would show."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(dev).requires_grad_(True)
+    ln = torch.nn.LayerNorm(C, eps=1e-6).to(dev)
+    lin = torch.nn.Linear(C, N).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+        ln.bias.copy_(0.3 * torch.randn(C, generator=g))
+    assert ops.ln_image_usable(x, ln, lin, 1) and not ops.ln_image_usable(x, ln, lin, 0)
+    dy = torch.randn(M, N, generator=g).to(dev)
+    ds = torch.randn(M, C, generator=g).to(dev)
+    prime = torch.full((int(ops.L.load().acr_x3_image_floats(M, C)),), float("nan"), device=dev)
+    del prime
+    h, skip, hi = ops.layer_norm_image(x, ln)
+    assert h.shape == x.shape and h.untyped_storage().nbytes() == 4
+    y = ops.linear_or_hip(h, lin, None, True, math=1, x_image=hi)
+    ((y * dy).sum() + (skip * ds).sum()).backward()
+    got = [y.detach(), x.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    assert all(torch.isfinite(t).all() for t in got)
+    xd = x.detach().double().requires_grad_(True)
+    ps = [p.detach().double().requires_grad_(True) for p in (ln.weight, ln.bias, lin.weight, lin.bias)]
+    ref = F.linear(F.layer_norm(xd, (C,), ps[0], ps[1], 1e-6), ps[2], ps[3])
+    ((ref * dy.double()).sum() + (xd * ds.double()).sum()).backward()
+    want = [ref, xd.grad] + [p.grad for p in ps]
+    names = ("y", "dx", "dgamma", "dbeta", "dW", "db")
+    for n, a, b in zip(names, got, want):
+        err = (a.double() - b).abs().max() / b.abs().max()
+        assert err <= 2e-5, (n, float(err))
+    # the two-kernel path: same numbers up to the rounding of the row statistics (another summation order)
+    for p in (x, ln.weight, ln.bias, lin.weight, lin.bias):
+        p.grad = None
+    h2, skip2 = ops.layer_norm_skip(x, ln)
+    y2 = ops.linear_or_hip(h2, lin, None, True, math=1)
+    ((y2 * dy).sum() + (skip2 * ds).sum()).backward()
+    two = [y2.detach(), x.grad, ln.weight.grad, ln.bias.grad, lin.weight.grad, lin.bias.grad]
+    for n, a, b in zip(names, got, two):
+        err = (a - b).abs().max() / b.abs().max()
+        assert err <= 2e-6, (n, float(err))
+    # and the MLP form (norm2 -> fc1 -> GELU -> fc2 + skip)
+    fc2 = torch.nn.Linear(N, C).to(dev)
+    for p in (x, ln.weight, ln.bias, lin.weight, lin.bias):
+        p.grad = None
+    h, skip, hi = ops.layer_norm_image(x, ln)
+    z = ops.mlp_f32(h, lin, fc2, skip, 1, hi)
+    (z * ds).sum().backward()
+    ps = [p.detach().double().requires_grad_(True) for p in (x, ln.weight, ln.bias, lin.weight, lin.bias, fc2.weight, fc2.bias)]
+    zr = ps[0] + F.linear(F.gelu(F.linear(F.layer_norm(ps[0], (C,), ps[1], ps[2], 1e-6), ps[3], ps[4])), ps[5], ps[6])
+    (zr * ds.double()).sum().backward()
+    for n, a, b in [("z", z, zr)] + [("g%d" % i, p.grad, q.grad) for i, (p, q) in enumerate(zip((x, ln.weight, ln.bias, lin.weight, lin.bias, fc2.weight, fc2.bias), ps))]:
+        err = (a.double() - b).abs().max() / b.abs().max()
+        assert err <= 3e-5, (n, float(err))
+
+
 def test_weight_std_all_f32():
     """One-launch weight standardisation on fp32 weights vs the fp64 expression (std_conv.py:56-59), forward + backward."""
     from acr_wsss_amd import ops
