@@ -734,7 +734,12 @@ class VisionTransformer(nn.Module):
         pe = self.patch_embed.proj
         if (isinstance(self.patch_embed, HybridEmbed) and StdConv2dSame.hip_1x1 and pe.bias is not None
                 and ops.conv1x1_fusable(x, pe.weight, pe.stride[0])):
-            x = ops.conv1x1(x, pe.weight, None, self.acr_math) + pe.bias.view(1, -1, 1, 1)      # 1024 -> 768 projection on the NCHW GEMM kernels
+            x = ops.conv1x1(x, pe.weight, None, self.acr_math)                                   # 1024 -> 768 projection on the NCHW GEMM kernels
+            prefix = self.cls_token[0] if self.dist_token is None else torch.cat([self.cls_token[0], self.dist_token[0]], 0)
+            if x.shape[2] * x.shape[3] + self.num_tokens == pos.shape[1] and ops.tokens_fusable(x, pe.bias, prefix, pos):
+                # bias add, transpose to token-major, class token, position embedding: one pass (and one backward pass) instead of four
+                return ops.tokens(x, pe.bias, prefix, pos), res_features
+            x = x + pe.bias.view(1, -1, 1, 1)
         else:
             x = pe(x)
         x = x.flatten(2).transpose(1, 2)

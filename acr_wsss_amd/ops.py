@@ -1337,6 +1337,44 @@ def layer_norm_skip(x, ln, use_hip=True):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps), x
 
 
+TOKENS_HIP = os.environ.get("ACR_TOKENS_HIP", "1") != "0"      # A/B: the hybrid ViT's token assembly as one kernel each way
+
+
+class TokensFn(Function):
+    """tokens = cat(prefix, (y + bias)^T) + pos in one pass each way (csrc/tokens.hip; vision_transformer.py:449-467): y (B, D, h, w) is
+    the patch projection's output WITHOUT its bias, prefix (P, D) the class (+ distillation) token, pos (1, P + h*w, D)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, prefix, pos):
+        B, D = y.shape[:2]
+        T = y.shape[2] * y.shape[3]
+        P = prefix.shape[0]
+        tok = torch.empty((B, P + T, D), dtype=torch.float32, device=y.device)
+        L.check(L.load().acr_tokens_fwd_f32(L.ptr(y), L.ptr(bias), L.ptr(prefix), L.ptr(pos), L.ptr(tok), B, D, T, P, L.stream_ptr()), "acr_tokens_fwd_f32")
+        ctx.geom = (tuple(y.shape), P)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        (B, D, h, w), P = ctx.geom
+        T = h * w
+        dtok = (dtok if dtok.dtype == torch.float32 else dtok.float()).contiguous()
+        dy = torch.empty((B, D, h, w), dtype=torch.float32, device=dtok.device)
+        dpos = torch.empty((1, P + T, D), dtype=torch.float32, device=dtok.device)
+        L.check(L.load().acr_tokens_bwd_f32(L.ptr(dtok), L.ptr(dy), L.ptr(dpos), B, D, T, P, L.stream_ptr()), "acr_tokens_bwd_f32")
+        dbias = dpos[0, P:].sum(0) if ctx.needs_input_grad[1] else None
+        return dy, dbias, dpos[0, :P], dpos
+
+
+def tokens_fusable(y, bias, prefix, pos):
+    return (TOKENS_HIP and y.is_cuda and y.dim() == 4 and all(t.dtype == torch.float32 and t.is_contiguous() for t in (y, bias, prefix, pos))
+            and prefix.shape[0] <= 8 and pos.shape[1] == prefix.shape[0] + y.shape[2] * y.shape[3] and not torch.is_autocast_enabled())
+
+
+def tokens(y, bias, prefix, pos):
+    return TokensFn.apply(y, bias, prefix, pos)
+
+
 LN_IMAGE = os.environ.get("ACR_LN_IMAGE", "1") != "0"      # A/B: the blocks' LayerNorms write their consumer's operand image directly
 
 

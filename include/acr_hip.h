@@ -392,6 +392,15 @@ int acr_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, c
 int acr_layernorm_image_f32(const float* x, const float* gamma, const float* beta, float* image, float* stats, int32_t M, int32_t C, float eps,
                             void* stream);
 
+/* ---- token assembly of the hybrid ViT (vision_transformer.py:449-467: flatten(2).transpose(1, 2), cat(cls[, dist], x), + pos_embed) ----
+ * acr_tokens_fwd_f32: tok[b][P+t][d] = y[b][d][t] + bias[d] + pos[P+t][d], tok[b][p][d] = prefix[p][d] + pos[p][d] for p < P;
+ *   y (B, D, T) = the patch projection's output WITHOUT its bias, prefix (P, D) = class (+ distillation) token, pos (P+T, D), P <= 8.
+ * acr_tokens_bwd_f32: dy[b][d][t] = dtok[b][P+t][d], dpos[r][d] = sum_b dtok[b][r][d] in batch order (the bias gradient is the sum of
+ *   dpos rows >= P, the prefix gradient its first P rows). */
+int acr_tokens_fwd_f32(const float* y, const float* bias, const float* prefix, const float* pos, float* tok, int32_t B, int32_t D, int32_t T,
+                       int32_t P, void* stream);
+int acr_tokens_bwd_f32(const float* dtok, float* dy, float* dpos, int32_t B, int32_t D, int32_t T, int32_t P, void* stream);
+
 /* ---- ResNetV2 stem: fused GroupNorm(32) [+ residual] [+ ReLU], bf16 NCHW ----
  * models/layers/norm_act.py:69-85 (GroupNormAct), models/resnetv2.py:205-215 (norm3 -> act3(x + shortcut)).
  * act: 0 = none, 1 = ReLU, 2 = ReLU(gn(x) + resid).  x/resid/y: (N,C,H,W) contiguous, HW = H*W (multiple of 8),

@@ -857,6 +857,31 @@ def test_layernorm_image_f32(M, C, N):
         assert err <= 3e-5, (n, float(err))
 
 
+@pytest.mark.parametrize("B,D,h,w,P", [(4, 768, 28, 28, 1), (3, 192, 14, 14, 2), (2, 100, 5, 7, 1), (32, 768, 28, 28, 1)])
+def test_tokens_assembly(B, D, h, w, P):
+    """csrc/tokens.hip vs the reference's chain (vision_transformer.py:449-467): projection bias add, flatten(2).transpose(1, 2), cat with
+    the class (+ distillation) token, + pos_embed -- forward bit for bit (same order of the two additions), the projection's gradient
+    bit for bit (a transposed copy), position / bias / prefix gradients to summation-order tolerance.  Tiles that run past T and D."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(B + D)
+    y = torch.randn(B, D, h, w, generator=g).to(dev).requires_grad_(True)
+    bias = torch.randn(D, generator=g).to(dev).requires_grad_(True)
+    prefix = torch.randn(P, D, generator=g).to(dev).requires_grad_(True)
+    pos = torch.randn(1, P + h * w, D, generator=g).to(dev).requires_grad_(True)
+    assert ops.tokens_fusable(y, bias, prefix, pos)
+    tok = ops.tokens(y, bias, prefix, pos)
+    dtok = torch.randn(tok.shape, generator=g).to(dev)
+    (tok * dtok).sum().backward()
+    got = [tok.detach(), y.grad, bias.grad, prefix.grad, pos.grad]
+    y2, b2, p2, pos2 = (t.detach().clone().requires_grad_(True) for t in (y, bias, prefix, pos))
+    ref = torch.cat([p2.unsqueeze(0).expand(B, -1, -1), (y2 + b2.view(1, -1, 1, 1)).flatten(2).transpose(1, 2)], dim=1) + pos2
+    (ref * dtok).sum().backward()
+    assert torch.equal(got[0], ref) and torch.equal(got[1], y2.grad)
+    for n, a, b in (("dbias", got[2], b2.grad), ("dprefix", got[3], p2.grad), ("dpos", got[4], pos2.grad)):
+        assert (a - b).abs().max() <= 2e-6 * b.abs().max() * B ** 0.5, n
+
+
 def test_weight_std_all_f32():
     """One-launch weight standardisation on fp32 weights vs the fp64 expression (std_conv.py:56-59), forward + backward."""
     from acr_wsss_amd import ops
