@@ -78,7 +78,7 @@ class StdConv2dSame(nn.Conv2d):
             # the two stride-2 1x1 convolutions (the shortcuts of stages 1 and 2; SAME padding is empty for a 1x1 kernel:
             # y[i][j] = W x[2i][2j]): subsample first, then the same NCHW GEMM kernels as every other 1x1 -- the library ran
             # them as layout transposes + a Tensile GEMM; autograd's slice backward scatters the input gradient back
-            xs = x[:, :, ::2, ::2].contiguous()
+            xs = ops.subsample2(x)
             if ops.conv1x1_fusable(xs, w_hat, 1):
                 return ops.conv1x1(xs, w_hat, self._w_hat_t, self.acr_math, self._w_imgs)
         if self.hip_1x1 and ops.conv1x1_fusable(x, w_hat, self.stride[0]):

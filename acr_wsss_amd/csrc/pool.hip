@@ -155,3 +155,70 @@ extern "C" int acr_maxpool3x3s2_bwd_f32(const void* dy, const uint8_t* amax, voi
                                         int32_t ho, int32_t wo, int32_t pad_top, int32_t pad_left, void* stream) {
     return maxpool_bwd<float>("acr_maxpool3x3s2_bwd_f32", dy, amax, dx, nc, h, w, ho, wo, pad_top, pad_left, stream);
 }
+
+// ---- y[nc][i][j] = x[nc][2i][2j]: what a stride-2 1x1 convolution reads (the shortcuts of stages 1 and 2, models/resnetv2.py:232-249
+// DownsampleConv; SAME padding is empty for a 1x1 kernel), and its backward dx = dy scattered onto the even pixels, zero elsewhere --
+// one pass each way (autograd's nested slice backward made two zero fills and two strided copies of it).  fp32, Ho = ceil(H/2).
+template <bool VEC> __global__ __launch_bounds__(256) void subsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t nthr, int H, int W,
+                                                                                  int Ho, int Wo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nthr) return;
+    const int wq = (Wo + 3) >> 2;
+    const int q = (int)(i % wq);
+    int64_t t = i / wq;
+    const int r = (int)(t % Ho);
+    const int64_t nc = t / Ho;
+    const float* src = x + (nc * H + 2 * r) * W + 8 * q;
+    float* dst = y + (nc * Ho + r) * Wo + 4 * q;
+    if (VEC) {                                               // W % 8 == 0
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+        *reinterpret_cast<f32x4*>(dst) = f32x4{a[0], a[2], b[0], b[2]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * q + e < Wo) dst[e] = src[2 * e];
+    }
+}
+template <bool VEC> __global__ __launch_bounds__(256) void subsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t nthr, int H, int W,
+                                                                                  int Ho, int Wo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nthr) return;
+    const int wq = (W + 7) >> 3;
+    const int q = (int)(i % wq);
+    int64_t t = i / wq;
+    const int r = (int)(t % H);
+    const int64_t nc = t / H;
+    float* dst = dx + (nc * H + r) * W + 8 * q;
+    const float* src = dy + (nc * Ho + (r >> 1)) * Wo + 4 * q;
+    const bool even = (r & 1) == 0;
+    if (VEC) {                                               // W % 8 == 0
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (even) v = *reinterpret_cast<const f32x4*>(src);
+        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], 0.f, v[1], 0.f};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[2], 0.f, v[3], 0.f};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (8 * q + e < W) dst[e] = (even && (e & 1) == 0) ? src[e >> 1] : 0.f;
+    }
+}
+extern "C" int acr_subsample2_fwd_f32(const float* x, float* y, int64_t nc, int32_t h, int32_t w, void* stream) {
+    ACR_CHECK_ARG(x && y && nc > 0 && h > 0 && w > 0, "acr_subsample2_fwd_f32: bad argument");
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+    const int64_t nthr = nc * ho * ((wo + 3) / 4);
+    ACR_CHECK_ARG((nthr + 255) / 256 < (1ll << 31), "acr_subsample2_fwd_f32: too large");
+    const bool vec = (w % 8) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
+    if (vec) hipLaunchKernelGGL(subsample2_fwd_kernel<true>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, nthr, h, w, ho, wo);
+    else hipLaunchKernelGGL(subsample2_fwd_kernel<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, nthr, h, w, ho, wo);
+    return acr_check_launch("acr_subsample2_fwd_f32");
+}
+extern "C" int acr_subsample2_bwd_f32(const float* dy, float* dx, int64_t nc, int32_t h, int32_t w, void* stream) {
+    ACR_CHECK_ARG(dy && dx && nc > 0 && h > 0 && w > 0, "acr_subsample2_bwd_f32: bad argument");
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+    const int64_t nthr = nc * h * ((w + 7) / 8);
+    ACR_CHECK_ARG((nthr + 255) / 256 < (1ll << 31), "acr_subsample2_bwd_f32: too large");
+    const bool vec = (w % 8) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dy & 15) == 0;
+    if (vec) hipLaunchKernelGGL(subsample2_bwd_kernel<true>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, nthr, h, w, ho, wo);
+    else hipLaunchKernelGGL(subsample2_bwd_kernel<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, nthr, h, w, ho, wo);
+    return acr_check_launch("acr_subsample2_bwd_f32");
+}

@@ -912,6 +912,33 @@ def maxpool3x3s2_same(x, pt, pl, ph, pw):
     return MaxPoolSameFn.apply(x, pt, pl, ph, pw)
 
 
+class Subsample2Fn(Function):
+    """x[:, :, ::2, ::2] as a contiguous tensor (what a stride-2 1x1 convolution reads) -- one pass, and one pass back (the even
+    pixels of dx, zeros elsewhere) instead of autograd's two zero fills + two strided copies."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=x.device)
+        L.check(L.load().acr_subsample2_fwd_f32(L.ptr(x), L.ptr(y), N * C, H, W, L.stream_ptr()), "acr_subsample2_fwd_f32")
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W = ctx.shape
+        dy = (dy if dy.dtype == torch.float32 else dy.float()).contiguous()
+        dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+        L.check(L.load().acr_subsample2_bwd_f32(L.ptr(dy), L.ptr(dx), N * C, H, W, L.stream_ptr()), "acr_subsample2_bwd_f32")
+        return dx
+
+
+def subsample2(x):
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and not torch.is_autocast_enabled():
+        return Subsample2Fn.apply(x)
+    return x[:, :, ::2, ::2].contiguous()
+
+
 F32_HIP_CONV1X1 = os.environ.get("ACR_F32_HIP_CONV1X1", "1") != "0"      # A/B switch: fp32 1x1 convolutions on acr_conv1x1_f32 vs MIOpen
 
 

@@ -337,6 +337,10 @@ int acr_maxpool3x3s2_fwd_f32(const void* x, void* y, uint8_t* amax, int64_t nc, 
                              int32_t wo, int32_t pad_top, int32_t pad_left, void* stream);
 int acr_maxpool3x3s2_bwd_f32(const void* dy, const uint8_t* amax, void* dx, int64_t nc, int32_t h, int32_t w,
                              int32_t ho, int32_t wo, int32_t pad_top, int32_t pad_left, void* stream);
+/* y[nc][i][j] = x[nc][2i][2j] (Ho = ceil(h/2), Wo = ceil(w/2)): the input of a stride-2 1x1 convolution (DownsampleConv, resnetv2.py:232-249),
+ * and its backward dx = dy on the even pixels, zero elsewhere.  fp32. */
+int acr_subsample2_fwd_f32(const float* x, float* y, int64_t nc, int32_t h, int32_t w, void* stream);
+int acr_subsample2_bwd_f32(const float* dy, float* dx, int64_t nc, int32_t h, int32_t w, void* stream);
 
 /* ---- Fused optimizer step, bf16 weights + fp32 masters (tool/torchutils.py:10-31 PolyOptimizer = SGD with
  * momentum slot = wt_dec, weight decay 0):  mom = momentum*mom + g;  master -= lr*mom;  param = bf16(master).

@@ -882,6 +882,23 @@ def test_tokens_assembly(B, D, h, w, P):
         assert (a - b).abs().max() <= 2e-6 * b.abs().max() * B ** 0.5, n
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 16, 24), (3, 5, 9, 13), (1, 4, 7, 16), (2, 256, 112, 112)])
+def test_subsample2(shape):
+    """ops.subsample2 (the input of a stride-2 1x1 convolution) and its backward are x[:, :, ::2, ::2] and its autograd backward,
+    bit for bit -- vector path (W % 8 == 0) and the guarded scalar one (odd sizes)."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(dev).requires_grad_(True)
+    y = ops.subsample2(x)
+    dy = torch.randn(y.shape, generator=g).to(dev)
+    (y * dy).sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    ref = x2[:, :, ::2, ::2].contiguous()
+    (ref * dy).sum().backward()
+    assert torch.equal(y, ref) and torch.equal(x.grad, x2.grad)
+
+
 def test_weight_std_all_f32():
     """One-launch weight standardisation on fp32 weights vs the fp64 expression (std_conv.py:56-59), forward + backward."""
     from acr_wsss_amd import ops
