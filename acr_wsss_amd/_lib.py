@@ -170,7 +170,7 @@ SIGNATURES = {
 OPTIONS = {"gemm_variant": (0, "ACR_GEMM_VARIANT"), "gemm_nowide": (1, "ACR_GEMM_NOWIDE"), "gemm_regstage": (2, "ACR_GEMM_REGSTAGE"),
            "wgrad_variant": (3, "ACR_WGRAD_VARIANT"), "wgrad_waves": (4, "ACR_WGRAD_WAVES"), "dq_variant": (5, "ACR_DQ_VARIANT"),
            "gemm_f32_regstage": (6, "ACR_GEMM_F32_REGSTAGE"), "gemm_x3_inkernel": (11, "ACR_GEMM_X3_INKERNEL"),
-           "gemm_f32_notail": (9, "ACR_GEMM_F32_NOTAIL"), "attn_f32_nosplittail": (10, "ACR_ATTN_F32_NOSPLITTAIL")}
+           "gemm_f32_notail": (9, "ACR_GEMM_F32_NOTAIL"), "attn_delta_1head": (7, "ACR_ATTN_DELTA_1HEAD"), "attn_f32_nosplittail": (10, "ACR_ATTN_F32_NOSPLITTAIL")}
 
 _lib = None
 

@@ -157,6 +157,95 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_sres_kernel
 // for every head four 16-byte loads, P = exp2(S - lse2), summed in head order in registers (deterministic), transposed
 // through a private LDS tile so that the (T, T) map is written in 128-byte row segments.
 // ---------------------------------------------------------------------------------------------
+// The same sums with the workgroup = NW = 4 heads of one (sample, query block) (H % 4 == 0): the gradient block
+// gm[b][32 queries][32 keys] of a step is the same for every head, and read the way the kernel above reads it -- a float4 per lane
+// from 32 different rows per instruction -- it costs the texture path 32 cache lines per wave instruction against 8 for the score
+// block (measured: 3.2 TB/s against the 5 TB/s of the head-mean pass over the same scores).  Here the 256 threads fetch the block
+// once per workgroup as 32 row segments of 128 bytes (8 lines per instruction), park it in LDS (row stride 36 floats: the
+// accumulator-order float4 reads of 16 lanes then touch every bank once) and all four waves read it from there; double-buffered,
+// one fence-free barrier per key block, the next block's scores and gm piece in flight meanwhile.  Same operations in the same order
+// as the kernel above: bit-identical delta.
+template <int NW> __global__ __launch_bounds__(64 * NW) void attn_delta_sres4_kernel(AttnGeom g, int NB, const float* __restrict__ sres,
+                                                               const float* __restrict__ o, const float* __restrict__ d_o,
+                                                               const float* __restrict__ lse2, const float* __restrict__ gm,
+                                                               int64_t gm_sb, int64_t gm_st, float* __restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) float gt[2][32 * 36];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int theta = lane & 31, hh = lane >> 5;
+    const int HG = g.H / NW;
+    const int hd = (blockIdx.x % HG) * NW + wave;
+    const int t = blockIdx.x / HG;
+    const int qb = t % NB, b = t / NB;
+    const int qrow = qb * 32 + theta;
+    const bool qok = qrow < g.T;
+    const int qc = min(qrow, g.T - 1);
+    float part = 0.f;
+    {
+        const int64_t off = (int64_t)b * g.osb + (int64_t)hd * g.osh + (int64_t)qc * g.ost + 32 * hh;
+        const float* op = o + off;
+        const float* dp = d_o + off;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(op + 4 * i), c = *reinterpret_cast<const f32x4*>(dp + 4 * i);
+            part += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+        }
+    }
+    part += __shfl_xor(part, 32);
+    const float l2q = qok ? lse2[((int64_t)b * g.H + hd) * g.T + qrow] : INFINITY;
+    const float* sp = sres + sres_block(g, NB, b, hd, qb, 0) + lane * 4;
+    const bool loader = tid < 256;                         // the first four waves fetch the gm blocks
+    const int lrow = (tid & 255) >> 3, lc = (tid & 7) * 4;  // this thread's float4 of a gm block: row lrow, columns lc ..
+    const float* gl = gm + (int64_t)b * gm_sb + (int64_t)min(qb * 32 + lrow, g.T - 1) * gm_st + lc;
+    const int nfull = g.T >> 5;                            // key blocks entirely inside [0, T)
+    float rho = 0.f;
+    f32x4 sv[4], svn[4], gn;
+    if (nfull > 0) {
+        if (loader) gn = *reinterpret_cast<const f32x4*>(gl);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) sv[gq] = SRES_LOAD_NT(sp + gq * 256);
+        if (loader) *reinterpret_cast<f32x4*>(&gt[0][lrow * 36 + lc]) = gn;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        acr_barrier_nofence();
+    }
+    for (int kb = 0; kb < nfull; ++kb) {
+        const bool more = kb + 1 < nfull;
+        if (more) {
+            if (loader) gn = *reinterpret_cast<const f32x4*>(gl + (kb + 1) * 32);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) svn[gq] = SRES_LOAD_NT(sp + (int64_t)(kb + 1) * SB_FLOATS + gq * 256);
+        }
+        const float* gb = &gt[kb & 1][theta * 36 + 4 * hh];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gb + 8 * gq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rho = fmaf(__builtin_amdgcn_exp2f(sv[gq][e] - l2q), gv[e], rho);
+        }
+        if (more) {
+            if (loader) *reinterpret_cast<f32x4*>(&gt[(kb + 1) & 1][lrow * 36 + lc]) = gn;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) sv[gq] = svn[gq];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of buffer kb & 1 and its writes of the other one
+        acr_barrier_nofence();
+    }
+    if (nfull < NB) {                                       // the partial last key block: as the kernel above (scores there are -inf past T)
+        const int k0 = nfull * 32;
+        const float* gr = gm + (int64_t)b * gm_sb + (int64_t)qc * gm_st;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + (int64_t)nfull * SB_FLOATS + gq * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gv = gr[min(k0 + 8 * gq + 4 * hh + e, g.T - 1)];
+                rho = fmaf(__builtin_amdgcn_exp2f(s4[e] - l2q), gv, rho);
+            }
+        }
+    }
+    rho += __shfl_xor(rho, 32);
+    if (hh == 0 && qok) delta[((int64_t)b * g.H + hd) * g.T + qrow] = part + rho * (1.f / (float)g.H);
+}
+
 __global__ __launch_bounds__(256) void attn_pmean_sres_kernel(AttnGeom g, int NB, const float* __restrict__ sres,
                                                               const float* __restrict__ lse2, float* __restrict__ out,
                                                               int64_t out_sb, int64_t out_st) {
@@ -680,8 +769,14 @@ void acr_attn_pmean_sres(const AttnGeom& g, const float* scores, const float* ls
 void acr_attn_delta_sres(const AttnGeom& g, const float* scores, const float* o, const float* d_o, const float* lse2, const float* gm,
                          int64_t gm_sb, int64_t gm_st, float* delta, hipStream_t st) {
     const int NB = (g.T + 31) / 32;
-    hipLaunchKernelGGL(attn_delta_sres_kernel, dim3((g.B * NB * g.H + 3) / 4), dim3(256), 0, st, g, NB, scores, o, d_o, lse2, gm, gm_sb,
-                       gm_st, delta);
+    // groups of FOUR heads: with all twelve heads of ViT-B in one workgroup gm is fetched once instead of three times, but the
+    // twelve-wave barrier per key block costs more than that saves (277 us against 254 us per launch at the bench shape)
+    if (gm != nullptr && (g.H % 4) == 0 && acr_opt(ACR_OPT_ATTN_DELTA_1HEAD) == 0)
+        hipLaunchKernelGGL(attn_delta_sres4_kernel<4>, dim3(g.B * NB * (g.H / 4)), dim3(256), 0, st, g, NB, scores, o, d_o, lse2, gm, gm_sb, gm_st,
+                           delta);
+    else
+        hipLaunchKernelGGL(attn_delta_sres_kernel, dim3((g.B * NB * g.H + 3) / 4), dim3(256), 0, st, g, NB, scores, o, d_o, lse2, gm, gm_sb,
+                           gm_st, delta);
 }
 
 void acr_attn_bwd_f32_sres(const AttnGeom& g, const float* q, const float* k, const float* v, const float* o, const float* d_o,

@@ -85,7 +85,7 @@ typedef enum acr_option {
     ACR_OPT_WGRAD_WAVES = 4,    /* 4 or 8 waves per 256x256 workgroup */
     ACR_OPT_DQ_VARIANT = 5,     /* acr_attn_bwd (bf16) dQ sweep: 0 = by presence of G, 2 = 2-wave, 4 = 4-wave */
     ACR_OPT_GEMM_F32_REGSTAGE = 6, /* 1: acr_gemm_f32 always takes the register-staged kernel (A/B of the LDS-DMA kernel) */
-    ACR_OPT_RESERVED_7 = 7,      /* was ACR_OPT_GEMM_X3_MFMA16 (16x16x32 image products: a tested negative result, out of the library since round 5) */
+    ACR_OPT_ATTN_DELTA_1HEAD = 7, /* 1: the delta pass of the resident-score backward keeps one wave per (query block, head) reading the gradient block from HBM itself (A/B of the 4-head LDS-staged kernel) */
     ACR_OPT_RESERVED_8 = 8,      /* was ACR_OPT_ATTN_F32_NW (five-wave forward workgroups: measured slower, out of the library since round 5) */
     ACR_OPT_GEMM_F32_NOTAIL = 9, /* 1: acr_gemm_f32 NT / NN never K-splits the tiles beyond the last whole half-round (A/B) */
     ACR_OPT_ATTN_F32_NOSPLITTAIL = 10, /* 1: resident-score attention keeps the leftover 32-row block as an ordinary (1 live wave) workgroup (A/B) */

@@ -128,6 +128,32 @@ def test_attention_f32(B, T, H, with_g, gen, monkeypatch):
     assert (qkv.grad.double() - qd.grad).abs().max() <= 3e-5 * scale, (qkv.grad.double() - qd.grad).abs().max() / scale
 
 
+@pytest.mark.parametrize("math", [0, 1])
+@pytest.mark.parametrize("B,T,H", [(2, 785, 12), (1, 197, 4), (2, 64, 8), (1, 2305, 4), (1, 577, 24)])
+def test_attention_delta_kernels_agree(B, T, H, math):
+    """The delta pass of the resident-score backward (delta_i = O_i . dO_i + 1/H sum_j P_ij G_ij) with four heads per workgroup and
+    the gradient block staged through LDS (the default when H % 4 == 0) does the same operations in the same order as the
+    one-wave-per-head kernel it replaced: the whole backward repeats bit for bit under the A/B switch."""
+    from acr_wsss_amd import ops, _lib
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(T + H)
+    qkv0 = (1.5 * torch.randn(B, T, 3 * H * 64, generator=g)).to(dev)
+    d_o = torch.randn(B, T, H * 64, generator=g).to(dev)
+    gpm = torch.randn(B, T, T, generator=g).to(dev)
+    grads = []
+    try:
+        for one_head in (0, 1):
+            _lib.set_option("attn_delta_1head", one_head)
+            qkv = qkv0.clone().requires_grad_(True)
+            stack = ops.MeanStack(B, 1, T, dev)
+            o, pm = ops.attention_core(qkv, H, stack, 0, None, math)
+            ((o * d_o).sum() + (pm * gpm).sum()).backward()
+            grads.append(qkv.grad)
+    finally:
+        _lib.set_option("attn_delta_1head", 0)
+    assert torch.equal(grads[0], grads[1])
+
+
 @pytest.mark.parametrize("B,T,H", [(1, 2, 1), (2, 17, 2), (2, 197, 3), (1, 785, 12), (1, 1025, 2)])
 @pytest.mark.parametrize("with_g", [True, False])
 @pytest.mark.parametrize("f32math", [False, True])
