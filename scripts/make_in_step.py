@@ -12,17 +12,17 @@ GROUPS = {
             # forward Linears AND input gradients (NT on the cached W^T since round 2): one symbol family
             "acr_gemm_f32_nt": ["gemm_f32_dma_kernel<true, true,", "gemm_f32_kernel<true, true,"],
             "acr_gemm_f32_nn": ["gemm_f32_dma_kernel<true, false,", "gemm_f32_kernel<true, false,"],
-            "acr_attn_bwd": ["attn_delta_sres_kernel", "attn_bwd_sres_kernel", "attn_delta_dma_kernel", "attn_bwd_dma_kernel", "attn_dq_dma_kernel", "attn_dkdv_dma_kernel", "attn_delta_kernel<float>",
+            "acr_attn_bwd": ["attn_delta_sres", "attn_bwd_sres_kernel", "attn_delta_dma_kernel", "attn_bwd_dma_kernel", "attn_dq_dma_kernel", "attn_dkdv_dma_kernel", "attn_delta_kernel<float>",
                              "attn_dq_kernel<float>", "attn_dkdv_kernel<float>"],
             "acr_attn_fwd": ["attn_fwd_sres_kernel", "attn_pmean_sres_kernel", "attn_fwd_dma_kernel", "attn_pmean_dma_kernel", "attn_fwd_kernel<float>", "attn_tile_qk_kernel<float, 0>"],
             "acr_consistency_fwd": ["cons_fwd", "cons_reduce"]},
     # split products (math = "f32_split"): products on images (gemm_f32_planes_*), the image pass, split-product attention
     "f32_split": {"acr_gemm_f32_tn": ["gemm_f32_planes_tn_kernel", "gemm_f32_reduce"],
                   "acr_gemm_f32_nt": ["gemm_f32_planes_kernel<"],
-                  "acr_x3_image": ["planes_tile_kernel", "planes_tile_t_kernel", "planes_colsum_kernel"],
-                  "acr_attn_bwd": ["attn_delta_sres_kernel", "attn_bwd_x3_kernel"],
+                  "acr_x3_image": ["planes_tile_kernel", "planes_tile_t_kernel", "planes_tile_many", "planes_colsum_kernel"],
+                  "acr_attn_bwd": ["attn_delta_sres", "attn_bwd_x3_kernel"],
                   "acr_attn_fwd": ["attn_fwd_x3_kernel", "attn_pmean_sres_kernel"],
-                  "acr_conv_stem": ["gemm_f32_split_kernel", "gemm_f32_wimg_kernel", "conv3x3_", "conv1x1_ksum"],
+                  "acr_conv_stem": ["gemm_f32_split_kernel", "gemm_f32_wimg", "conv3x3_", "conv1x1_ksum", "c3_s2d", "c3_d2s", "c3_zero", "subsample2"],
                   "acr_groupnorm": ["gnf_"],
                   "acr_consistency_fwd": ["cons_fwd", "cons_reduce"]},
     "bf16": {"acr_wgrad_bf16": ["gemm_tn_bf16", "wgrad_reduce"],
