@@ -41,10 +41,10 @@ FLOP_PER_IMG_448 = 1.1307e12          # SURVEY 6 [probe]: 2 views, fwd+bwd, hybr
 # MI355X_MICROARCH.md: dense matrix peaks.  f32_split: six bf16 MFMAs per fp32-equivalent product -> bf16 peak / 6
 PEAK_MFMA = {"f32": 157.3e12, "f32_split": 2.5e15 / 6, "bf16": 2.5e15}
 PRECISION = {"f32": "fp32 end to end (reference precision, exact-fp32 MFMA)",
-             "f32_split": "fp32 tensors end to end; every Linear / 1x1-convolution / attention product evaluated on the bf16 MFMA as six exact "
+             "f32_split": "fp32 tensors end to end; every Linear / convolution (1x1, 3x3, the 7x7 stem one) / attention product evaluated on the bf16 MFMA as six exact "
                           "terms of a three-way operand split (24 mantissa bits per operand), fp32 accumulation -- as accurate against fp64 as the "
                           "fp32 FMA chain (every fp32 parity test runs under it at the same tolerances; adversarial-operand test <= 2x the exact "
-                          "kernel's error); softmax, norms, loss, optimizer and the stem's 3x3 / 7x7 convolutions: exact fp32 as in f32",
+                          "kernel's error); softmax, norms, loss, optimizer: exact fp32 as in f32",
              "bf16": "bf16 params/activations/grads + bf16 MFMA, fp32 master weights + fp32 accumulate/softmax/loss"}
 # rocprofv3 kernel-trace of this bench + separate PMC passes, per dtype, recorded BY THE BUILDER on its own gpurun box and
 # committed: the `in_step` blocks and `traffic` figures of the line are CONSTANTS read from this file, not measurements of the
