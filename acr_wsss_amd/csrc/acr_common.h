@@ -88,3 +88,53 @@ __device__ __forceinline__ void acr_store4<__bf16>(__bf16* p, f32x4 v) {
 }
 template <typename T>
 __device__ __forceinline__ float acr_load1(const T* p) { return (float)*p; }
+
+// ---- slab sums of a K-split product whose OUTPUT is small --------------------------------------------------------------------------
+// out[i] = sum_k slab[k][i] (float4 per column index i < n4).  One thread per output float4 walking all slabs (the products' own
+// reduce kernels) leaves a 64 x 64 weight gradient with 4 workgroups reading 256 slabs one after the other: 123 us for 4 MB
+// (scripts/lab/conv_wgrad_trace.py; the stem's 1x1 / 3x3 weight gradients spent 1.4 ms per step there).  Here a workgroup is
+// 32 columns x G slab groups: thread (tx, ty) sums slabs ty, ty + G, ... in ascending order with four loads in flight, and the G
+// partial sums meet in LDS, where they are added in group order.  Deterministic: the grouping depends on (n4, nslab) only.
+template <int G>
+__global__ __launch_bounds__(32 * G) void acr_slab_sum_wide_kernel(const float* __restrict__ ws, int nslab, int64_t n4, float* __restrict__ out) {
+    __shared__ f32x4 part[G][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + tx;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(ws) + i;
+        int k = ty;
+        for (; k + 3 * G < nslab; k += 4 * G) {
+            const f32x4 v0 = p[(int64_t)k * n4], v1 = p[(int64_t)(k + G) * n4], v2 = p[(int64_t)(k + 2 * G) * n4], v3 = p[(int64_t)(k + 3 * G) * n4];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < nslab; k += G) s += p[(int64_t)k * n4];
+    }
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < n4) {
+        f32x4 t = part[0][tx];
+#pragma unroll
+        for (int g = 1; g < G; ++g) t += part[g][tx];
+        reinterpret_cast<f32x4*>(out)[i] = t;
+    }
+}
+// slab groups for an output of n4 float4: enough threads to keep ~128k loads in flight, 0 = the one-thread-per-output kernel is fine
+static inline int acr_slab_sum_groups(int nslab, int64_t n4) {
+    if (n4 >= 65536 || nslab < 8) return 0;
+    int g = 32;
+    while (g > 4 && n4 * (g / 2) >= 131072) g >>= 1;
+    while (g > 4 && g > nslab) g >>= 1;
+    return g;
+}
+// true when the wide kernel took the sum
+static inline bool acr_slab_sum_wide(const float* ws, int nslab, int64_t n4, float* out, hipStream_t st) {
+    const int g = acr_slab_sum_groups(nslab, n4);
+    if (g == 0) return false;
+    const dim3 grid((unsigned)((n4 + 31) / 32));
+    if (g == 32) hipLaunchKernelGGL((acr_slab_sum_wide_kernel<32>), grid, dim3(1024), 0, st, ws, nslab, n4, out);
+    else if (g == 16) hipLaunchKernelGGL((acr_slab_sum_wide_kernel<16>), grid, dim3(512), 0, st, ws, nslab, n4, out);
+    else if (g == 8) hipLaunchKernelGGL((acr_slab_sum_wide_kernel<8>), grid, dim3(256), 0, st, ws, nslab, n4, out);
+    else hipLaunchKernelGGL((acr_slab_sum_wide_kernel<4>), grid, dim3(128), 0, st, ws, nslab, n4, out);
+    return true;
+}

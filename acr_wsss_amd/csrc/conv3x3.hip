@@ -939,8 +939,9 @@ extern "C" int acr_conv3x3_wgrad_f32(int32_t math, const float* dy, const float*
     if (wide64) hipLaunchKernelGGL(conv3x3_wgrad64_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, st, g);
     else hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, st, g);
     const int64_t n4 = (int64_t)cout * 9 * cin / 4;
-    hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsamp * g.ksplit, n4,
-                       dw_packed);
+    if (!acr_slab_sum_wide(ws, nsamp * g.ksplit, n4, dw_packed, st))
+        hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsamp * g.ksplit, n4,
+                           dw_packed);
     return acr_check_launch("acr_conv3x3_wgrad_f32");
 }
 
@@ -1204,6 +1205,7 @@ extern "C" int acr_conv_taps_wgrad_f32(int32_t math, const float* dy, const floa
     if (wide64) hipLaunchKernelGGL(conv3x3_wgrad64_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, st, g);
     else hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, st, g);
     const int64_t n4 = (int64_t)cout * ntap * cin / 4;
-    hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsamp * g.ksplit, n4, dw_packed);
+    if (!acr_slab_sum_wide(ws, nsamp * g.ksplit, n4, dw_packed, st))
+        hipLaunchKernelGGL(conv3x3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsamp * g.ksplit, n4, dw_packed);
     return acr_check_launch("acr_conv_taps_wgrad_f32");
 }

@@ -2183,6 +2183,7 @@ extern "C" int acr_conv1x1_wgrad_f32(int32_t math, const float* dy, const float*
     else
         hipLaunchKernelGGL((gemm_f32_kernel<true, true, 3>), grid, dim3(256), 0, st, g);
     const int64_t n4 = (int64_t)cout * cin / 4;
-    hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, g.nsplit, n4, dw);
+    if (!acr_slab_sum_wide(ws, g.nsplit, n4, dw, st))
+        hipLaunchKernelGGL(gemm_f32_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, g.nsplit, n4, dw);
     return acr_check_launch("acr_conv1x1_wgrad_f32");
 }
