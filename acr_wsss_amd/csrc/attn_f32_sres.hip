@@ -165,11 +165,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_sres_kernel
 // accumulator-order float4 reads of 16 lanes then touch every bank once) and all four waves read it from there; double-buffered,
 // one fence-free barrier per key block, the next block's scores and gm piece in flight meanwhile.  Same operations in the same order
 // as the kernel above: bit-identical delta.
-template <int NW> __global__ __launch_bounds__(64 * NW) void attn_delta_sres4_kernel(AttnGeom g, int NB, const float* __restrict__ sres,
+#ifndef DELTA4_MINB
+#define DELTA4_MINB 1
+#endif
+template <int NW> __global__ __launch_bounds__(64 * NW, DELTA4_MINB) void attn_delta_sres4_kernel(AttnGeom g, int NB, const float* __restrict__ sres,
                                                                const float* __restrict__ o, const float* __restrict__ d_o,
                                                                const float* __restrict__ lse2, const float* __restrict__ gm,
                                                                int64_t gm_sb, int64_t gm_st, float* __restrict__ delta) {
-    __shared__ __attribute__((aligned(16))) float gt[2][32 * 36];
+    __shared__ __attribute__((aligned(16))) float gt[3][32 * 36];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int theta = lane & 31, hh = lane >> 5;
     const int HG = g.H / NW;
@@ -198,36 +201,41 @@ template <int NW> __global__ __launch_bounds__(64 * NW) void attn_delta_sres4_ke
     const float* gl = gm + (int64_t)b * gm_sb + (int64_t)min(qb * 32 + lrow, g.T - 1) * gm_st + lc;
     const int nfull = g.T >> 5;                            // key blocks entirely inside [0, T)
     float rho = 0.f;
-    f32x4 sv[4], svn[4], gn;
-    if (nfull > 0) {
-        if (loader) gn = *reinterpret_cast<const f32x4*>(gl);
+    // Three register sets / three LDS tiles in rotation: the loads of key block kb + 2 are issued before block kb is summed, so two
+    // blocks (8 KB per wave) are in flight across every barrier.  With one block ahead -- loads issued, the previous block summed
+    // (300 cycles), loads waited for, barrier -- a step took the slowest of the four waves' memory round trips: 3.8 TB/s.
+    f32x4 sv[3][4], gn[3];
+    auto fetch = [&](int kb, int set) {
+        if (loader) gn[set] = *reinterpret_cast<const f32x4*>(gl + kb * 32);
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) sv[gq] = SRES_LOAD_NT(sp + gq * 256);
-        if (loader) *reinterpret_cast<f32x4*>(&gt[0][lrow * 36 + lc]) = gn;
+        for (int gq = 0; gq < 4; ++gq) sv[set][gq] = SRES_LOAD_NT(sp + (int64_t)kb * SB_FLOATS + gq * 256);
+    };
+    if (nfull > 0) {
+        fetch(0, 0);
+        if (nfull > 1) fetch(1, 1);
+        if (loader) *reinterpret_cast<f32x4*>(&gt[0][lrow * 36 + lc]) = gn[0];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         acr_barrier_nofence();
     }
-    for (int kb = 0; kb < nfull; ++kb) {
-        const bool more = kb + 1 < nfull;
-        if (more) {
-            if (loader) gn = *reinterpret_cast<const f32x4*>(gl + (kb + 1) * 32);
+    for (int kb0 = 0; kb0 < nfull; kb0 += 3) {
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) svn[gq] = SRES_LOAD_NT(sp + (int64_t)(kb + 1) * SB_FLOATS + gq * 256);
+        for (int u = 0; u < 3; ++u) {
+            const int kb = kb0 + u;
+            if (kb < nfull) {                               // workgroup-uniform
+                constexpr int n1[3] = {1, 2, 0}, n2[3] = {2, 0, 1};
+                if (kb + 2 < nfull) fetch(kb + 2, n2[u]);
+                const float* gb = &gt[u][theta * 36 + 4 * hh];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(gb + 8 * gq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rho = fmaf(__builtin_amdgcn_exp2f(sv[u][gq][e] - l2q), gv[e], rho);
+                }
+                if (kb + 1 < nfull && loader) *reinterpret_cast<f32x4*>(&gt[n1[u]][lrow * 36 + lc]) = gn[n1[u]];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile u and its writes of the next one
+                acr_barrier_nofence();
+            }
         }
-        const float* gb = &gt[kb & 1][theta * 36 + 4 * hh];
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(gb + 8 * gq);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rho = fmaf(__builtin_amdgcn_exp2f(sv[gq][e] - l2q), gv[e], rho);
-        }
-        if (more) {
-            if (loader) *reinterpret_cast<f32x4*>(&gt[(kb + 1) & 1][lrow * 36 + lc]) = gn;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) sv[gq] = svn[gq];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of buffer kb & 1 and its writes of the other one
-        acr_barrier_nofence();
     }
     if (nfull < NB) {                                       // the partial last key block: as the kernel above (scores there are -inf past T)
         const int k0 = nfull * 32;
@@ -771,9 +779,12 @@ void acr_attn_delta_sres(const AttnGeom& g, const float* scores, const float* o,
     const int NB = (g.T + 31) / 32;
     // groups of FOUR heads: with all twelve heads of ViT-B in one workgroup gm is fetched once instead of three times, but the
     // twelve-wave barrier per key block costs more than that saves (277 us against 254 us per launch at the bench shape)
-    if (gm != nullptr && (g.H % 4) == 0 && acr_opt(ACR_OPT_ATTN_DELTA_1HEAD) == 0)
-        hipLaunchKernelGGL(attn_delta_sres4_kernel<4>, dim3(g.B * NB * (g.H / 4)), dim3(256), 0, st, g, NB, scores, o, d_o, lse2, gm, gm_sb, gm_st,
-                           delta);
+#ifndef DELTA4_NW
+#define DELTA4_NW 4
+#endif
+    if (gm != nullptr && (g.H % DELTA4_NW) == 0 && acr_opt(ACR_OPT_ATTN_DELTA_1HEAD) == 0)
+        hipLaunchKernelGGL(attn_delta_sres4_kernel<DELTA4_NW>, dim3(g.B * NB * (g.H / DELTA4_NW)), dim3(64 * DELTA4_NW), 0, st, g, NB, scores, o, d_o,
+                           lse2, gm, gm_sb, gm_st, delta);
     else
         hipLaunchKernelGGL(attn_delta_sres_kernel, dim3((g.B * NB * g.H + 3) / 4), dim3(256), 0, st, g, NB, scores, o, d_o, lse2, gm, gm_sb,
                            gm_st, delta);
