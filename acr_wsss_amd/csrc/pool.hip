@@ -105,6 +105,98 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(const T* __restric
     store8(dx + (nc * H + h) * W + w0, g);
 }
 
+// fp32 maps with no left / top padding (the stem's SAME pool of an even-sized map: pad (0,1,0,1)) and W % 8 == 0: FOUR outputs of a row
+// per thread -- the 9 input columns they cover are two 16-byte loads + one float per input row, the outputs one 16-byte store and
+// their argmax bytes one 4-byte store (one output per thread with nine 4-byte loads ran at 2.2 TB/s).  Windows are walked in the
+// scalar kernel's (i, j) order with its comparison, so maxima and argmax bytes are the same.
+__global__ __launch_bounds__(256) void maxpool_fwd_vec4_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ amax,
+                                                               int64_t total4, int H, int W, int Ho, int Wo) {
+    const int64_t t4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t4 >= total4) return;
+    const int Wq = Wo >> 2;
+    const int wq = (int)(t4 % Wq);
+    const int64_t t = t4 / Wq;
+    const int ho = (int)(t % Ho);
+    const int64_t nc = t / Ho;
+    const float* xp = x + nc * H * W + 8 * wq;
+    const bool last = 8 * wq + 8 < W;                        // the ninth column exists
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {0, 0, 0, 0};
+    bool have[4] = {false, false, false, false};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int h = 2 * ho + i;
+        if (h < H) {
+            const float* rp = xp + (int64_t)h * W;
+            const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp)), b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + 4));
+            const float v[9] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], last ? rp[8] : 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (2 * k + j < 8 || last) {
+                        const float u = v[2 * k + j];
+                        if (!have[k] || u > best[k] || u != u) { best[k] = u; arg[k] = i * 3 + j; have[k] = true; }
+                    }
+                }
+        }
+    }
+    const int64_t o = (nc * Ho + ho) * Wo + 4 * wq;
+    *reinterpret_cast<f32x4*>(y + o) = f32x4{best[0], best[1], best[2], best[3]};
+    *reinterpret_cast<uint32_t*>(amax + o) = (uint32_t)arg[0] | ((uint32_t)arg[1] << 8) | ((uint32_t)arg[2] << 16) | ((uint32_t)arg[3] << 24);
+}
+// Backward of the same geometry (H even): a thread owns input rows 2r, 2r+1 x 8 columns.  The windows that can put their maximum
+// there are rows r-1 (its third row) and r (its first two) x columns 4q-1 .. 4q+3: per window row one 4-byte + one 1-byte argmax load
+// and one 16-byte + one 4-byte gradient load, every contribution added in the scalar kernel's (ho, wo) order -- the same sums bit
+// for bit, with each window row read by two threads instead of by every pixel it touches.
+__global__ __launch_bounds__(256) void maxpool_bwd_vec2x8_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ amax, float* __restrict__ dx,
+                                                                 int64_t total, int H, int W, int Ho, int Wo) {
+    const int64_t tix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tix >= total) return;
+    const int W8 = W >> 3;
+    const int q = (int)(tix % W8);
+    const int64_t t = tix / W8;
+    const int r = (int)(t % (H >> 1));
+    const int64_t nc = t / (H >> 1);
+    const float* dyp = dy + nc * Ho * Wo;
+    const uint8_t* ap = amax + nc * Ho * Wo;
+    float g[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[a][k] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int ho = r - 1 + d;
+        if (ho < 0 || ho >= Ho) continue;
+        const int64_t ro = (int64_t)ho * Wo + 4 * q;
+        const uint32_t a4 = *reinterpret_cast<const uint32_t*>(ap + ro);
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(dyp + ro);
+        int am[5];
+        float vv[5];
+        am[0] = q > 0 ? (int)ap[ro - 1] : 255;               // window column 4q-1 (none left of the map)
+        vv[0] = q > 0 ? dyp[ro - 1] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { am[c + 1] = (int)((a4 >> (8 * c)) & 255u); vv[c + 1] = v4[c]; }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            if (am[c] == 255) continue;
+            const int i = am[c] / 3, j = am[c] - 3 * i;
+            const int row = 2 * ho + i - 2 * r;              // 0, 1: mine
+            const int e = 2 * (4 * q - 1 + c) + j - 8 * q;   // column inside my 8
+            if (row >= 0 && row < 2 && e >= 0 && e < 8) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) g[a][k] += (a == row && k == e) ? vv[c] : 0.f;
+            }
+        }
+    }
+    float* o = dx + (nc * H + 2 * r) * W + 8 * q;
+    store8(o, g[0]);
+    store8(o + W, g[1]);
+}
+
 template <typename T>
 static int maxpool_fwd(const char* what, const void* x, void* y, uint8_t* amax, int64_t nc, int32_t h, int32_t w, int32_t ho, int32_t wo,
                        int32_t pad_top, int32_t pad_left, void* stream) {
@@ -114,6 +206,13 @@ static int maxpool_fwd(const char* what, const void* x, void* y, uint8_t* amax, 
                   "%s: every window must contain at least one input pixel", what);
     const int64_t total = nc * ho * wo;
     ACR_CHECK_ARG((total + 255) / 256 < (1ll << 31), "%s: too large", what);
+    if (sizeof(T) == 4 && pad_top == 0 && pad_left == 0 && (w % 8) == 0 && wo * 2 == w && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+        ((uintptr_t)amax & 3) == 0) {
+        const int64_t total4 = total / 4;
+        hipLaunchKernelGGL(maxpool_fwd_vec4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y,
+                           amax, total4, h, w, ho, wo);
+        return acr_check_launch(what);
+    }
     hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y,
                        amax, total, h, w, ho, wo, pad_top, pad_left);
     return acr_check_launch(what);
@@ -127,6 +226,13 @@ static int maxpool_bwd(const char* what, const void* dy, const uint8_t* amax, vo
                   "%s: bad geometry", what);
     const int64_t total = nc * h * w;
     ACR_CHECK_ARG((total + 255) / 256 < (1ll << 31), "%s: too large", what);
+    if (sizeof(T) == 4 && pad_top == 0 && pad_left == 0 && (w % 8) == 0 && (h % 2) == 0 && wo * 2 == w && ho * 2 == h && ((uintptr_t)dx & 15) == 0 &&
+        ((uintptr_t)dy & 15) == 0 && ((uintptr_t)amax & 3) == 0) {
+        const int64_t nthr = total / 16;
+        hipLaunchKernelGGL(maxpool_bwd_vec2x8_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, amax,
+                           (float*)dx, nthr, h, w, ho, wo);
+        return acr_check_launch(what);
+    }
     if ((w % 8) == 0 && ((uintptr_t)dx & 15) == 0) {
         const int64_t total8 = total / 8;
         hipLaunchKernelGGL(maxpool_bwd_vec_kernel<T>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dy,

@@ -495,7 +495,7 @@ def test_conv1x1_bf16(N, cin, cout, H, W):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (2, 5, 9, 11), (1, 64, 224, 224), (2, 4, 7, 16)])
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (2, 5, 9, 11), (1, 64, 224, 224), (2, 4, 7, 16), (3, 2, 16, 24)])
 def test_maxpool_same_bf16(shape, dtype):
     """SAME-padded 3x3/2 max-pool (forward value, argmax routing of the gradient) vs F.pad(-inf)+max_pool2d, bf16 and fp32
     maps; values are made distinct so the argmax is unique and the comparison is exact."""
