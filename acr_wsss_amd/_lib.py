@@ -141,6 +141,8 @@ SIGNATURES = {
     "acr_layernorm_image_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "acr_tokens_fwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "acr_tokens_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "acr_mlsm_fwd_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "acr_mlsm_bwd_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "acr_subsample2_fwd_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "acr_subsample2_bwd_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "acr_preprocess_batch": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, ctypes.POINTER(c_float), ctypes.POINTER(c_float),

@@ -1584,6 +1584,40 @@ def consistency(a, p, a2=None):
     return out[0], out[1]
 
 
+class MlsmFn(Function):
+    """F.multilabel_soft_margin_loss(x, y) (mean reduction) of fp32 logits as one launch each way (csrc/mlsm.hip); the upstream
+    gradient stays on the device."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        N, C = x.shape
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        L.check(L.load().acr_mlsm_fwd_f32(L.ptr(x), x.stride(0), L.ptr(y), y.stride(0), N, C, L.ptr(out), L.stream_ptr()), "acr_mlsm_fwd_f32")
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        N, C = x.shape
+        g = g.to(torch.float32).contiguous()
+        dx = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        L.check(L.load().acr_mlsm_bwd_f32(L.ptr(x), x.stride(0), L.ptr(y), y.stride(0), L.ptr(g), N, C, L.ptr(dx), L.stream_ptr()),
+                "acr_mlsm_bwd_f32")
+        return dx, None
+
+
+def mlsm_loss(x, y):
+    """multilabel_soft_margin_loss(x, y): the HIP kernel pair for fp32 (N, C) logits on the GPU, the stock op otherwise."""
+    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and y.shape == x.shape and y.is_cuda and x.stride(1) == 1
+            and not torch.is_autocast_enabled()):
+        y = y.to(torch.float32)
+        if y.stride(1) != 1:
+            y = y.contiguous()
+        return MlsmFn.apply(x, y)
+    return torch.nn.functional.multilabel_soft_margin_loss(x, y)
+
+
 def patch_cam(x, weight, bias):
     """relu(x @ weight.T + bias) for patch tokens x (N, D) -> (N, C) fp32 (DPT/ACR.py:133-134)."""
     L.require_gpu(x, weight, bias)

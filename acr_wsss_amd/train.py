@@ -29,8 +29,8 @@ def acr_loss(cls_list, attn_list, label, p, alpha):
     else:
         cls_align, aff_align = ops.consistency(attn_list[0], p, attn_list[1])
     x1, x2 = cls_list[0], cls_list[1]
-    cls_loss_1 = F.multilabel_soft_margin_loss(x1.float(), label)
-    cls_loss_2 = F.multilabel_soft_margin_loss(x2.float(), label)
+    cls_loss_1 = ops.mlsm_loss(x1.float(), label)
+    cls_loss_2 = ops.mlsm_loss(x2.float(), label)
     loss = cls_loss_1 + cls_loss_2 + cls_align * alpha + aff_align * alpha
     return loss, dict(cls_loss_1=cls_loss_1, cls_loss_2=cls_loss_2, cls_align=cls_align, aff_align=aff_align, loss=loss)
 

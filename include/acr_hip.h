@@ -438,6 +438,13 @@ int acr_weight_std_bf16(const void* desc_dev, int32_t n_conv, int32_t total_chan
 int acr_weight_std_f32(const void* desc_dev, int32_t n_conv, int32_t total_channels, float eps, int32_t backward,
                        void* stream);                /* fp32 tensors, same descriptor table */
 
+/* ---- multilabel soft-margin loss of the class logits (train_acr.py:160-161: F.multilabel_soft_margin_loss(x, label) per view) ----
+ * x, y: (N, C) fp32 with row pitches ldx, ldy (elements); loss[0] = mean_n (1/C) sum_c -(y ls(x) + (1 - y) ls(-x)), ls = log-sigmoid.
+ * Backward: dx (N, C) dense = g[0] * (sigmoid(x) - y) / (N C), g = the upstream gradient of the scalar loss, in DEVICE memory.
+ * One launch each way (the stock op: ~20 launches per view and direction); deterministic. */
+int acr_mlsm_fwd_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, int32_t N, int32_t C, float* loss, void* stream);
+int acr_mlsm_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* g, int32_t N, int32_t C, float* dx, void* stream);
+
 /* ---- attention-consistency regulariser (train_acr.py:143-161, inline in train()) ----
  * a1, a2: (B,L,T,T) fp32 head-mean stacks of view 1 / view 2 (T = p*p + 1), batch stride a_sb each
  * (so both may live in one (2B,L,T,T) buffer).  With pi(i*p+j) = i*p+(p-1-j):

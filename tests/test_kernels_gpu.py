@@ -1636,3 +1636,29 @@ def test_c_abi_launches_capture_into_a_hip_graph():
         torch.cuda.synchronize()
         for got, want in zip((o, pm, dqkv, y), ref):
             assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,pitch", [(16, 20, 20), (3, 80, 96), (300, 7, 7), (1, 1, 4)])
+def test_mlsm_loss(N, C, pitch):
+    """ops.mlsm_loss (csrc/mlsm.hip, one launch each way) against F.multilabel_soft_margin_loss in float64: the loss of
+    train_acr.py:160-161 and its gradient w.r.t. the logits, with an upstream gradient that is not 1, for logits whose rows sit in a
+    wider buffer and logits far in both tails of the log-sigmoid."""
+    from acr_wsss_amd import ops
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(N * 131 + C)
+    big = (torch.randn(N, pitch, generator=g) * 6.0).to(dev)
+    if N > 2:
+        big[0, 0], big[1, 0] = 80.0, -80.0
+    x = big[:, :C].requires_grad_(True)
+    y = (torch.rand(N, C, generator=g) > 0.7).float().to(dev)
+    loss = ops.mlsm_loss(x, y)
+    (loss * 2.5).backward()
+    xd = big[:, :C].double().detach().requires_grad_(True)
+    ref = F.multilabel_soft_margin_loss(xd, y.double())
+    (ref * 2.5).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert (x.grad.double() - xd.grad).abs().max() <= 2e-6 * xd.grad.abs().max()
+    stock = F.multilabel_soft_margin_loss(big[:, :C].detach(), y)
+    assert abs(float(loss) - float(stock)) <= 1e-6 * abs(float(stock))
