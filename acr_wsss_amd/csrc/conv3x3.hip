@@ -902,11 +902,20 @@ __global__ __launch_bounds__(256) void conv3x3_reduce_kernel(const float* __rest
 
 static int c3_wgrad_ksplit(int nsamp, int cout, int cin, int HW, int ntap = 9) {
     const int tiles = (cout <= 64 ? (ntap * cin + C3G_BN - 1) / C3G_BN : ((cout + C3_BM - 1) / C3_BM) * ((ntap * cin + C3_BN - 1) / C3_BN)) * nsamp;
-    int ks = 512 / tiles;
-    const int maxs = HW / 1024;
-    if (ks > maxs) ks = maxs;
-    if (ks < 1) ks = 1;
-    const int kps = ((HW + ks - 1) / ks + 31) / 32 * 32;
+    // The chip holds 512 of these workgroups (two per CU) and a launch costs whole rounds of them: 288 tiles (128 channels at 56 x 56)
+    // as ONE round ran 319 us with 44 % of the slots empty.  Pick the pixel split that minimises
+    //     rounds x (32-pixel stages per part + 3 of prologue / epilogue)  +  slab traffic (written and read once, ~4 TB/s, in stage units)
+    // with parts of at least 256 pixels; one 32-pixel stage of two co-resident workgroups takes ~3.2 us (scripts/lab/conv_stem_time.py).
+    int best = 1;
+    double bcost = 1e30;
+    for (int ks = 1; ks <= 8 && HW / ks >= 256; ++ks) {
+        const int nst = ((HW + ks - 1) / ks + 31) / 32;
+        const int rounds = (tiles * ks + 511) / 512;
+        const double slab = ks > 1 ? (double)ks * nsamp * cout * ntap * cin * 8.0 / 4e12 / 3.2e-6 : 0.0;
+        const double cost = rounds * (nst + 3.0) + slab;
+        if (cost < bcost * 0.97) { bcost = cost; best = ks; }
+    }
+    const int kps = ((HW + best - 1) / best + 31) / 32 * 32;
     return (HW + kps - 1) / kps;
 }
 extern "C" size_t acr_conv3x3_wgrad_ws_floats(int32_t nsamp, int32_t cout, int32_t cin, int32_t H, int32_t W) {
