@@ -22,7 +22,7 @@ GROUPS = {
                   "acr_x3_image": ["planes_tile_kernel", "planes_tile_t_kernel", "planes_tile_many", "planes_colsum_kernel"],
                   "acr_attn_bwd": ["attn_delta_sres", "attn_bwd_x3_kernel"],
                   "acr_attn_fwd": ["attn_fwd_x3_kernel", "attn_pmean_sres_kernel"],
-                  "acr_conv_stem": ["gemm_f32_split_kernel", "gemm_f32_wimg", "conv3x3_", "conv1x1_ksum", "c3_s2d", "c3_d2s", "c3_zero", "subsample2"],
+                  "acr_conv_stem": ["gemm_f32_split_kernel", "gemm_f32_wimg", "conv3x3_", "conv1x1_ksum", "c3_s2d", "c3_d2s", "c3_zero", "subsample2", "acr_slab_sum_wide"],
                   "acr_groupnorm": ["gnf_"],
                   "acr_consistency_fwd": ["cons_fwd", "cons_reduce"]},
     "bf16": {"acr_wgrad_bf16": ["gemm_tn_bf16", "wgrad_reduce"],
