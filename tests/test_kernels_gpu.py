@@ -984,7 +984,7 @@ def test_groupnorm_f32(N, C, H, W, act):
 
 
 @pytest.mark.parametrize("N,cin,cout,H,W", [(2, 64, 64, 8, 8), (3, 64, 256, 16, 24), (2, 256, 64, 28, 28), (2, 1024, 256, 28, 28),
-                                             (2, 128, 512, 56, 56), (1, 64, 256, 112, 112), (2, 1024, 768, 28, 28)])
+                                             (2, 128, 512, 56, 56), (1, 64, 256, 112, 112), (2, 1024, 768, 28, 28), (8, 64, 64, 56, 56)])
 @pytest.mark.parametrize("math", [0, 1])
 def test_conv1x1_f32(N, cin, cout, H, W, math):
     """fp32 NCHW 1x1 convolution on the fp32 GEMM kernels (one z-slice per sample): forward, input gradient with the shortcut's
