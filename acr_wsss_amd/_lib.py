@@ -46,6 +46,8 @@ SIGNATURES = {
     "acr_attn_scores_floats": (c_int64, [_P]),
     "acr_attn_fwd_scores": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                       c_void_p]),
+    "acr_attn_fwd_scores_oimg": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                           c_void_p, c_void_p]),
     "acr_attn_bwd_scores": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acr_attn_bwd_ws_floats": (c_int64, [_P]),

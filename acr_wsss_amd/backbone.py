@@ -403,6 +403,11 @@ class Attention(nn.Module):
         proj GEMM epilogue on the bf16 path).  ``x_image``: x is the output of ops.layer_norm_image (it exists only as that image)."""
         self._override = {}
         qkv = ops.linear_or_hip(x, self.qkv, None, self.hip_linear, math=self.acr_math, x_image=x_image)  # packed (B, T, 3*H*64): no permute copy
+        if (self.acr_math == 1 and ops.ATTN_O_IMAGE and self.hip_linear and ops.X3_IMAGES and ops.linear_f32_usable(qkv, self.proj.weight)
+                and not torch.is_autocast_enabled() and ops._f32_ok(self.proj.weight, self.proj.bias, resid)):
+            # split products: o leaves the attention forward as proj's operand image (no image pass over o)
+            o, self.last_pm, oimg = ops.attention_core_oimg(qkv, self.num_heads, stack, layer, self, self.acr_math)
+            return ops.linear_or_hip(o, self.proj, resid, self.hip_linear, math=self.acr_math, x_image=oimg)
         o, self.last_pm = ops.attention_core(qkv, self.num_heads, stack, layer, self, self.acr_math)
         return ops.linear_or_hip(o, self.proj, resid, self.hip_linear, math=self.acr_math)
 

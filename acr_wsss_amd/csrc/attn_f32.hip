@@ -682,6 +682,30 @@ extern "C" int acr_attn_fwd_scores(const acr_attn_desc* d, const void* q, const 
     return acr_check_launch("acr_attn_fwd_scores");
 }
 
+// acr_attn_fwd_scores for ACR_F32_BF16X3 whose output ALSO leaves as the operand image of the product that reads it (proj):
+// the image pass over o (one read + the image's write, 42 us per layer at the bench shape) folds into the forward's epilogue.
+extern "C" int acr_attn_fwd_scores_oimg(const acr_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse2,
+                                        float* scores, float* pmean, int64_t pmean_sb, int64_t pmean_st, float* o_image, void* stream) {
+    int rc = check_desc(d, "acr_attn_fwd_scores_oimg");
+    if (rc) return rc;
+    if (d->dtype != ACR_F32_BF16X3) {
+        acr_set_error("acr_attn_fwd_scores_oimg: ACR_F32_BF16X3 only (the image is the split-product operand form)");
+        return ACR_ERR_UNSUPPORTED;
+    }
+    ACR_CHECK_ARG(q && k && v && o && lse2 && scores && o_image, "acr_attn_fwd_scores_oimg: null pointer");
+    ACR_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(scores) && aligned16(o_image),
+                  "acr_attn_fwd_scores_oimg: q/k/v/o/scores/o_image must be 16-byte aligned");
+    ACR_CHECK_ARG(!pmean || (pmean_st >= d->T && pmean_sb >= (int64_t)d->T * pmean_st),
+                  "acr_attn_fwd_scores_oimg: pmean row pitch < T or batch stride < T*pitch");
+    ACR_CHECK_ARG(d->o_sh == 64 && d->o_st == (int64_t)d->H * 64 && d->o_sb == (int64_t)d->T * d->o_st,
+                  "acr_attn_fwd_scores_oimg: o must be the dense (B, T, H*64) activation (its image is that of the (B*T) x (H*64) matrix)");
+    rc = check_x3(d, "acr_attn_fwd_scores_oimg");
+    if (rc) return rc;
+    acr_attn_fwd_f32_x3(geom(d), (const float*)q, (const float*)k, (const float*)v, (float*)o, lse2, scores, pmean, pmean_sb, pmean_st,
+                        (hipStream_t)stream, reinterpret_cast<char*>(o_image));
+    return acr_check_launch("acr_attn_fwd_scores_oimg");
+}
+
 extern "C" int acr_attn_bwd_scores(const acr_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
                                    const void* d_o, const float* lse2, const float* scores, const float* gmean, int64_t gmean_sb,
                                    int64_t gmean_st, void* dq, void* dk, void* dv, float* delta_ws, void* stream) {

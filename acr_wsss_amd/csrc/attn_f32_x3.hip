@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
                                                              const bf16_t* __restrict__ vp, float* __restrict__ o, float* __restrict__ lse2,
                                                              float* __restrict__ sres, const float* __restrict__ q32,
                                                              const float* __restrict__ k32, const float* __restrict__ v32,
-                                                             AttnGeom g32, int ntail) {
+                                                             AttnGeom g32, int ntail, char* __restrict__ oimg) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * X3_SLOT_B];        // [slot][K planes | V planes]
     __shared__ float mlsh[4 * 64];                                             // split tail: (m | l) of the four partial sweeps
     // The last `ntail` workgroups of the grid (dispatched after every full one) are split-tail workgroups, one per (b, h): T = 785
@@ -466,6 +466,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
             *reinterpret_cast<f32x4*>(ob + 32 + 8 * grp + 4 * h) = c;
         }
         if (h == 0) lse2[((int64_t)b * g.H + hd) * g.T + q0 + r] = m + log2f(l);
+        // The output as the NEXT product's split-product image (proj reads o as [token][feature] rows; include/acr_hip.h "split-product
+        // images"): row = b T + query of the (B T) x D matrix, this head's 64 features = 8 chunks of 8.  Lane (r, h) holds features
+        // 8 grp + 4 h .. + 3 of each quad: the two halves of a chunk sit in lanes (r, 0) and (r, 1), so the pair swaps one quad per two
+        // chunks and lane h finishes the chunks of parity h.  Same split expression as the image pass (planes_split8): same bits.
+        if (oimg != nullptr) {
+            const int64_t row = (int64_t)b * g.T + q0 + r;
+            const int nkb = g.D >> 4;
+            char* ib = oimg + ((row >> 7) * nkb + hd * 4) * (int64_t)X3_TILE_B + (int)(row & 127) * 32;
+            const int sw = (int)((row >> 3) & 1);
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float own[4], snd[4], rcv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = (half ? o1 : o0)[4 * (2 * j) + e] * inv, hi = (half ? o1 : o0)[4 * (2 * j + 1) + e] * inv;
+                        own[e] = h ? hi : lo;                   // lane 0 keeps quad 2j (chunk 2j, low half); lane 1 quad 2j+1 (chunk 2j+1, high half)
+                        snd[e] = h ? lo : hi;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rcv[e] = __shfl_xor(snd[e], 32);
+                    const float v8[8] = {h ? rcv[0] : own[0], h ? rcv[1] : own[1], h ? rcv[2] : own[2], h ? rcv[3] : own[3],
+                                         h ? own[0] : rcv[0], h ? own[1] : rcv[1], h ? own[2] : rcv[2], h ? own[3] : rcv[3]};
+                    bf16x8 p0, p1, p2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        bf16_t h0, h1, h2;
+                        x3_split1(v8[e], h0, h1, h2);
+                        p0[e] = h0; p1[e] = h1; p2[e] = h2;
+                    }
+                    const int c8 = half * 4 + 2 * j + h;        // chunk of 8 features inside the head: stage hd*4 + (c8 >> 1), half c8 & 1
+                    char* dst = ib + (c8 >> 1) * X3_TILE_B + (((c8 & 1) ^ sw) << 4);
+                    *reinterpret_cast<bf16x8*>(dst) = p0;
+                    *reinterpret_cast<bf16x8*>(dst + X3_PLANE_B) = p1;
+                    *reinterpret_cast<bf16x8*>(dst + 2 * X3_PLANE_B) = p2;
+                }
+        }
     }
 }
 
@@ -872,7 +910,7 @@ static X3Geom x3_geom(const AttnGeom& g) {
 }
 
 void acr_attn_fwd_f32_x3(const AttnGeom& g, const float* q, const float* k, const float* v, float* o, float* lse2, float* scores,
-                         float* pmean, int64_t pmean_sb, int64_t pmean_st, hipStream_t st) {
+                         float* pmean, int64_t pmean_sb, int64_t pmean_st, hipStream_t st, char* oimg) {
     const X3Geom x = x3_geom(g);
     bf16_t* planes = reinterpret_cast<bf16_t*>(scores + x3_score_floats(g));
     X3SplitArgs a;
@@ -884,9 +922,10 @@ void acr_attn_fwd_f32_x3(const AttnGeom& g, const float* q, const float* k, cons
     // measured (scripts/lab/attn_gen.py, A/B through ACR_OPT_ATTN_F32_NOSPLITTAIL): the forward's split tails pay from NB = 33 on
     // (T = 1025: 0.624 -> 0.612 ms, T = 2305 at B = 2: 0.355 -> 0.342 ms) but not at T = 785 (0.705 -> 0.724 ms: a tail workgroup's
     // 6-7 unpipelined exact-fp32 steps take about as long as the 25 pipelined split-product steps of a three-per-CU full one)
-    const int ntail = (x3_split_tail(NB, 4) && NB >= 33) ? g.B * g.H : 0;
+    // (the split-tail bodies write fp32 o only: a launch that also writes o's image keeps the leftover block on an ordinary workgroup)
+    const int ntail = (x3_split_tail(NB, 4) && NB >= 33 && oimg == nullptr) ? g.B * g.H : 0;
     hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3(g.B * g.H * (ntail ? NB / 4 : (NB + 3) / 4) + ntail), dim3(256), 0, st, x, (const bf16_t*)planes,
-                       (const bf16_t*)(planes + 3 * x.plane), (const bf16_t*)(planes + 6 * x.plane), o, lse2, scores, q, k, v, g, ntail);
+                       (const bf16_t*)(planes + 3 * x.plane), (const bf16_t*)(planes + 6 * x.plane), o, lse2, scores, q, k, v, g, ntail, oimg);
     if (pmean) acr_attn_pmean_sres(g, scores, lse2, pmean, pmean_sb, pmean_st, st);
 }
 

@@ -101,7 +101,7 @@ class AttnCoreFn(Function):
     """o = softmax(q k^T d^-0.5) v  (+ head-mean side output), packed qkv in, (B,T,D) out."""
 
     @staticmethod
-    def forward(ctx, qkv, heads, stack, layer, owner, math=0):
+    def forward(ctx, qkv, heads, stack, layer, owner, math=0, want_oimg=False):
         L.require_gpu(qkv)
         # an output nobody differentiated arrives as None in backward, not as a zero tensor: CAM generation back-propagates
         # the class logit through `o` only, and a materialised zero head-mean gradient would cost a (B,T,T) fill + re-layout
@@ -134,7 +134,20 @@ class AttnCoreFn(Function):
             scores = torch.empty(lib.acr_attn_scores_floats(d), dtype=torch.float32, device=qkv.device)
         tok = _t0("attn_fwd" if pm is not None else "attn_fwd_nomean", B, heads, T)
         pm_sb, pm_st = (pm.stride(0), pm.stride(1)) if pm is not None else (0, 0)
-        if scores is not None:
+        # the output as the operand image of the Linear behind it (proj), written by the forward's epilogue instead of by an image
+        # pass over o -- split products with resident scores only, and not where the forward runs split-tail workgroups
+        # (T = 1025, 2305, ...: they write fp32 o only)
+        oimg = None
+        if want_oimg and scores is not None and math == 1 and not ((-(-T // 32)) % 4 == 1 and T > 32 * 32):
+            rows = B * T
+            oimg = x3_image_empty(rows, D, qkv.device)
+            if rows % 128:                                  # the image contract: rows past the matrix are zero (the weight gradient contracts over rows)
+                per_block = oimg.numel() // (-(-rows // 128))
+                oimg[-per_block:].zero_()
+        if oimg is not None:
+            L.check(lib.acr_attn_fwd_scores_oimg(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(scores), L.ptr(pm), pm_sb, pm_st, L.ptr(oimg),
+                                                 L.stream_ptr()), "acr_attn_fwd_scores_oimg")
+        elif scores is not None:
             L.check(lib.acr_attn_fwd_scores(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(scores), L.ptr(pm), pm_sb, pm_st,
                                             L.stream_ptr()), "acr_attn_fwd_scores")
         else:
@@ -155,12 +168,16 @@ class AttnCoreFn(Function):
             owner._saved = (qkv, lse2, heads) if keep else None
             owner._saved_do = None
             owner._saved_gpm = None
+        if want_oimg:
+            if oimg is not None:
+                ctx.mark_non_differentiable(oimg)
+            return o, pm, oimg
         if pm is None:
             return o, None
         return o, pm
 
     @staticmethod
-    def backward(ctx, d_o, g_pm):
+    def backward(ctx, d_o, g_pm, *unused):
         saved = ctx.saved_tensors
         qkv, o, lse2 = saved[:3]
         scores = saved[3] if len(saved) > 3 else None
@@ -200,7 +217,7 @@ class AttnCoreFn(Function):
         if ctx.owner is not None:
             ctx.owner._saved_do = d_o
             ctx.owner._saved_gpm = g_pm       # dLoss/d(mean_h P): reaches every head's P as G/H (get_attn_gradients)
-        return dqkv, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None
 
 
 class StackAliasFn(Function):
@@ -220,6 +237,14 @@ class StackAliasFn(Function):
 
 def attention_core(qkv, heads, stack=None, layer=0, owner=None, math=0):
     return AttnCoreFn.apply(qkv, heads, stack, layer, owner, math)
+
+
+ATTN_O_IMAGE = os.environ.get("ACR_ATTN_O_IMAGE", "1") != "0"      # A/B: the attention output's image from the forward's epilogue
+
+
+def attention_core_oimg(qkv, heads, stack=None, layer=0, owner=None, math=0):
+    """attention_core that also returns o's split-product image (or None where the forward cannot write it): (o, pmean, o_image)."""
+    return AttnCoreFn.apply(qkv, heads, stack, layer, owner, math, True)
 
 
 def attn_probs(qkv, lse2, heads):

@@ -1662,3 +1662,23 @@ def test_mlsm_loss(N, C, pitch):
     assert (x.grad.double() - xd.grad).abs().max() <= 2e-6 * xd.grad.abs().max()
     stock = F.multilabel_soft_margin_loss(big[:, :C].detach(), y)
     assert abs(float(loss) - float(stock)) <= 1e-6 * abs(float(stock))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(3, 100), (2, 785), (1, 32), (5, 197)])
+def test_attention_output_image_is_the_pass_image(B, T):
+    """Split products: the attention forward writes its output ALSO as the split-product image the Linear behind it reads
+    (acr_attn_fwd_scores_oimg) -- bit for bit what the image pass over o writes (acr_x3_image), padding rows of the last 128-row block
+    included, and o / the head mean themselves are unchanged."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    H = 12
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + T)
+    qkv = (1.5 * torch.randn(B, T, 3 * H * 64, generator=g)).to(dev).requires_grad_(True)
+    stack = ops.MeanStack(B, 1, T, dev)
+    o1, pm1 = ops.attention_core(qkv, H, stack, 0, None, 1)
+    o1, pm1 = o1.detach().clone(), pm1.detach().clone()
+    o2, pm2, img = ops.attention_core_oimg(qkv, H, stack, 0, None, 1)
+    assert img is not None and torch.equal(o1, o2) and torch.equal(pm1, pm2)
+    ref = ops.x3_image(o2.detach().reshape(B * T, H * 64))
+    assert img.shape == ref.shape and torch.equal(img.view(torch.int32), ref.view(torch.int32))
