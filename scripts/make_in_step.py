@@ -95,5 +95,10 @@ for dt, groups in GROUPS.items():
     rec["traffic"] = traffic
     rec["traffic_note"] = "per launch of the roofline probe's geometry (fc1-shaped GEMMs; attention at B=32 views, H=12, T=785); FETCH_SIZE KB x2 x1024, WRITE_SIZE KB x1024 (MI355X_MICROARCH.md, HBM)"
     out[dt] = rec
-json.dump(out, open(os.path.join(ROOT, "profiles", "%s_in_step_kernels.json" % tag), "w"), indent=1)
+dst = os.path.join(ROOT, "profiles", "%s_in_step_kernels.json" % tag)
+if os.path.exists(dst):                                    # a run over a subset of the dtypes replaces those records only
+    prev = json.load(open(dst))
+    prev.update(out)
+    out = prev
+json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps({k: {"top": v["top"], "wall": v["wall_ms_per_step"]} for k, v in out.items()}))
