@@ -85,6 +85,13 @@ class StdConv2dSame(nn.Conv2d):
             return ops.conv1x1(x, w_hat, self._w_hat_t, self.acr_math, self._w_imgs)   # NCHW 1x1 conv = per-sample MFMA GEMM, no layout transposes
         if self.hip_3x3 and not self.dynamic_pad and ops.conv3x3_fusable(x, w_hat, self.stride[0], self.acr_math):
             return ops.conv3x3(x, w_hat, self._w_imgs)                     # split-product implicit GEMM, no layout transposes
+        if (self.hip_3x3 and self.pad_narrow and not self.dynamic_pad and x.dim() == 4 and 4 <= x.shape[3] < 16 and x.shape[3] % 4 == 0
+                and self.kernel_size == (3, 3)):
+            # maps narrower than the kernels' 16-pixel rows (CAM generation at scale 0.5: 12 x 12 in the last stage): zero columns on
+            # the right ARE the SAME padding of the last real column, so the convolution of the widened map, cut back, is the result
+            xp = F.pad(x, (0, 16 - x.shape[3]))
+            if ops.conv3x3_fusable(xp, w_hat, self.stride[0], self.acr_math):
+                return ops.conv3x3(xp, w_hat, self._w_imgs)[..., :x.shape[3]].contiguous()
         return F.conv2d(x, w_hat, None, self.stride, self.padding)
 
     def forward_skip(self, x):
@@ -98,6 +105,7 @@ class StdConv2dSame(nn.Conv2d):
     hip_1x1 = True
     hip_1x1_strided = os.environ.get("ACR_CONV1X1_STRIDED_HIP", "1") != "0"      # A/B: stride-2 1x1 convolutions as subsample + HIP GEMM
     hip_3x3 = os.environ.get("ACR_CONV3X3_HIP", "1") != "0"      # A/B: the stem's 3x3 convolutions under f32_split on csrc/conv3x3.hip
+    pad_narrow = os.environ.get("ACR_CONV3X3_PAD_NARROW", "1") != "0"      # A/B: maps of 4 / 8 / 12 columns widened to 16 instead of the library
     acr_math = 0            # _lib.MATH code of the fp32 products (set_math)
 
     _w_hat = None           # set for one forward by ResNetV2 when all weights are standardised in one fused launch

@@ -1682,3 +1682,27 @@ def test_attention_output_image_is_the_pass_image(B, T):
     assert img is not None and torch.equal(o1, o2) and torch.equal(pm1, pm2)
     ref = ops.x3_image(o2.detach().reshape(B * T, H * 64))
     assert img.shape == ref.shape and torch.equal(img.view(torch.int32), ref.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W", [4, 8, 12])
+def test_conv3x3_narrow_maps_are_widened_not_handed_to_the_library(W, monkeypatch):
+    """Split products: a 3x3 SAME convolution of a map narrower than the kernels' 16-pixel rows (the last stage of CAM generation at
+    scale 0.5 is 12 x 12) runs on the HIP kernels over a copy widened with zero columns -- which ARE the SAME padding of the last real
+    column -- and is cut back: vs float64 conv2d of the standardised weight, and F.conv2d must not be reached."""
+    from acr_wsss_amd import backbone
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(W)
+    conv = backbone.StdConv2dSame(64, 96, 3).to(dev)
+    conv.acr_math = 1
+    x = torch.randn(2, 64, 12, W, generator=g).to(dev)
+    w_hat = conv.standardized_weight().detach()
+    ref = F.conv2d(x.double(), w_hat.double(), None, 1, 1)
+    def boom(*a, **k):
+        raise AssertionError("F.conv2d reached")
+    monkeypatch.setattr(backbone.F, "conv2d", boom)
+    with torch.no_grad():
+        y = conv(x)
+    assert y.shape == ref.shape and y.is_contiguous()
+    assert (y.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
