@@ -48,6 +48,7 @@ SIGNATURES = {
                                       c_void_p]),
     "acr_attn_fwd_scores_oimg": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                            c_void_p, c_void_p]),
+    "acr_attn_fwd_oimg_offered": (c_int32, [_P]),
     "acr_attn_bwd_scores": (c_int32, [_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acr_attn_bwd_ws_floats": (c_int64, [_P]),

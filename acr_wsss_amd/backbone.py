@@ -239,6 +239,10 @@ class ResNetV2(nn.Module):
             key = (x.dtype,) + tuple((c.weight.data_ptr(), c.weight._version, c.acr_math) for c in convs)
             if self._frozen is not None and self._frozen[0] == key:
                 return self._frozen[1], self._frozen[2], self._frozen[3]
+        if torch.cuda.is_current_stream_capturing():
+            # a miss of the frozen cache inside a hipGraph capture: the standardisation / image launches upload descriptor
+            # tables from temporary pinned memory, which a replay would read again after it was recycled
+            raise RuntimeError("ResNetV2: frozen standardised-weight cache missed inside a hipGraph capture")
         # One launch per GROUP of convolutions (stem + stages 0-1 | last stage), not one for all 52 (see forward)
         w_hats, wts, imgs = [None] * len(convs), [None] * len(convs), [None] * len(convs)
         for idx in self._wstd_groups(convs):
@@ -661,6 +665,8 @@ def pass_graph(model, inp, start_layer, func):
     if g is not None and g is not False and not g.valid(model):
         del cache[key]
         g = None
+    if g is None and not _sighted(vit, key):
+        return None                            # first pass of this geometry: eager launches (see VisionTransformer.graph_sightings)
     if g is None:
         keep = vit.graph_prefix
         vit.graph_prefix = False               # the pass is captured whole: no nested replay of a prefix graph
@@ -676,10 +682,24 @@ def pass_graph(model, inp, start_layer, func):
         finally:
             vit.graph_prefix = keep
         cache[key] = g
-        while len(cache) > vit.max_prefix_graphs:
+        while len(cache) > vit.max_pass_graphs:
             cache.popitem(last=False)
     cache.move_to_end(key)
     return g or None
+
+
+def _sighted(vit, key):
+    """True once ``key`` (an input geometry) has been asked for ``vit.graph_sightings`` times: a capture costs two warm-up passes,
+    the capture itself and a private pool holding the pass's activations -- about four passes of work -- so a geometry seen ONCE
+    (natural-size images, the last short batch of a list) runs eagerly and only a recurring one is captured.  The
+    record survives a graph's invalidation (a weight update re-captures at once) and is bounded."""
+    seen = vit.__dict__.setdefault("_graph_sightings", OrderedDict())
+    n = seen.get(key, 0) + 1
+    seen[key] = n
+    seen.move_to_end(key)
+    while len(seen) > 64:
+        seen.popitem(last=False)
+    return n >= vit.graph_sightings
 
 
 class VisionTransformer(nn.Module):
@@ -798,12 +818,15 @@ class VisionTransformer(nn.Module):
     acr_math = 0            # _lib.MATH code of the patch-embedding projection's fp32 products (set_math)
     graph_prefix = os.environ.get("ACR_INFER_GRAPH", "1") != "0"      # A/B: hipGraph replay of the gradient-free prefix
     graph_pass = os.environ.get("ACR_INFER_PASS_GRAPH", "1") != "0"   # A/B: whole GETAM passes as captured graphs (PassGraph)
-    max_prefix_graphs = 8
+    max_prefix_graphs = 8   # LRU bound of the captured prefixes ...
+    max_pass_graphs = 8     # ... and, separately, of the captured whole passes (each holds its forward's saved activations)
+    graph_sightings = 2     # a geometry is captured the second time it is seen (1 = at once); variable-size inputs: INTEGRATION.md
 
     def train(self, mode=True):
         if mode:                               # back to training: the captured prefixes' private pools (activations of every
             self.__dict__.pop("_prefix_graphs", None)      # geometry seen) go back to the allocator
             self.__dict__.pop("_pass_graphs", None)
+            self.__dict__.pop("_graph_sightings", None)
         return super().train(mode)
 
     def prefix_graph(self, x, k):
@@ -821,6 +844,8 @@ class VisionTransformer(nn.Module):
         if g is not None and g is not False and not g.valid(self):
             del cache[key]                     # the parameters moved (.to / .float / load into new storage): capture again
             g = None
+        if g is None and not _sighted(self, ("prefix",) + key):
+            return None
         if g is None:
             try:
                 g = PrefixGraph(self, x, k)

@@ -33,6 +33,7 @@ void acr_attn_delta_sres(const AttnGeom& g, const float* scores, const float* o,
 // acr_attn_x3_bwd_ws_floats floats (delta + the bf16 planes of dO).
 int64_t acr_attn_x3_scores_floats(const AttnGeom& g);
 int64_t acr_attn_x3_bwd_ws_floats(const AttnGeom& g);
+bool acr_attn_x3_fwd_uses_split_tail(int T);     // forward of this T runs split-tail workgroups (which write fp32 o only)
 // oimg != nullptr: o additionally leaves as the split-product image of the (B T) x (H 64) matrix (acr_attn_fwd_scores_oimg)
 void acr_attn_fwd_f32_x3(const AttnGeom& g, const float* q, const float* k, const float* v, float* o, float* lse2, float* scores,
                          float* pmean, int64_t pmean_sb, int64_t pmean_st, hipStream_t st, char* oimg = nullptr);

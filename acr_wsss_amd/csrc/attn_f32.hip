@@ -706,6 +706,13 @@ extern "C" int acr_attn_fwd_scores_oimg(const acr_attn_desc* d, const void* q, c
     return acr_check_launch("acr_attn_fwd_scores_oimg");
 }
 
+// 1 when acr_attn_fwd_scores_oimg is the faster forward for this problem (split products, and a T whose leftover block the plain
+// forward would not hand to split-tail workgroups), 0 when the caller should run acr_attn_fwd_scores + an image pass over o.
+extern "C" int acr_attn_fwd_oimg_offered(const acr_attn_desc* d) {
+    if (!d || d->dtype != ACR_F32_BF16X3 || d->T <= 0) return 0;
+    return acr_attn_x3_fwd_uses_split_tail(d->T) ? 0 : 1;
+}
+
 extern "C" int acr_attn_bwd_scores(const acr_attn_desc* d, const void* q, const void* k, const void* v, const void* o,
                                    const void* d_o, const float* lse2, const float* scores, const float* gmean, int64_t gmean_sb,
                                    int64_t gmean_st, void* dq, void* dk, void* dv, float* delta_ws, void* stream) {

@@ -505,6 +505,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
                 }
         }
     }
+    // The image contract: rows past the matrix, up to the end of its last 128-row block, are ZERO (the weight gradient contracts over
+    // image rows).  The wave that owns the last query block of the last sample writes them for its head's four stages -- (rows, 4
+    // stages, 3 planes, 2 halves) 16-byte stores -- instead of a memset launch per layer on the host.
+    if (oimg != nullptr && live && b == g.B - 1 && q0 + 32 >= g.T) {
+        const int64_t rows = (int64_t)g.B * g.T, rend = (rows + 127) & ~(int64_t)127;
+        const int nkb = g.D >> 4;
+        const bf16x8 z = {0};
+        for (int i = lane; i < (int)(rend - rows) * 24; i += 64) {
+            const int64_t row = rows + i / 24;
+            const int rem = i % 24, stage = rem / 6, pl = (rem % 6) >> 1, half = rem & 1;
+            char* dst = oimg + ((row >> 7) * nkb + hd * 4 + stage) * (int64_t)X3_TILE_B + pl * X3_PLANE_B + (int)(row & 127) * 32 + half * 16;
+            *reinterpret_cast<bf16x8*>(dst) = z;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -909,6 +923,13 @@ static X3Geom x3_geom(const AttnGeom& g) {
     return x;
 }
 
+// does the forward with an o-image epilogue keep this T's leftover block on a split-tail workgroup?  (then the image is not offered:
+// the tail bodies write fp32 o only)
+bool acr_attn_x3_fwd_uses_split_tail(int T) {
+    const int NB = (T + 31) / 32;
+    return x3_split_tail(NB, 4) && NB >= 33;
+}
+
 void acr_attn_fwd_f32_x3(const AttnGeom& g, const float* q, const float* k, const float* v, float* o, float* lse2, float* scores,
                          float* pmean, int64_t pmean_sb, int64_t pmean_st, hipStream_t st, char* oimg) {
     const X3Geom x = x3_geom(g);
@@ -923,7 +944,7 @@ void acr_attn_fwd_f32_x3(const AttnGeom& g, const float* q, const float* k, cons
     // (T = 1025: 0.624 -> 0.612 ms, T = 2305 at B = 2: 0.355 -> 0.342 ms) but not at T = 785 (0.705 -> 0.724 ms: a tail workgroup's
     // 6-7 unpipelined exact-fp32 steps take about as long as the 25 pipelined split-product steps of a three-per-CU full one)
     // (the split-tail bodies write fp32 o only: a launch that also writes o's image keeps the leftover block on an ordinary workgroup)
-    const int ntail = (x3_split_tail(NB, 4) && NB >= 33 && oimg == nullptr) ? g.B * g.H : 0;
+    const int ntail = (acr_attn_x3_fwd_uses_split_tail(g.T) && oimg == nullptr) ? g.B * g.H : 0;
     hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3(g.B * g.H * (ntail ? NB / 4 : (NB + 3) / 4) + ntail), dim3(256), 0, st, x, (const bf16_t*)planes,
                        (const bf16_t*)(planes + 3 * x.plane), (const bf16_t*)(planes + 6 * x.plane), o, lse2, scores, q, k, v, g, ntail, oimg);
     if (pmean) acr_attn_pmean_sres(g, scores, lse2, pmean, pmean_sb, pmean_st, st);

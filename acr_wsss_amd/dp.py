@@ -83,7 +83,10 @@ class GradSync:
             # every slot starts on a 64-element (>= 128-byte) boundary: gradient views stay 16-byte aligned for the
             # vectorised consumers (fused optimizer step); the padding is zero and rides along in the all-reduce
             pad = lambda n: (n + 63) // 64 * 64
-            b.flat = torch.zeros(sum(pad(p.numel()) for p in grp), dtype=grp[0].dtype, device=grp[0].device)
+            # (+ one 64-element slot behind the LAST bucket's gradients: the static regime's "this rank deviated" flag rides
+            # along in that bucket's all-reduce, see finish())
+            extra = 64 if grp is groups[-1] else 0
+            b.flat = torch.zeros(sum(pad(p.numel()) for p in grp) + extra, dtype=grp[0].dtype, device=grp[0].device)
             b.views, off = [], 0
             for p in grp:
                 b.views.append(b.flat[off:off + p.numel()].view_as(p))
@@ -94,6 +97,10 @@ class GradSync:
             b.pending, b.work = 0, None
             b.index = len(self.buckets)
             self.buckets.append(b)
+        self._flag = self.buckets[-1].flat[-64:] if self.buckets else None      # see finish(): deviation flag of the static regime
+        self._flag_pending = None                         # (pinned host copy, event) of the previous static step's reduced flag
+        self._deviation = None                            # what THIS rank saw when it last deviated (for the message)
+        self._prev_unused = set()
         self._armed = False
         self._late = []
         self._next = 0                                    # index of the next bucket to exchange (canonical order)
@@ -116,7 +123,7 @@ class GradSync:
             self._side = dist.new_group(
                 ranks=dist.get_process_group_ranks(process_group) if process_group is not None else None, backend="gloo")
         self.stats = {"steps": 0, "bucket_launches_in_backward": 0, "bucket_launches_in_finish": 0, "late_reexchanges": 0,
-                      "rank_disagreements": 0, "agreement_exchanges": 0}
+                      "rank_disagreements": 0, "agreement_exchanges": 0, "static_deviations": 0}
 
     def describe(self):
         """What bench.py reports about the exchange (sizes in MB per bucket, launch counters so far)."""
@@ -130,6 +137,7 @@ class GradSync:
         a bucket has arrived they are copied into the bucket with ONE multi-tensor launch and ``.grad`` is re-pointed at
         the bucket views.  Slots of parameters without a gradient are zeroed when the bucket leaves."""
         self._late = []
+        self._prev_unused = set(self._unused)             # snapshot: the hooks discard entries from _unused during backward
         if self._tl is not None:
             self._tl = [("start", -1, 0, self._event())]
         for b in self.buckets:
@@ -185,7 +193,10 @@ class GradSync:
             b.work = False
 
     def _launch_ready(self):
-        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+        # static regime: the last bucket leaves from finish(), after this rank's deviation flag has been written behind its
+        # gradients (it is the declared-late bucket -- its gradients land with the end of backward anyway)
+        limit = len(self.buckets) - (1 if (self._agree and self.static_graph and self._static_ok) else 0)
+        while self._next < limit and self.buckets[self._next].pending == 0:
             self._launch(self.buckets[self._next])
             self._next += 1
 
@@ -207,6 +218,41 @@ class GradSync:
             if not self._avg:
                 b.flat.div_(self.world)
 
+    def exchange_only(self):
+        """All buckets all-reduced back to back in index order, nothing else -- what the exchange costs on its own, with no
+        backward to hide under and no compute competing for HBM, CUs or watts (bench.py's ``ms_allreduce_only``).  The bucket
+        contents are whatever the last step left there: a diagnostic, not part of a training step."""
+        if not self._collective:
+            return
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        works = [dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True) for b in self.buckets]
+        for w in works:
+            w.wait()
+
+    def _check_static_flag(self):
+        """Look at the deviation flag the previous static step all-reduced (see finish()).  Non-zero on every rank alike: leave
+        the static regime (the agreeing protocol takes over from this step on and re-learns the pattern) -- or raise if
+        ``strict``."""
+        if self._flag_pending is None:
+            return
+        host, ev = self._flag_pending
+        self._flag_pending = None
+        if ev is not None:
+            ev.synchronize()
+        if float(host[0]) == 0.0:
+            return
+        self.stats["static_deviations"] += 1
+        self._static_ok = False
+        mine = self._deviation
+        self._deviation = None
+        msg = ("GradSync(static_graph=True): some rank's previous step deviated from the learned gradient pattern (this rank: %s); "
+               "its late gradients of that one step were not exchanged"
+               % ("%d late parameter(s), %d presence change(s)" % mine if mine else "no deviation"))
+        if self.strict:
+            raise RuntimeError(msg + " -- the graph is not static: construct GradSync with static_graph=False")
+        import warnings
+        warnings.warn(msg + "; back on the per-step agreement until the pattern is stable again")
+
     def finish(self):
         """Call after backward: exchange the buckets backward could not complete (in index order), agree with the other
         ranks on late parameters and on the parameters nobody produced a gradient for, wait for every collective, turn
@@ -215,27 +261,37 @@ class GradSync:
             self._tl.append(("end", -1, 0, self._event()))
             self._tl_steps.append(self._tl)
             self._tl_steps = self._tl_steps[-8:]
-        while self._next < len(self.buckets):
-            self._launch(self.buckets[self._next], "finish")
-            self._next += 1
         npar = len(self._params)
         mine = set(self._late)
         late = [p in mine for p in self._params]
         nograd = [p.grad is None for p in self._params]
         agree = self._agree
+        static_step = False
         if agree and self.static_graph and self._static_ok:
-            # static graph, pattern learned: no host rendezvous.  This rank's step must match the pattern every rank agreed on
-            # (then the collective sequence below is the same everywhere: no late exchange, the same buckets).
+            # The flag the PREVIOUS static step all-reduced (its copy landed in pinned memory a step ago: waiting for that event
+            # costs nothing while the host runs less than a step ahead of the GPU).  Every rank reads the same reduced value, so
+            # every rank leaves the static regime -- or raises, under ``strict`` -- on the same step, BEFORE this step's remaining
+            # collectives are issued: nobody is left blocking in RCCL on a peer that raised alone.
+            self._check_static_flag()
+        if agree and self.static_graph and self._static_ok:
+            # static graph, pattern learned: no host rendezvous.  This rank's step should match the pattern every rank agreed on;
+            # whether it does is written behind the last bucket's gradients and all-reduced WITH them.  A deviating rank still
+            # issues exactly the static sequence of collectives (all buckets in index order, no late exchange), so no rank can
+            # hang; its late gradients of this one step are dropped, and the next step is back on the agreeing protocol.
             if self.recheck_every > 0 and (self.stats["steps"] + 1) % self.recheck_every == 0:
                 pass                                      # debug: run the collective agreement on this step anyway
             else:
                 mism = sum(1 for i, n in enumerate(nograd) if n != (i in self._static_nograd))
+                self._flag.fill_(1.0 if (mine or mism) else 0.0)
                 if mine or mism:
-                    raise RuntimeError("GradSync(static_graph=True): this step deviates from the learned gradient pattern (%d late "
-                                       "parameter(s), %d presence change(s)); the graph is not static -- construct GradSync with "
-                                       "static_graph=False" % (len(mine), mism))
+                    self._deviation = (len(mine), mism)
+                    late = [False] * npar
                 agree = False
-        prev_unused = self._unused
+                static_step = True
+        while self._next < len(self.buckets):
+            self._launch(self.buckets[self._next], "finish")
+            self._next += 1
+        prev_unused = self._prev_unused
         if agree:
             self.stats["agreement_exchanges"] += 1
             # one small host-side exchange, per parameter: "late" on ANY rank, "has a gradient" on ANY rank, "has none" on ANY
@@ -262,6 +318,23 @@ class GradSync:
                 self._static_ok, self._static_nograd = stable, now
         for b in self.buckets:
             self._wait(b)
+        if static_step:
+            # every rank leaves the step with the LEARNED presence pattern, whatever its own graph did: a gradient this rank
+            # alone produced (late, never exchanged) is dropped and a gradient it alone lacks is the bucket's average -- the
+            # optimizers of all ranks then apply the same update and the replicas stay identical
+            for b in self.buckets:
+                for p, v in zip(b.params, b.views):
+                    p.grad = None if self._pidx[p] in self._static_nograd else v
+        if static_step and self._collective:
+            # behind the last bucket's all-reduce on the current stream: the reduced flag (> 0 iff some rank deviated) goes to
+            # pinned memory asynchronously; it is looked at in the next step's finish()
+            host = torch.empty(1, dtype=torch.float32, pin_memory=self._flag.is_cuda)
+            host.copy_(self._flag[:1].float(), non_blocking=True)
+            ev = None
+            if self._flag.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+            self._flag_pending = (host, ev)
         if any(late):
             # Late gradients (a parameter thought unused produced one, on some rank, after its bucket had left with a zeroed
             # slot): ONE extra exchange of just those tensors -- own late gradient, or zero where it was not late here (then it
@@ -287,6 +360,8 @@ class GradSync:
                     if p.grad is None and not nograd[self._pidx[p]]:
                         p.grad = v
         # re-learned every step: a tensor that stops (or starts) receiving gradients costs one late exchange, once
+        if static_step:                                   # (static regime: the learned pattern stands; a deviation shows next step)
+            nograd = [i in self._static_nograd for i in range(npar)]
         self._unused = {p for p, n in zip(self._params, nograd) if n}
         self.stats["steps"] += 1
         self._armed = False

@@ -231,11 +231,15 @@ def shard_indices(n, rank=0, world=1):
     return list(range(rank, n, world))
 
 
-def infer_cam_list(model, items, out_cam=None, rank=0, world=1, batch_size=1, out_crf=None, low_alpha=1, high_alpha=12, **kw):
+def infer_cam_list(model, items, out_cam=None, rank=0, world=1, batch_size=8, out_crf=None, low_alpha=1, high_alpha=12, **kw):
     """Shard ``items`` -- an indexable of (name, img (1,3,h,w), label (1,C), (W,H)[, orig uint8 (W,H,3)]) -- over ranks and
     write ``<out_cam>/<name>.npy`` in the reference's wire format: a pickled {class: float32 (W,H)} dict
     (infer_cam.py:227-228, read back by evaluation.py:23-25).  Returns {name: cam_dict} of this rank.
-    ``batch_size`` > 1 groups consecutive images of this rank whose network inputs have the same size.
+    ``batch_size`` (default 8, round 6) groups consecutive images of this rank whose network inputs have the same size -- the
+    reference resizes every image to crop x crop first (myTool.py:1364-1403), so batches always form on its pipeline; results per
+    image are those of the one-image call (samples never interact: test_infer_cam_images_batch_matches_single_images).  A group
+    ends at a shape change; if a batch does not fit in memory the batch size is halved for the rest of the list (down to 1 =
+    the reference's ``chunker(img_list, 1)``, infer_cam.py:123).
     ``out_crf`` (infer_cam.py:68,218-225, defaults of --low_alpha / --high_alpha :72-73): also run the dense CRF on every
     cam_dict at both alphas, on the GPU (crf.crf_with_alpha), and write ``<out_crf>_<alpha>/<name>.npy``; needs the
     original image as the fifth item element."""
@@ -269,9 +273,22 @@ def infer_cam_list(model, items, out_cam=None, rank=0, world=1, batch_size=1, ou
         while len(grp) < batch_size and pos + len(grp) < len(mine) and items[mine[pos + len(grp)]][1].shape == shape:
             grp.append(mine[pos + len(grp)])
         pos += len(grp)
-        imgs = torch.cat([items[i][1] for i in grp], dim=0).to(dev)
-        labels = torch.cat([items[i][2] for i in grp], dim=0)
-        collect = launch_cam_images(model, imgs, labels, [items[i][3] for i in grp], **kw)
+        try:
+            imgs = torch.cat([items[i][1] for i in grp], dim=0).to(dev)
+            labels = torch.cat([items[i][2] for i in grp], dim=0)
+            collect = launch_cam_images(model, imgs, labels, [items[i][3] for i in grp], **kw)
+        except torch.cuda.OutOfMemoryError:
+            if len(grp) == 1:
+                raise
+            # memory bound: collect what is in flight (its buffers go back to the allocator), halve the batch, take this group again
+            imgs = labels = None
+            if pending is not None:
+                finish(*pending)
+                pending = None
+            torch.cuda.empty_cache()
+            batch_size = max(1, len(grp) // 2)
+            pos -= len(grp)
+            continue
         if pending is not None:
             finish(*pending)
         pending = (grp, collect)

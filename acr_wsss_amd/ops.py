@@ -138,12 +138,8 @@ class AttnCoreFn(Function):
         # pass over o -- split products with resident scores only, and not where the forward runs split-tail workgroups
         # (T = 1025, 2305, ...: they write fp32 o only)
         oimg = None
-        if want_oimg and scores is not None and math == 1 and not ((-(-T // 32)) % 4 == 1 and T > 32 * 32):
-            rows = B * T
-            oimg = x3_image_empty(rows, D, qkv.device)
-            if rows % 128:                                  # the image contract: rows past the matrix are zero (the weight gradient contracts over rows)
-                per_block = oimg.numel() // (-(-rows // 128))
-                oimg[-per_block:].zero_()
+        if want_oimg and scores is not None and math == 1 and lib.acr_attn_fwd_oimg_offered(d):
+            oimg = x3_image_empty(B * T, D, qkv.device)     # rows past B*T of the last 128-row block: zeroed by the kernel's epilogue
         if oimg is not None:
             L.check(lib.acr_attn_fwd_scores_oimg(d, qp, kp, vp, L.ptr(o), L.ptr(lse2), L.ptr(scores), L.ptr(pm), pm_sb, pm_st, L.ptr(oimg),
                                                  L.stream_ptr()), "acr_attn_fwd_scores_oimg")
@@ -599,6 +595,11 @@ def x3_image_many(specs, device):
     src[offset + r*sr + (k // kin)*sko + (k % kin)*ski] (include/acr_hip.h).  Returns the images, views of ONE buffer."""
     import numpy as np
     lib = L.load()
+    if torch.cuda.is_current_stream_capturing():
+        # the descriptor table below travels through a temporary pinned buffer: a captured copy node would re-read that (by then
+        # recycled) host memory on every replay and the images would silently be garbage (ADVICE r5).  Captures must HIT the
+        # caches the warm-up passes filled; a miss falls back to eager launches loudly (backbone.pass_graph / prefix_graph)
+        raise RuntimeError("acr_x3_image_many inside a hipGraph capture: its descriptor table is a one-shot host upload")
     sizes = [int(lib.acr_x3_image_floats(rows, K)) for (_, _, rows, K, _, _, _, _) in specs]
     buf = torch.empty(sum(sizes), dtype=torch.float32, device=device)
     rec = np.zeros(len(specs), dtype=[("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("K", "<i4"), ("sr", "<i4"), ("kin", "<i4"),
@@ -619,7 +620,8 @@ def x3_image_many(specs, device):
     table = host.to(device, non_blocking=True)
     nb = rec.nbytes
     L.check(lib.acr_x3_image_many(L.ptr(table), L.c_void_p(table.data_ptr() + nb), wg0, L.stream_ptr()), "acr_x3_image_many")
-    buf._acr_keep = table                                   # the launch reads the table asynchronously: keep it with the images
+    for im in imgs:                                         # the launch reads the table asynchronously: it lives as long as any image
+        im._acr_keep = table
     return imgs
 
 

@@ -142,11 +142,14 @@ int acr_attn_fwd_scores(const acr_attn_desc* desc, const void* q, const void* k,
 /* acr_attn_fwd_scores (desc->dtype = ACR_F32_BF16X3 only) whose output additionally leaves as the split-product image of the
  * (B*T) x (H*64) matrix o (o dense: o_sh = 64, o_st = H*64, o_sb = T*o_st) -- what acr_x3_image(o, H*64, B*T, H*64, o_image, ...) would
  * write, bit for bit, for every row < B*T: the operand of the Linear behind the attention (models/vision_transformer.py:211-212).
- * o_image: acr_x3_image_floats(B*T, H*64) floats; the caller zeroes the rows past B*T of the last 128-row block (the image contract)
- * when B*T is not a multiple of 128.  The leftover 32-row block of T = 1025, 2305, ... stays on an ordinary workgroup in this call. */
+ * o_image: acr_x3_image_floats(B*T, H*64) floats; the rows past B*T of the last 128-row block are written as zeros by the call
+ * (the image contract; round 6 -- the caller used to zero them).  The leftover 32-row block of T = 1025, 2305, ... stays on an
+ * ordinary workgroup in this call: acr_attn_fwd_oimg_offered(desc) = 1 where this entry point is the faster forward, 0 where
+ * acr_attn_fwd_scores (split-tail workgroups) + acr_x3_image(o) is. */
 int acr_attn_fwd_scores_oimg(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
                              void* o, float* lse2, float* scores, float* pmean, int64_t pmean_sb, int64_t pmean_st, float* o_image,
                              void* stream);
+int acr_attn_fwd_oimg_offered(const acr_attn_desc* desc);
 int acr_attn_bwd_scores(const acr_attn_desc* desc, const void* q, const void* k, const void* v,
                         const void* o, const void* d_o, const float* lse2, const float* scores,
                         const float* gmean, int64_t gmean_sb, int64_t gmean_st,

@@ -20,10 +20,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session", autouse=True)
 def _reproducible_library_convolutions():
     """The hand-written kernels sum nothing with atomics: a training step is bit-reproducible run to run (loss and every
-    gradient, fp32 and bf16; scripts/lab/determinism.py) -- EXCEPT for the stem's 3x3 / 7x7 convolutions, which stay on MIOpen,
-    whose default solver choice includes split-K kernels with atomic accumulation (igemm_*_gkgs), forward included.  On the
-    random recipe weights that last-bit scatter is amplified to ~0.5 % of the bf16 loss, enough to make loose comparisons flip.
-    The GPU tests therefore ask MIOpen for its deterministic solvers; the bench keeps the default (fastest) ones."""
+    gradient, in every mode; scripts/lab/determinism.py).  Under split products (`math="f32_split"`, the headline) no convolution
+    runs on a library at all.  In the exact-fp32 and bf16 modes the stem's 3x3 / 7x7 / strided convolutions are still MIOpen's, whose
+    default solver choice includes split-K kernels with atomic accumulation (igemm_*_gkgs), forward included; on the random recipe
+    weights that last-bit scatter is amplified to ~0.5 % of the bf16 loss, enough to make loose comparisons flip.  The GPU tests
+    therefore ask MIOpen for its deterministic solvers (a no-op for f32_split); the bench keeps the default (fastest) ones."""
     old = torch.backends.cudnn.deterministic
     torch.backends.cudnn.deterministic = True
     yield

@@ -81,6 +81,71 @@ def test_two_rank_train_step_matches_single_process():
     assert diff.max() <= 2e-3 * ref.abs().max() and diff.mean() <= 1e-5 * ref.abs().max(), (diff.max(), diff.mean())
 
 
+def _build_hybrid():
+    from acr_wsss_amd.DPT.ACR import ACR
+    torch.manual_seed(5)
+    m = ACR(num_classes=20, backbone_name="vitb_hybrid", use_pretrain=False, math="f32_split").to("cuda:0")
+    with torch.no_grad():
+        for blk in m.pretrained.model.blocks:
+            blk.attn.qkv.weight.mul_(4.0)
+    return m
+
+
+def _hybrid_worker(rank, world, port, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from acr_wsss_amd.dp import GradSync, broadcast_parameters
+    from acr_wsss_amd.train import PolyOptimizer, train_step
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _build_hybrid()
+    broadcast_parameters(model, 0)
+    # exactly what bench.py --gpus N builds: the declared-late stem parameters in the last bucket, static graph
+    sync = GradSync(model.parameters(), bucket_mb=64, late_params=model.late_gradient_parameters(), static_graph=True)
+    opt = PolyOptimizer(model.parameters(), lr=0.01, weight_decay=5e-4, max_step=10)
+    img, label = _batch()
+    sl = slice(rank * 2, rank * 2 + 2)
+    for _ in range(4):
+        train_step(model, opt, img[sl].cuda(), label[sl].cuda(), 125, grad_sync=sync)
+    torch.cuda.synchronize()
+    out[rank] = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])
+    if rank == 0:
+        late = set(id(p) for p in model.late_gradient_parameters())
+        out["info"] = dict(sync.describe(), log=list(sync.launch_log),
+                           late_last=[all(id(p) in late for p in b.params) for b in sync.buckets], static=sync._static_ok)
+    dist.destroy_process_group()
+
+
+def test_two_rank_hybrid_late_buckets_static_graph_matches_single_process():
+    """the configuration bench.py --gpus N runs -- the HYBRID model (ResNetV2 stem: weight-standardisation launches
+    whose backward decides when the stem's gradients exist), `late_params=model.late_gradient_parameters()` and
+    `static_graph=True` -- on two ranks (sharing cuda:0 over gloo), four steps: the first learns the gradient-less tensors, the
+    second confirms the pattern, the last two run in the static regime (no host rendezvous, the last bucket leaves from
+    finish() with the deviation flag).  Replicas bit-identical; parameters equal a single process stepping on the whole batch
+    (tolerance: a 2-sample shard and the 4-sample batch reduce in different orders, and sign() gradients amplify that)."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_hybrid_worker, args=(world, port, out), nprocs=world, join=True)
+    torch.testing.assert_close(out[0], out[1], rtol=0, atol=0)
+    info = out["info"]
+    nb = info["buckets"]
+    assert nb >= 3 and info["late_last"][-1] and not any(info["late_last"][:-1]) and info["static"], info
+    assert info["steps"] == 4 and info["agreement_exchanges"] == 2 and info["static_deviations"] == 0 and info["rank_disagreements"] == 0, info
+    assert info["late_reexchanges"] == 0 and [i for i, _ in info["log"]] == list(range(nb)), info
+    assert info["log"][-1] == (nb - 1, "finish") and all(w == "backward" for _, w in info["log"][:-1]), info["log"]
+    assert info["unused_parameters"] == 9                  # the reference's never-used tensors (bkg_token, norm.*, head.*, scratch.*)
+    from acr_wsss_amd.train import PolyOptimizer, train_step
+    model = _build_hybrid()
+    opt = PolyOptimizer(model.parameters(), lr=0.01, weight_decay=5e-4, max_step=10)
+    img, label = _batch()
+    for _ in range(4):
+        train_step(model, opt, img.cuda(), label.cuda(), 125)
+    ref = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])
+    diff = (out[0] - ref).abs()
+    print("hybrid DP vs single process: max %.3e mean %.3e of max %.3e" % (diff.max(), diff.mean(), ref.abs().max()))
+    assert diff.max() <= 2e-3 * ref.abs().max() and diff.mean() <= 1e-5 * ref.abs().max(), (diff.max(), diff.mean())
+
+
 def _rccl_worker(rank, world, port, out):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -166,9 +231,16 @@ def test_bench_two_ranks_gloo_rehearsal(tmp_path):
     assert sorted(d["sync"]) == ["bf16", "f32", "f32_split"]
     for m, sy in d["sync"].items():
         assert sy["buckets"] >= 1 and len(sy["bucket_mb"]) == sy["buckets"] and sy["rank_disagreements"] == 0, m
-        # step 0 learns the unused tensors (everything from finish()); from step 1 on every bucket goes out inside backward
-        assert sy["steps_counted"] == 4 and sy["bucket_launches_in_backward"] == 3 * sy["buckets"], m
-        assert sy["bucket_launches_in_finish"] == sy["buckets"] and sy["late_reexchanges"] == 0, m
+        # step 0 learns the unused tensors (everything from finish()); step 1 confirms the pattern with every bucket going out
+        # inside backward; steps 2 and 3 run in the static regime: no host rendezvous, and the LAST bucket (the declared-late
+        # gradients + this rank's deviation flag) leaves from finish()
+        assert sy["steps_counted"] == 4 and sy["bucket_launches_in_backward"] == 3 * sy["buckets"] - 2, m
+        assert sy["bucket_launches_in_finish"] == sy["buckets"] + 2 and sy["late_reexchanges"] == 0, m
+        assert sy["static_graph"] is True and sy["host_agreement_exchanges"] == 2 and sy["static_deviations"] == 0, m
+        # the diagnostics of an N > 1 run: the step with the exchange disarmed and the exchange on its own
+        assert sy["ms_step"] > 0 and sy["ms_compute_only"] > 0 and sy["ms_allreduce_only"] > 0 and sy["allreduce_mb"] > 300 * (0.5 if m == "bf16" else 1), (m, sy)
+        assert abs(sy["exposed_ms"] - (sy["ms_step"] - sy["ms_compute_only"])) < 1e-2 and sy["allreduce_busbw_gbs"] > 0, (m, sy)
+    assert rec["loss_step0_agree"] is True and 0 <= rec["loss_step0_max_rel"] <= 5e-5
     # a wrong WORLD_SIZE is still an error, not a silent single-rank run
     bad = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                          cwd=str(tmp_path))

@@ -279,8 +279,9 @@ def test_grad_sync_survives_rank_dependent_gradient_presence():
         assert (float(seg.abs().max()) == 0.0) == (not who)
 
 
-def _dp_static_worker(rank, world, port, out):
+def _dp_static_worker(rank, world, port, out, strict=False, who="all"):
     import time
+    import warnings
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     from acr_wsss_amd.dp import GradSync, broadcast_parameters
@@ -291,7 +292,7 @@ def _dp_static_worker(rank, world, port, out):
     unused = net[3].unused
     broadcast_parameters(net, 0)
     late = list(net[0].parameters())                     # "the stem": declared late, gets the last bucket(s) to itself
-    sync = GradSync(net.parameters(), bucket_mb=0.0003, late_params=late, static_graph=True, recheck_every=4)
+    sync = GradSync(net.parameters(), bucket_mb=0.0003, late_params=late, static_graph=True, recheck_every=4, strict=strict)
     g = torch.Generator().manual_seed(7)
     x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
     xs, ys = x[rank::world], y[rank::world]
@@ -307,17 +308,33 @@ def _dp_static_worker(rank, world, port, out):
         logs.append(list(sync.launch_log))
         opt.step()
     out[rank] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
-    # a step that breaks the learned pattern on EVERY rank (the unused tensor takes part): each rank raises on its own, before
-    # any collective it alone would have decided on
-    err = None
-    try:
-        loss = ((net(xs + unused.sum() * 1e-2) - ys) ** 2).mean()
-        sync.prepare()
-        loss.backward()
-        sync.finish()
-    except RuntimeError as e:
-        err = str(e)
+    # A step that breaks the learned pattern (the unused tensor takes part) -- on every rank, or on rank 0 ONLY: the deviating
+    # rank issues the static sequence of collectives anyway and its flag rides in the last bucket, so nobody hangs and nobody
+    # raises alone; on the NEXT step every rank reads the same reduced flag and they all leave the static regime together (a
+    # warning; an error under strict=True), re-learn the pattern through the agreeing protocol and stay bit-identical replicas.
+    err, warned = None, []
+    devs, statics = [], []
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        try:
+            for it in range(5):
+                opt.zero_grad(set_to_none=True)
+                deviate = it == 0 and (who == "all" or rank == 0)
+                loss = ((net(xs + (unused.sum() * 1e-2 if deviate else 0.0)) - ys) ** 2).mean()
+                sync.prepare()
+                loss.backward()
+                sync.finish()
+                devs.append(sync.stats["static_deviations"])
+                statics.append(sync.stats["agreement_exchanges"])
+                opt.step()
+        except RuntimeError as e:
+            err = str(e)
+        warned = [str(w.message) for w in caught if "static_graph" in str(w.message)]
     out["err%d" % rank] = err
+    out["warn%d" % rank] = warned
+    out["devs%d" % rank] = devs
+    out["statics%d" % rank] = statics
+    out["after%d" % rank] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
     if rank == 0:
         out["exchanges"] = exchanges
         out["logs"] = logs
@@ -335,6 +352,26 @@ def _dp_static_worker(rank, world, port, out):
         for _ in range(20):
             dist.all_reduce(flags, op=dist.ReduceOp.MAX)
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_grad_sync_static_graph_one_rank_deviates(strict):
+    """a step that deviates from the learned pattern on ONE rank only.  That rank used to raise alone after having
+    enqueued its all-reduces, leaving its peers blocked in RCCL until the watchdog.  Now its flag travels in the last bucket:
+    no rank hangs, all of them see it on the next step and warn (strict: raise) TOGETHER, and the replicas stay identical."""
+    world = 2
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_dp_static_worker, args=(world, port, out, strict, "rank0"), nprocs=world, join=True)
+    for r in range(world):
+        if strict:
+            assert out["err%d" % r] and "static_graph" in out["err%d" % r], out["err%d" % r]
+            assert out["devs%d" % r] == [0]
+        else:
+            assert out["err%d" % r] is None and len(out["warn%d" % r]) == 1
+            assert ("this rank: 1 late" in out["warn%d" % r][0]) == (r == 0) or ("presence change" in out["warn%d" % r][0]) == (r == 0), out["warn%d" % r]
+            assert out["devs%d" % r] == [0, 1, 1, 1, 1] and out["statics%d" % r] == [4, 5, 6, 6, 6], (out["devs%d" % r], out["statics%d" % r])
+            torch.testing.assert_close(out["after0"], out["after%d" % r], rtol=0, atol=0)
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -357,7 +394,14 @@ def test_grad_sync_static_graph_skips_the_host_rendezvous(world):
     assert k > 0 and all(late_last[k:]) and not any(late_last[:k])          # the declared-late parameters: last buckets, nothing else in them
     nb = len(late_last)
     assert all([i for i, _ in lg] == list(range(nb)) for lg in out["logs"])
-    assert all(out["err%d" % r] and "static_graph" in out["err%d" % r] for r in range(world))
+    # the deviating step (every rank deviated): nobody raised; one step later every rank saw the flag, warned and left the static
+    # regime; two agreeing steps later they are static again; replicas identical throughout
+    for r in range(world):
+        assert out["err%d" % r] is None and len(out["warn%d" % r]) == 1, (out["err%d" % r], out["warn%d" % r])
+        # host-side agreement exchanges: none on the deviating step (10), one to re-learn on step 11 (stable at once: static again),
+        # the every-4th-step re-check on step 12, none after
+        assert out["devs%d" % r] == [0, 1, 1, 1, 1] and out["statics%d" % r] == [4, 5, 6, 6, 6], (out["devs%d" % r], out["statics%d" % r])
+        torch.testing.assert_close(out["after0"], out["after%d" % r], rtol=0, atol=0)
     torch.manual_seed(100)
     net = _dp_net()
     g = torch.Generator().manual_seed(7)
