@@ -85,3 +85,33 @@ def test_no_cpu_path():
     from acr_wsss_amd._lib import AcrHipError
     with pytest.raises(AcrHipError):
         data.val_batch([np.zeros((8, 8, 3), np.uint8)], 16, device="cpu")
+
+
+GOLDEN_CHUNKS = ["train_a", "train_b", "train_c", "val_a", "val_b"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CHUNKS)
+def test_oracle_equals_the_reference_chunk_functions(name):
+    """fixtures written by the reference's OWN get_data_from_chunk_v2 / get_data_from_chunk_val (myTool.py:1158-1199,
+    :1364-1403, imported unmodified by tests/golden/make_data_golden.py with its real RandomResizeLong / flip / RandomCrop,
+    normalisation and chunk assembly; Python's random and np.random seeded).  The oracle, fed the same decoded RGB arrays and
+    generators seeded alike, must reproduce the reference's float32 batch EXACTLY: same draws in the same order, same target
+    shapes, same crop placement, same float64 arithmetic.  What this does not pin is the resize rule itself: the generator's
+    cv2.resize stand-in is the oracle's cv2_resize_linear (cv2 is not installed) -- the one unpinned step of this row."""
+    import os
+    from conftest import GOLDEN
+    fx = dict(np.load(os.path.join(GOLDEN, "data_chunk_%s.npz" % name)))
+    crop, seed = int(fx["crop"]), int(fx["seed"])
+    decoded = [fx["rgb_%d" % i] for i in range(fx["images"].shape[0])]
+    if name.startswith("train"):
+        got, geoms = DO.get_data_from_chunk_v2(decoded, crop, random.Random(seed), np.random.RandomState(seed))
+        assert any(g["flip"] for g in geoms) or len(geoms) == 1          # both flip branches occur in the multi-image chunks
+    else:
+        got = DO.get_data_from_chunk_val(decoded, crop, np.random.RandomState(seed))
+    assert got.dtype == np.float32 and got.shape == fx["images"].shape
+    np.testing.assert_array_equal(got, fx["images"])
+    # the reference's de-normalised uint8 copy (myTool.py:1186-1191) follows from the batch: the normalisation constants round-trip
+    ori = np.zeros_like(got, dtype=np.float32)
+    for c in range(3):
+        ori[:, c] = (got[:, c] * np.float32(DO.STD[c]) + np.float32(DO.MEAN[c])) * 255.0
+    assert np.abs(ori.astype(np.uint8).astype(np.int32) - fx["ori_images"].astype(np.int32)).max() <= 1

@@ -153,3 +153,24 @@ def test_chunk_loader_reads_files_like_the_reference(tmp_path):
     assert rate > 100                                        # sanity floor; the measured figure goes to DESIGN.md
     for l in (loader, a, b, t):
         l.close()
+
+
+@pytest.mark.parametrize("name", ["train_a", "train_b", "train_c", "val_a", "val_b"])
+def test_hip_batch_matches_the_reference_chunk_functions(name):
+    """The HIP input pipeline against fixtures written by the REFERENCE's own get_data_from_chunk_v2 / _val (myTool.py:1158-1199,
+    :1364-1403; tests/golden/make_data_golden.py -- real RandomResizeLong / flip / RandomCrop / normalisation / chunk assembly,
+    seeded generators; only cv2.resize is a stand-in, the one unpinned step): same decoded RGB arrays, the batcher seeded like
+    the reference run -> the reference's float32 batch within the pipeline's fp32 tolerance, zero bands exact."""
+    import os
+    from conftest import GOLDEN
+    fx = dict(np.load(os.path.join(GOLDEN, "data_chunk_%s.npz" % name)))
+    crop, seed = int(fx["crop"]), int(fx["seed"])
+    decoded = [fx["rgb_%d" % i] for i in range(fx["images"].shape[0])]
+    if name.startswith("train"):
+        x, _ = data.TrainBatcher(crop, device=DEV, seed=seed)(decoded, torch.from_numpy(fx["labels"]))
+    else:
+        x = data.val_batch(decoded, crop, device=DEV)
+    got = x.cpu().numpy()
+    assert got.shape == fx["images"].shape
+    assert np.array_equal(got == 0, fx["images"] == 0)
+    np.testing.assert_allclose(got, fx["images"], rtol=0, atol=2e-5)
