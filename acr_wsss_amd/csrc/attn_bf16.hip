@@ -31,23 +31,6 @@ struct AttnGeomB {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-#ifdef LAB_TLB                     // lab builds only (scripts/lab/attn_bf16_phases.py): per-phase cycle sums of every wave 0
-__device__ unsigned long long g_lab_attnb[8 * 16384];
-extern "C" int acr_lab_attnb_read(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_attnb), (size_t)n * 8);
-}
-#define LABB_T() __builtin_amdgcn_s_memtime()
-#define LABB_DECL unsigned long long lt_[6] = {0, 0, 0, 0, 0, 0}, lp_ = 0; (void)lp_
-#define LABB_MARK() (lp_ = LABB_T())
-#define LABB_ADD(i) do { const unsigned long long n_ = LABB_T(); lt_[i] += n_ - lp_; lp_ = n_; } while (0)
-#define LABB_OUT(kind, nsteps) do { if (threadIdx.x == 0 && blockIdx.x < 16384) { unsigned long long* d_ = g_lab_attnb + 8 * blockIdx.x; \
-        for (int i_ = 0; i_ < 6; ++i_) d_[i_] = lt_[i_]; d_[6] = (nsteps); d_[7] = (kind); } } while (0)
-#else
-#define LABB_DECL
-#define LABB_MARK()
-#define LABB_ADD(i)
-#define LABB_OUT(kind, nsteps)
-#endif
 
 // Compiler-level fence: global loads issued before it stay before it, LDS stores after it stay after it.  Without
 // it hipcc sinks every staging load next to its ds_write and drains vmcnt(0) per 16-byte chunk.
@@ -495,10 +478,8 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
     int cur = 0;
     // one step = 64 keys.  EDGE steps (the partial last tile, and the step that prefetches it) carry the clamps and
     // the key masks; all other steps are straight-line code without a single compare/select.
-    LABB_DECL;
     auto step = [&](int k0, auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
-        LABB_MARK();
         tile_gload<128, EDGE>(kr, k + base, g.st, k0 + 64, g.T, tid);
         tile_gload<128, EDGE>(vr, v + base, g.st, k0 + 64, g.T, tid);
         f32x4 gq[2][4];
@@ -512,7 +493,6 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
                 }
         }
         ACR_MEMBAR();
-        LABB_ADD(0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const bf16_t* ktc = kt[cur] + kb * 32 * BP;
@@ -520,7 +500,6 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
             f32x16 s = {0}, dp = {0};
             mma_rowop_bf(s, ktc, qreg, lane);               // S^T raw [key = krow][query = r]
             mma_rowop_bf(dp, vtc, doreg, lane);             // dP^T
-            LABB_ADD(1);
             // in place: s becomes dS and dp becomes P.  (Filling fresh f32x16 values element by element makes hipcc
             // initialise each 16-register tuple with 16 v_mov first: 64 of a step's ~250 VALU instructions.)
 #pragma unroll
@@ -541,27 +520,22 @@ __global__ __launch_bounds__(128, 2) void attn_dq_bf16_kernel(AttnGeomB g, const
                 }
                 s[reg] = p * (t - dl);
             }
-            LABB_ADD(2);
             mma_accop_a_bf(dq0, s, ktc, 0, lane);           // dQ[query = krow][d = 32*blk + r]
             mma_accop_a_bf(dq1, s, ktc, 1, lane);
             if (HAS_G) {
                 mma_accop_a_bf(y0, dp, ktc, 0, lane);       // Y[query = krow][d]
                 mma_accop_a_bf(y1, dp, ktc, 1, lane);
             }
-            LABB_ADD(3);
         }
         ACR_MEMBAR();
         tile_lstore<128>(kt[cur ^ 1], kr, k0 + 64, g.T, tid);
         tile_lstore<128>(vt[cur ^ 1], vr, k0 + 64, g.T, tid);
-        LABB_ADD(4);
         __syncthreads();
-        LABB_ADD(5);
         cur ^= 1;
     };
     int k0 = 0;
     for (; k0 + 128 <= g.T; k0 += 64) step(k0, std::false_type{});
     for (; k0 < g.T; k0 += 64) step(k0, std::true_type{});
-    LABB_OUT(1, (g.T + 63) >> 6);
     if (HAS_G) {
         rho += __shfl_xor(rho, 32);                         // both halves of a lane pair hold keys of the same query row
         rho *= invH;                                        // lane r (either half): rho_{q0+r} / H

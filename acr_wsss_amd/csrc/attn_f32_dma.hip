@@ -30,13 +30,6 @@
 #include "attn_f32.h"
 #include "attn_f32_tiles.h"
 
-#ifdef LAB_STAMP                   // lab builds only (scripts/lab): per-phase cycle sums of wave 0 of every forward workgroup
-__device__ unsigned long long g_lab_stamp[8 * 16384];
-extern "C" int acr_lab_read_stamps(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_stamp), (size_t)n * 8);
-}
-#define LAB_T() __builtin_amdgcn_s_memtime()
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // forward: one workgroup = (b, h, 128 queries); wave w owns queries q0 + 32w ..; K/V tiles of 32 keys stream through LDS
@@ -68,20 +61,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(AttnGeom g, const 
     int doff[2];
     dma_offsets32(doff, g.st, wave, lane);
     const char* sm = reinterpret_cast<const char*>(smem);
-#ifdef LAB_STAMP
-    unsigned long long st_bar = 0, st_dma = 0, st_s = 0, st_sm = 0, st_pv = 0, st_n = 0;
-#endif
     // one 32-key step on ring slot SLOT (compile time: every LDS address below is lane base + immediate)
     auto step = [&](int k0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int KOFF = SLOT * 2 * DT_FLOATS * 4, VOFF = KOFF + DT_FLOATS * 4;
-#ifdef LAB_STAMP
-        const unsigned long long tb = LAB_T();
-#endif
         acr_dma_barrier();                                 // slot SLOT has landed; the other slot is free
-#ifdef LAB_STAMP
-        const unsigned long long t0 = LAB_T();
-#endif
         // The co-resident wave of the other workgroup streams 64-cycle fp32 MFMAs through this SIMD; at equal priority this
         // wave's DMA issue and softmax VALU get one issue slot per MFMA gap (measured with s_memtime stamps: 4 DMA
         // instructions 1 280 cycles, ~100 VALU instructions 2 750 cycles).  VALU cannot overlap the fp32 MFMA anyway, so the
@@ -97,14 +81,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(AttnGeom g, const 
         __builtin_amdgcn_s_setprio(0);
         if (!live) return;
         f32x16 s = {0};
-#ifdef LAB_STAMP
-        const unsigned long long t1 = LAB_T();
-#endif
         rowop_i<KOFF>(s, sm, lb, qreg);                    // s[reg] = S2[key = k0 + krow][query = q0 + r]
-#ifdef LAB_STAMP
-        asm volatile("" :: "v"(s[15]));
-        const unsigned long long t2 = LAB_T();
-#endif
         __builtin_amdgcn_s_setprio(2);
         if (k0 + 32 > g.T) {                               // only the last key tile has keys beyond T (uniform branch)
 #pragma unroll
@@ -132,31 +109,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(AttnGeom g, const 
         rs += __shfl_xor(rs, 32);
         l += rs;
         __builtin_amdgcn_s_setprio(0);
-#ifdef LAB_STAMP
-        asm volatile("" :: "v"(p[15]), "v"(l));
-        const unsigned long long t3 = LAB_T();
-#endif
         accop_b_i<VOFF, 0>(o0, p, sm, lb);                 // o[reg] = O^T[d = 32*blk + krow][query = r]
         accop_b_i<VOFF, 1>(o1, p, sm, lb);
-#ifdef LAB_STAMP
-        asm volatile("" :: "v"(o0[15]), "v"(o1[15]));
-        const unsigned long long t4 = LAB_T();
-        st_bar += t0 - tb; st_dma += t1 - t0; st_s += t2 - t1; st_sm += t3 - t2; st_pv += t4 - t3; st_n += 1;
-#endif
     };
-#ifdef LAB_STAMP
-    const unsigned long long tk0 = LAB_T();
-#endif
     for (int k0 = 0; k0 < g.T; k0 += 64) {
         step(k0, std::integral_constant<int, 0>{});
         if (k0 + 32 < g.T) step(k0 + 32, std::integral_constant<int, 1>{});
     }
-#ifdef LAB_STAMP
-    if (tid == 0 && blockIdx.x < 16384) {
-        unsigned long long* d = g_lab_stamp + 8 * blockIdx.x;
-        d[0] = st_bar; d[1] = st_dma; d[2] = st_s; d[3] = st_sm; d[4] = st_pv; d[5] = st_n; d[6] = LAB_T() - tk0; d[7] = live;
-    }
-#endif
     if (live && q0 + r < g.T) {
         const float inv = 1.f / l;
         float* ob = o + (int64_t)b * g.osb + (int64_t)(q0 + r) * g.ost + (int64_t)hd * g.osh;

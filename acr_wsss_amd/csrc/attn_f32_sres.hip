@@ -28,23 +28,6 @@
 #include "attn_f32_tiles.h"
 #include "attn_f32_sres_tails.h"
 
-#ifdef LAB_TL                      // lab builds only (scripts/lab/attn_bwd_phases.py): per-phase cycle sums of every wave 0
-__device__ unsigned long long g_lab_attn[8 * 16384];
-extern "C" int acr_lab_attn_read(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_attn), (size_t)n * 8);
-}
-#define LAB_T() __builtin_amdgcn_s_memtime()
-#define LAB_DECL unsigned long long lt_[6] = {0, 0, 0, 0, 0, 0}, lp_ = 0; (void)lp_
-#define LAB_MARK() (lp_ = LAB_T())
-#define LAB_ADD(i) do { const unsigned long long n_ = LAB_T(); lt_[i] += n_ - lp_; lp_ = n_; } while (0)
-#define LAB_OUT(kind, nsteps) do { if (threadIdx.x == 0 && blockIdx.x < 16384) { unsigned long long* d_ = g_lab_attn + 8 * blockIdx.x; \
-        for (int i_ = 0; i_ < 6; ++i_) d_[i_] = lt_[i_]; d_[6] = (nsteps); d_[7] = (kind); } } while (0)
-#else
-#define LAB_DECL
-#define LAB_MARK()
-#define LAB_ADD(i)
-#define LAB_OUT(kind, nsteps)
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // forward: workgroup = (b, h, 128 queries), wave = 32 queries; K/V tiles of 32 keys stream through the two-slot LDS ring
@@ -464,16 +447,13 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, float* ssm, float
     uint32_t gaddr[4];                                                                  // quad gq = keys 8 gq + 4 h .. + 3 of row r
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) gaddr[gq] = lds_addr_of(gw) + r * 128 + (((2 * gq + h) ^ ((r >> 1) & 7)) << 4);
-    LAB_DECL;
     auto step = [&](int k0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int KOFF = SLOT * 2 * DT_FLOATS * 4, VOFF = KOFF + DT_FLOATS * 4;
-        LAB_MARK();
         // issue order of a live wave's step:  tile(t+1) [4] | G(t+1) [4]  scores(t+2) [4].  At this barrier tile(t) must have
         // landed; behind it the previous step issued G(t) and scores(t+1).
         sres_wait_vm((k0 > 0 && live) ? (gb0 ? 4 : 0) + (k0 + 32 < g.T ? 4 : 0) : 0);
         acr_barrier_nofence();                             // not __syncthreads(): its release fence drains every DMA (acr_common.h)
-        LAB_ADD(0);
         if (k0 + 64 <= g.T) {
             dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, kb + (int64_t)(k0 + 32) * g.st, doff, wave);
             dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, vb + (int64_t)(k0 + 32) * g.st, doff, wave);
@@ -483,13 +463,8 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, float* ssm, float
         }
         SRES_FENCE();
         if (!live) return;
-        LAB_ADD(1);
         f32x16 dp = {0};
         rowop_x<VOFF>(dp, lb, doreg);                      // dP^T[key = krow][query = r]
-#ifdef LAB_TL
-        asm volatile("" :: "v"(dp[15]));
-#endif
-        LAB_ADD(2);
         // G(t) must have landed in this wave's tile: behind it are scores(t+1) [4] and this step's tile(t+1) [4]
         if (k0 > 0) sres_wait_vm(k0 + 32 < g.T ? 8 : 0);
         f32x4 s4[4], g4[4];
@@ -521,19 +496,13 @@ __device__ __forceinline__ void attn_dq_sres_body(float* smem, float* ssm, float
         if (k0 + 32 < g.T) dma_g(k0 + 32);
         if (k0 + 64 < g.T) dma_scores((k0 >> 5) + 2, SLOT);
         SRES_FENCE();
-        LAB_ADD(3);
         accop_x<KOFF, 0, true>(dq0, ds, lb);               // dQ[query = krow][d = 32*blk + r]
         accop_x<KOFF, 1, true>(dq1, ds, lb);
-#ifdef LAB_TL
-        asm volatile("" :: "v"(dq0[15]), "v"(dq1[15]));
-#endif
-        LAB_ADD(4);
     };
     for (int k0 = 0; k0 < g.T; k0 += 64) {
         step(k0, std::integral_constant<int, 0>{});
         if (k0 + 32 < g.T) step(k0 + 32, std::integral_constant<int, 1>{});
     }
-    LAB_OUT(1, (g.T + 31) >> 5);
     if (!live) return;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -626,16 +595,13 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
             tb[j] = lds_addr_of(ssm) + ((wave * 2 * SB_FLOATS) + gk * 256 + 128 * hk + ek + 4 * ((j + 4 * h) ^ mm)) * 4;
     }
     const uint32_t gaddr = lds_addr_of(gsm) + (wave * SB_FLOATS + 4 * h * 32 + r) * 4;      // + 128 * c_reg per register
-    LAB_DECL;
     auto step = [&](int q0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int QOFF = SLOT * 2 * DT_FLOATS * 4, DOOFF = QOFF + DT_FLOATS * 4;
-        LAB_MARK();
         // issue order of a live wave's step:  tile(t+1) [4]  lse2 / delta(t) [2 plain loads, consumed in this step] | G(t+1) [4]
         // scores(t+2) [4].  At this barrier tile(t) must have landed; behind it the previous step issued G(t) and scores(t+1).
         sres_wait_vm((q0 > 0 && live) ? (gb0 ? 4 : 0) + (q0 + 32 < g.T ? 4 : 0) : 0);
         acr_barrier_nofence();
-        LAB_ADD(0);
         if (q0 + 64 <= g.T) {
             dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS, qb + (int64_t)(q0 + 32) * g.st, qoff, wave);
             dma_tile32_i(smem + (SLOT ^ 1) * 2 * DT_FLOATS + DT_FLOATS, dob + (int64_t)(q0 + 32) * g.ost, dooff, wave);
@@ -647,13 +613,8 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         if (!live) return;
         const int qi = min(q0 + r, g.T - 1);
         const float lq_lane = lrow[qi], dq_lane = drow[qi];         // this step's lse2 / delta, one query per lane
-        LAB_ADD(1);
         f32x16 dp = {0};
         rowop_x<DOOFF>(dp, lb, vreg);                      // dP[query = krow][key = r]
-#ifdef LAB_TL
-        asm volatile("" :: "v"(dp[15]));
-#endif
-        LAB_ADD(2);
         // G(t) must have landed in this wave's tile: behind it are scores(t+1) [4], this step's tile(t+1) [4] (and the two plain
         // loads above, if they are still in flight: 8 is the stricter count)
         if (q0 > 0) sres_wait_vm(q0 + 32 < g.T ? 8 : 0);
@@ -696,21 +657,15 @@ __device__ __forceinline__ void attn_dkdv_sres_body(float* smem, float* ssm, flo
         if (q0 + 32 < g.T) dma_g(q0 + 32);
         if (q0 + 64 < g.T) dma_scores((q0 >> 5) + 2, SLOT);
         SRES_FENCE();
-        LAB_ADD(3);
         accop_x<DOOFF, 0, true>(dv0, p, lb);               // dV[key = krow][d = 32*blk + r]
         accop_x<DOOFF, 1, true>(dv1, p, lb);
         accop_x<QOFF, 0, true>(dk0, ds, lb);
         accop_x<QOFF, 1, true>(dk1, ds, lb);
-#ifdef LAB_TL
-        asm volatile("" :: "v"(dv0[15]), "v"(dv1[15]), "v"(dk0[15]), "v"(dk1[15]));
-#endif
-        LAB_ADD(4);
     };
     for (int q0 = 0; q0 < g.T; q0 += 64) {
         step(q0, std::integral_constant<int, 0>{});
         if (q0 + 32 < g.T) step(q0 + 32, std::integral_constant<int, 1>{});
     }
-    LAB_OUT(2, (g.T + 31) >> 5);
     if (!live) return;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {

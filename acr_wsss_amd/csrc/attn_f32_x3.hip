@@ -40,25 +40,6 @@ typedef const __attribute__((address_space(1))) void* x3_glb_vp;
 #define X3_STORE_NT(p, v) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p))
 #define X3_LOAD_NT(p) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p))
 
-#ifdef LAB_TL                      // lab builds only (scripts/lab/attn_x3_phases.py): per-phase cycle sums of every wave 0
-__device__ unsigned long long g_lab_x3[8 * 16384];
-extern "C" int acr_lab_x3_read(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_x3), (size_t)n * 8);
-}
-#define X3L_T() __builtin_amdgcn_s_memtime()
-#define X3L_DECL unsigned long long lt_[6] = {0, 0, 0, 0, 0, 0}, lp_ = 0; (void)lp_
-#define X3L_MARK() (lp_ = X3L_T())
-#define X3L_ADD(i) do { const unsigned long long n_ = X3L_T(); lt_[i] += n_ - lp_; lp_ = n_; } while (0)
-#define X3L_OUT(kind, nsteps) do { if (threadIdx.x == 0 && blockIdx.x < 16384) { unsigned long long* d_ = g_lab_x3 + 8 * blockIdx.x; \
-        for (int i_ = 0; i_ < 6; ++i_) d_[i_] = lt_[i_]; d_[6] = (nsteps); d_[7] = (kind); } } while (0)
-#define X3L_USE(v) asm volatile("" :: "v"(v))
-#else
-#define X3L_DECL
-#define X3L_MARK()
-#define X3L_ADD(i)
-#define X3L_OUT(kind, nsteps)
-#define X3L_USE(v)
-#endif
 
 // ---- counted waits ------------------------------------------------------------------------------------------------------------
 // A step's tile DMA must have landed at the step's barrier, but the streams that run further ahead (score blocks two steps
@@ -79,16 +60,12 @@ __device__ __forceinline__ void x3_wait_vm(int n) {
 // compiler-only fence: vector-memory operations written after it are issued after the ones before it (the counts above rely
 // on the issue order; loads from global memory and LDS-DMA writes do not alias, so nothing else orders them for the compiler)
 #define X3_FENCE() asm volatile("" ::: "memory")
-#ifdef LAB_TL
-#define x3_barrier(n_younger) do { x3_wait_vm(n_younger); X3L_ADD(5); __syncthreads(); } while (0)      /* lab: the wait on its own */
-#else
 // acr_barrier_nofence (acr_common.h): __syncthreads()'s release fence made hipcc drain every outstanding DMA in front of the
 // barrier of every second step (`s_waitcnt vmcnt(0)`, found in the ISA) -- the counted wait above it is the synchronisation
 __device__ __forceinline__ void x3_barrier(int n_younger) {
     x3_wait_vm(n_younger);
     acr_barrier_nofence();
 }
-#endif
 
 struct X3Geom {
     int B, H, T, D;                        // D = H * 64: row pitch (elements) of every plane
@@ -389,13 +366,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
     const int doff = x3_dma_off(g.D, wave, lane);
     const float c2 = g.scale * ACR_LOG2E;
     float* sblk = sres + x3_block(g.H, NB, b, hd, min(q0 >> 5, NB - 1), 0) + lane * 4;
-    X3L_DECL;
     auto step = [&](int k0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int KOFF = SLOT * X3_SLOT_B, VOFF = KOFF + X3_TILE_B;
-        X3L_MARK();
         x3_barrier((k0 > 0 && live) ? 4 : 0);              // slot SLOT has landed (the previous step's 4 score stores may be in flight); the other slot is free
-        X3L_ADD(0);
         // the next tile's DMA (K planes, then V planes) is issued between the MFMA groups of this tile's first product
         auto dma_next = [&](const bf16_t* base, int toff) {
             if (k0 + 64 <= g.T) x3_dma_tile_i(smem + (SLOT ^ 1) * X3_SLOT_B + toff, base + (int64_t)(k0 + 32) * g.D, g.plane, doff, wave);
@@ -407,11 +381,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
             dma_next(vb, X3_TILE_B);
             return;
         }
-        X3L_ADD(1);
         f32x16 s = {0};
         x3_rowop<KOFF>(s, lb, qf, [&] { dma_next(kb, 0); }, [&] { dma_next(vb, X3_TILE_B); });      // s[reg] = q.k of key k0 + krow, query q0 + r
-        X3L_USE(s[15]);
-        X3L_ADD(2);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) s[reg] *= c2;   // scaled base-2 logits
         if (k0 + 32 > g.T) {                               // only the last key tile has keys beyond T (uniform branch)
@@ -444,17 +415,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(X3Geom g, const bf1
         l += rs;
         bf16x8 p0[3], p1[3];
         x3_split_acc<0>(p, p0);
-        X3L_USE(p0[2][7]);
-        X3L_ADD(3);
         x3_accop<VOFF, false>(o0, o1, p0, p1, lb, [&] { x3_split_acc<1>(p, p1); });      // o[reg] = O^T[d = 32*blk + krow][query = r]
-        X3L_USE(o0[15]); X3L_USE(o1[15]);
-        X3L_ADD(4);
     };
     for (int k0 = 0; k0 < g.T; k0 += 64) {
         step(k0, std::integral_constant<int, 0>{});
         if (k0 + 32 < g.T) step(k0 + 32, std::integral_constant<int, 1>{});
     }
-    X3L_OUT(3, (g.T + 31) >> 5);
     if (live && q0 + r < g.T) {
         const float inv = 1.f / l;
         float* ob = o + (int64_t)b * g.osb + (int64_t)(q0 + r) * g.ost + (int64_t)hd * g.osh;
@@ -602,26 +568,20 @@ __device__ __forceinline__ void attn_dq_x3_body(char* smem, float* ssm, float* g
     uint32_t gaddr[4];                                                                  // quad gq = keys 8 gq + 4 h .. + 3 of row r
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) gaddr[gq] = x3_lds_addr(gw) + r * 128 + (((2 * gq + h) ^ ((r >> 1) & 7)) << 4);
-    X3L_DECL;
     auto step = [&](int k0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int KOFF = SLOT * X3_SLOT_B, VOFF = KOFF + X3_TILE_B;
-        X3L_MARK();
         // Issue order of a live wave's step (younger to the right):  tile(t+1) [3] | G(t+1) [4]  scores(t+2) [4], all LDS-DMA.
         // At this barrier tile(t) must have landed; behind it the previous step issued G(t) and scores(t+1).
         x3_barrier((k0 > 0 && live) ? (gb0 ? 4 : 0) + (k0 + 32 < g.T ? 4 : 0) : 0);
-        X3L_ADD(0);
         auto dma_next = [&] {                              // this wave's three pieces of tile(t+1)
             if (k0 + 64 <= g.T) x3_dma_tile_i(tdst + (SLOT ^ 1) * X3_SLOT_B, tb + (int64_t)(k0 + 32) * g.D, g.plane, doff, pc);
             else if (k0 + 32 < g.T) x3_dma_tile(tdst + (SLOT ^ 1) * X3_SLOT_B, tb, g.plane, g.D, k0 + 32, g.T, pc, lane);
             X3_FENCE();
         };
         if (!live) { dma_next(); return; }
-        X3L_ADD(1);
         f32x16 dp = {0};
         x3_rowop<VOFF>(dp, lb, dof, dma_next);             // dP^T[key = krow][query = r]; tile(t+1) issued after the first MFMA group
-        X3L_USE(dp[15]);
-        X3L_ADD(2);
         // G(t) (issued in the previous step) must have landed in this wave's tile: behind it are scores(t+1) [4] and this step's
         // tile(t+1) [3].  The score block (t) is older than it.
         if (k0 > 0) x3_wait_vm(k0 + 32 < g.T ? 7 : 0);
@@ -651,20 +611,15 @@ __device__ __forceinline__ void attn_dq_x3_body(char* smem, float* ssm, float* g
         // the MFMA groups of the second product, like the second half of the split
         bf16x8 z0[3], z1[3];
         x3_split_acc<0>(ds, z0);
-        X3L_USE(z0[2][7]);
-        X3L_ADD(3);
         x3_accop<KOFF, true>(dq0, dq1, z0, z1, lb,          // dQ[query = krow][d = 32*blk + r]
                              [&] { x3_split_acc<1>(ds, z1); },
                              [&] { if (k0 + 32 < g.T) dma_g(k0 + 32); X3_FENCE(); },
                              [&] { if (k0 + 64 < g.T) dma_scores((k0 >> 5) + 2, SLOT); X3_FENCE(); });
-        X3L_USE(dq0[15]); X3L_USE(dq1[15]);
-        X3L_ADD(4);
     };
     for (int k0 = 0; k0 < g.T; k0 += 64) {
         step(k0, std::integral_constant<int, 0>{});
         if (k0 + 32 < g.T) step(k0 + 32, std::integral_constant<int, 1>{});
     }
-    X3L_OUT(1, (g.T + 31) >> 5);
     if (!live) return;
     const int64_t base = (int64_t)b * g.sb + (int64_t)hd * g.sh;
 #pragma unroll
@@ -762,27 +717,21 @@ __device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, float*
     }
     const uint32_t gaddr = x3_lds_addr(gsm) + (wave * X3_SB_FLOATS + 4 * h * 32 + r) * 4;      // + 128 * c_reg per register
     const uint32_t rcaddr = x3_lds_addr(rcw) + 16 * h;                                          // l4[gq] at + 32 gq, d4[gq] at + 128 + 32 gq
-    X3L_DECL;
     auto step = [&](int q0, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int QOFF = SLOT * X3_SLOT_B, DOOFF = QOFF + X3_TILE_B;
-        X3L_MARK();
         // Issue order of a live wave's step (younger to the right):  tile(t+1) [3] | lse2-delta(t+1) [1]  G(t+1) [4]  scores(t+2) [4],
         // all of them LDS-DMA.  At this barrier tile(t) must have landed; behind it the previous step issued lse2-delta(t), G(t)
         // and scores(t+1).
         x3_barrier((q0 > 0 && live) ? 1 + (gb0 ? 4 : 0) + (q0 + 32 < g.T ? 4 : 0) : 0);
-        X3L_ADD(0);
         auto dma_next = [&] {                              // this wave's three pieces of tile(t+1)
             if (q0 + 64 <= g.T) x3_dma_tile_i(tdst + (SLOT ^ 1) * X3_SLOT_B, tb + (int64_t)(q0 + 32) * g.D, g.plane, doff, pc);
             else if (q0 + 32 < g.T) x3_dma_tile(tdst + (SLOT ^ 1) * X3_SLOT_B, tb, g.plane, g.D, q0 + 32, g.T, pc, lane);
             X3_FENCE();
         };
         if (!live) { dma_next(); return; }
-        X3L_ADD(1);
         f32x16 dp = {0};
         x3_rowop<DOOFF>(dp, lb, vf, dma_next);             // dP[query = krow][key = r]; tile(t+1) issued after the first MFMA group
-        X3L_USE(dp[15]);
-        X3L_ADD(2);
         // lse2-delta(t) and G(t) (issued in the previous step) must have landed in this wave's private tiles: behind them are
         // scores(t+1) [4] and this step's tile(t+1) [3].  The score block (t) is older than both: it has landed with them.
         if (q0 > 0) x3_wait_vm(q0 + 32 < g.T ? 7 : 0);
@@ -825,13 +774,11 @@ __device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, float*
                 ds[reg] = pv * (dp[reg] + gv[reg] * invH - d4[gq][e]);
             }
         }
-        X3L_USE(p[15]); X3L_USE(ds[15]);
         // the private tiles have been read (their values are in p / ds): they are refilled between the MFMA groups below, like
         // the splits of P's second half and of dS; the DMAs land under the rest of the step and the next step's counted waits
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every read of the private tiles has returned
         bf16x8 z0[3], z1[3];
         x3_split_acc<0>(p, z0);
-        X3L_ADD(3);
         x3_accop<DOOFF, true>(dv0, dv1, z0, z1, lb,
                               [&] { x3_split_acc<1>(p, z1); },
                               [&] { if (q0 + 32 < g.T) dma_rc(q0 + 32); X3_FENCE(); },
@@ -840,14 +787,11 @@ __device__ __forceinline__ void attn_dkdv_x3_body(char* smem, float* ssm, float*
         x3_accop<QOFF, true>(dk0, dk1, z0, z1, lb,
                              [&] { x3_split_acc<1>(ds, z1); },
                              [&] { if (q0 + 64 < g.T) dma_scores((q0 >> 5) + 2, SLOT); X3_FENCE(); });
-        X3L_USE(dv0[15]); X3L_USE(dv1[15]); X3L_USE(dk0[15]); X3L_USE(dk1[15]);
-        X3L_ADD(4);
     };
     for (int q0 = 0; q0 < g.T; q0 += 64) {
         step(q0, std::integral_constant<int, 0>{});
         if (q0 + 32 < g.T) step(q0 + 32, std::integral_constant<int, 1>{});
     }
-    X3L_OUT(2, (g.T + 31) >> 5);
     if (!live) return;
     const int64_t base = (int64_t)b * g.sb + (int64_t)hd * g.sh;
 #pragma unroll

@@ -52,9 +52,6 @@ struct GemmF32Args {
     // batch (1x1 convolutions per sample): operands / outputs advance by *_zs per slice, k range the whole contraction
     int64_t a_zs, b_zs, c_zs, aux_zs;
     int k_zs, ksplit;                    // slice z = split / ksplit (operand / output offsets), contraction part split % ksplit
-#ifdef LAB_STAMP
-    unsigned long long* stamp;
-#endif
 };
 
 // Tile order of the NT / NN products: bands of 8 tile rows, column-major inside a band, so that the 64 workgroups an XCD
@@ -173,9 +170,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
     const float* __restrict__ pa = g.a + (int64_t)zs * g.a_zs;
     const float* __restrict__ pb = g.b + (int64_t)zs * g.b_zs;
 
-#ifdef LAB_STAMP
-    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
-#endif
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -246,12 +240,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args g) {
         if (k0 + F_BK < kend) step(ra1, rb1, ra0, rb0, k0 + F_BK, 1);
     }
 
-#ifdef LAB_STAMP
-    if (tid == 0 && g.stamp) {
-        g.stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0;
-        g.stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
-    }
-#endif
     // ---- epilogue: lane (r, h), register e of a 32x32 accumulator = row krow(e, h), column r
     if (ACT == 3) {
         float* slab = g.c + (int64_t)split * g.M * g.ldc;
@@ -341,15 +329,6 @@ __device__ __forceinline__ f32x4 dma_frag(const float* __restrict__ s, int base,
     return v;
 }
 
-#ifdef LAB_TL                      // lab builds only (scripts/lab/gemm_timeline.py): wall-clock timeline of every workgroup
-__device__ unsigned long long g_lab_tl[4 * 16384];
-extern "C" int acr_lab_tl_read(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_tl), (size_t)n * 8);
-}
-#define LAB_TL_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_lab_tl[4 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define LAB_TL_STAMP(i) do { } while (0)
-#endif
 
 // everything after the K loop of a DMA-ring kernel: tail slab (ACT 4), split slab + bias-gradient column sums (ACT 3) or the
 // epilogue.  `smem` must be free (all fragment reads behind a barrier).
@@ -396,16 +375,11 @@ __device__ __forceinline__ void gemm_f32_finish(const GemmF32Args& g, f32x16 (&a
         epilogue_f32<ACT, false>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
     else
         epilogue_f32<ACT, true>(gz, acc, m0 + wm * 64, n0 + wn * 64, r, h);
-#ifdef LAB_TL
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    LAB_TL_STAMP(3);
-#endif
 }
 
 template <bool A_KC, bool B_KC, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args g) {
     __shared__ __attribute__((aligned(1024))) float smem[4 * F_DTILE];      // [A0 | B0 | A1 | B1]
-    LAB_TL_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
@@ -420,9 +394,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
     const int kbeg = (split - zs * g.ksplit) * g.k_zs, kend = min(g.K, kbeg + g.kps);      // host: (kend - kbeg) % F_BK == 0
     const float* __restrict__ pa = g.a + (int64_t)zs * g.a_zs;
     const float* __restrict__ pb = g.b + (int64_t)zs * g.b_zs;
-#ifdef LAB_STAMP
-    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
-#endif
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -440,7 +411,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
     dma_chunk(smem, pa + kbeg * ka, offa, wave);
     dma_chunk(smem + F_DTILE, pb + kbeg * kb, offb, wave);
     acr_dma_barrier();
-    LAB_TL_STAMP(1);
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += F_BK, cur ^= 1) {
         if (k0 + F_BK < kend) {
@@ -471,13 +441,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmF32Args 
         }
         acr_dma_barrier();                                  // the chunk in flight has landed; buffer `cur` is free
     }
-    LAB_TL_STAMP(2);
-#ifdef LAB_STAMP
-    if (tid == 0 && g.stamp) {
-        g.stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0;
-        g.stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
-    }
-#endif
     gemm_f32_finish<A_KC, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, csum, want_cs);
 }
 
@@ -644,20 +607,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
     auto step = [&](int st, auto set_tag, auto first_tag) {
         constexpr int SET = decltype(set_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
-#ifdef SPLIT_SPREAD
-        if (nst >= S_SLOTS) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
         if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         acr_barrier_nofence();                              // stage st landed for every wave; all reads of stage st - 1 were waited for (SPLIT_LDS_WAIT8)
-#ifndef SPLIT_SPREAD
         if (st + S_SLOTS - 1 < nst) issue(st + S_SLOTS - 1);
-#else
-        if (FIRST && st + S_SLOTS - 1 < nst) issue(st + S_SLOTS - 1);
-#endif
         const uint32_t so = (uint32_t)(st & (S_SLOTS - 1)) * (2 * S_TILE * 4);
 #pragma unroll
         for (int i = 0; i < 2; ++i) split_frag8_x<A_KC>(fa[i], so, ra[i][0], ra[i][1]);
@@ -680,16 +634,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
         for (int j = 0; j < 2; ++j) split3_bf16(rb[j][0], rb[j][1], bp[SET][j][0], bp[SET][j][1], bp[SET][j][2]);
         if (!FIRST) {
             ACR_SPLIT_MFMA6(SET ^ 1, 0, 0) ACR_SPLIT_MFMA6(SET ^ 1, 0, 1) ACR_SPLIT_MFMA6(SET ^ 1, 1, 0) ACR_SPLIT_MFMA6(SET ^ 1, 1, 1)
-#ifdef SPLIT_SPREAD
-            issue(min(st + S_SLOTS - 1, nst - 1));          // unconditional (no branch inside the interleaved region): past the end it re-reads the last stage into a free slot
-#endif
 #pragma unroll
             for (int it = 0; it < 24; ++it) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA of stage st - 1
                 __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // eight VALU instructions of stage st's split
-#ifdef SPLIT_SPREAD
-                if (it % 6 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one of the refill's four LDS-DMA instructions
-#endif
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -702,9 +650,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const GemmF32Arg
     if (nst & 1) { ACR_SPLIT_MFMA6(0, 0, 0) ACR_SPLIT_MFMA6(0, 0, 1) ACR_SPLIT_MFMA6(0, 1, 0) ACR_SPLIT_MFMA6(0, 1, 1) }
     else { ACR_SPLIT_MFMA6(1, 0, 0) ACR_SPLIT_MFMA6(1, 0, 1) ACR_SPLIT_MFMA6(1, 1, 0) ACR_SPLIT_MFMA6(1, 1, 1) }
 #undef ACR_SPLIT_MFMA6
-#ifdef SPLIT_SPREAD
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end
-#endif
     __syncthreads();                                        // every wave is done with the ring: the finish may reuse it
     gemm_f32_finish<A_KC, ACT>(g, acc, smem, split, tt, tn, m0, n0, zs, wm, wn, r, h, tid, csum, want_cs);
 }
@@ -1840,9 +1785,6 @@ extern "C" int acr_gemm_x3(int32_t mode, int32_t act, const float* a_img, const 
     GemmF32Args g;
     g.a = a_img; g.lda = 0; g.b = b_img; g.ldb = 0; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.c = c; g.ldc = ldc; g.c2 = c2;
     g.cs = nullptr; g.M = M; g.N = N;
-#ifdef LAB_STAMP
-    g.stamp = g_lab_stamp;
-#endif
     g.K = (K + P_BK - 1) / P_BK * P_BK;                     // the images are zero past K
     g.tiles_m = (M + F_BM - 1) / F_BM; g.tiles_n = (N + F_BN - 1) / F_BN; g.nsplit = 1; g.kps = g.K;
     g.a_zs = g.b_zs = g.c_zs = g.aux_zs = 0; g.k_zs = g.kps; g.ksplit = 1 << 30;
@@ -1906,9 +1848,6 @@ extern "C" int acr_gemm_f32(int32_t mode, int32_t math, int32_t act, const float
     GemmF32Args g;
     g.a = a; g.lda = lda; g.b = b; g.ldb = ldb; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.c = c; g.ldc = ldc; g.c2 = c2;
     g.cs = nullptr; g.M = M; g.N = N; g.K = K;
-#ifdef LAB_STAMP
-    g.stamp = g_lab_stamp;
-#endif
     g.tiles_m = (M + F_BM - 1) / F_BM; g.tiles_n = (N + F_BN - 1) / F_BN; g.nsplit = 1; g.kps = (K + F_BK - 1) / F_BK * F_BK;
     g.a_zs = g.b_zs = g.c_zs = g.aux_zs = 0; g.k_zs = g.kps; g.ksplit = 1 << 30;
     g.tile0 = 0; g.tiles_launch = g.tiles_m * g.tiles_n;

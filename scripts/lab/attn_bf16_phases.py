@@ -1,5 +1,5 @@
 """GPU lab: per-phase cycles (s_memtime, wave 0 of every workgroup) of the bf16 attention dQ sweep.
-Needs scripts/lab/_build/libacr_tlb.so (build_variant.sh tlb attn_bf16.hip -DLAB_TLB)."""
+Needs scripts/lab/_build/libacr_tlb.so (build_variant.sh -H tlb attn_bf16.hip -DLAB_TLB: the hooked round-5 sources)."""
 import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,5 +1,5 @@
 """GPU lab: per-phase cycles (s_memtime, wave 0 of every workgroup) of the resident-score fp32 attention backward
-(attn_bwd_sres_kernel: dK/dV and dQ bodies).  Needs scripts/lab/_build/libacr_hip_tl.so (EXTRA=-DLAB_TL)."""
+(attn_bwd_sres_kernel: dK/dV and dQ bodies).  Needs scripts/lab/_build/libacr_hip_tl.so (scripts/lab/build_variant.sh -H srestl attn_f32_sres.hip -DLAB_TL: the hooked round-5 sources)."""
 import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,5 +1,5 @@
 """GPU lab: per-phase cycles (s_memtime, wave 0 of every workgroup) of the split-product attention (attn_f32_x3.hip: forward,
-dK/dV and dQ bodies).  Needs scripts/lab/_build/libacr_x3tl.so:  scripts/lab/build_variant.sh x3tl attn_f32_x3.hip -DLAB_TL"""
+dK/dV and dQ bodies).  Needs scripts/lab/_build/libacr_x3tl.so:  scripts/lab/build_variant.sh -H x3tl attn_f32_x3.hip -DLAB_TL  (the hooked round-5 sources)"""
 import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 """GPU lab: wall-clock timeline (s_memrealtime, 100 MHz) of every workgroup of one fp32 NT GEMM launch: when it started, when
 its first operand chunk had landed, when its K loop ended, when its epilogue stores had drained.  Needs the library built
-with EXTRA=-DLAB_TL (scripts/lab/_build/libacr_hip_tl.so).  usage: gemm_timeline.py N K"""
+with -DLAB_TL from the hooked round-5 sources (scripts/lab/build_variant.sh -H hip_tl gemm_f32.hip -DLAB_TL -> scripts/lab/_build/libacr_hip_tl.so).  usage: gemm_timeline.py N K"""
 import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

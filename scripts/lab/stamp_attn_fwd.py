@@ -1,4 +1,4 @@
-"""Lab (GPU box): per-phase cycles of the fp32 attention forward; needs libacr_hip.so built with EXTRA=-DLAB_STAMP."""
+"""Lab (GPU box): per-phase cycles of the fp32 attention forward; needs a library whose attn_f32_dma.hip is the hooked round-5 source: scripts/lab/build_variant.sh -H stamp attn_f32_dma.hip -DLAB_STAMP."""
 import ctypes, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from acr_wsss_amd import ops, _lib as L
