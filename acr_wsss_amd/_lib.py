@@ -171,18 +171,18 @@ SIGNATURES = {
                                       c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
 }
 
-# acr_option (include/acr_hip.h) and the documented A/B environment variable each one is set from at load time
-OPTIONS = {"gemm_variant": (0, "ACR_GEMM_VARIANT"), "gemm_nowide": (1, "ACR_GEMM_NOWIDE"), "gemm_regstage": (2, "ACR_GEMM_REGSTAGE"),
-           "wgrad_variant": (3, "ACR_WGRAD_VARIANT"), "wgrad_waves": (4, "ACR_WGRAD_WAVES"), "dq_variant": (5, "ACR_DQ_VARIANT"),
-           "gemm_f32_regstage": (6, "ACR_GEMM_F32_REGSTAGE"), "gemm_x3_inkernel": (11, "ACR_GEMM_X3_INKERNEL"),
-           "gemm_f32_notail": (9, "ACR_GEMM_F32_NOTAIL"), "attn_delta_1head": (7, "ACR_ATTN_DELTA_1HEAD"), "attn_f32_nosplittail": (10, "ACR_ATTN_F32_NOSPLITTAIL")}
+# acr_option (include/acr_hip.h): kernel-variant selectors of the library's explicit option table, name -> code.  Set through
+# set_option() by tests and lab scripts only; round 6 removed the environment variables that used to feed them at load time
+# (every A/B they served is recorded and settled) -- the library itself never reads the environment.
+OPTIONS = {"gemm_variant": 0, "gemm_nowide": 1, "gemm_regstage": 2, "wgrad_variant": 3, "wgrad_waves": 4, "dq_variant": 5,
+           "gemm_f32_regstage": 6, "attn_delta_1head": 7, "gemm_f32_notail": 9, "attn_f32_nosplittail": 10, "gemm_x3_inkernel": 11}
 
 _lib = None
 
 
 def set_option(name, value):
     """Select a kernel variant (A/B measurement switch; acr_set_option in include/acr_hip.h)."""
-    check(load().acr_set_option(OPTIONS[name][0], int(value)), "acr_set_option")
+    check(load().acr_set_option(OPTIONS[name], int(value)), "acr_set_option")
 
 
 class AcrHipError(RuntimeError):
@@ -204,10 +204,6 @@ def load():
         if lib.acr_version() != 2:
             raise AcrHipError("libacr_hip.so ABI version %d != 2 (rebuild it: __graft_entry__.build())" % lib.acr_version())
         _lib = lib
-        for name, (code, env) in OPTIONS.items():            # the library itself never reads the environment
-            val = os.environ.get(env)
-            if val is not None:
-                lib.acr_set_option(code, int(val) if val.lstrip("-").isdigit() else 1)
     return _lib
 
 

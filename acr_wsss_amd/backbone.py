@@ -103,9 +103,9 @@ class StdConv2dSame(nn.Conv2d):
         return self.forward(x), x
 
     hip_1x1 = True
-    hip_1x1_strided = os.environ.get("ACR_CONV1X1_STRIDED_HIP", "1") != "0"      # A/B: stride-2 1x1 convolutions as subsample + HIP GEMM
-    hip_3x3 = os.environ.get("ACR_CONV3X3_HIP", "1") != "0"      # A/B: the stem's 3x3 convolutions under f32_split on csrc/conv3x3.hip
-    pad_narrow = os.environ.get("ACR_CONV3X3_PAD_NARROW", "1") != "0"      # A/B: maps of 4 / 8 / 12 columns widened to 16 instead of the library
+    hip_1x1_strided = True      # A/B: stride-2 1x1 convolutions as subsample + HIP GEMM
+    hip_3x3 = True      # A/B: the stem's 3x3 convolutions under f32_split on csrc/conv3x3.hip
+    pad_narrow = True      # A/B: maps of 4 / 8 / 12 columns widened to 16 instead of the library
     acr_math = 0            # _lib.MATH code of the fp32 products (set_math)
 
     _w_hat = None           # set for one forward by ResNetV2 when all weights are standardised in one fused launch
@@ -377,9 +377,9 @@ class Mlp(nn.Module):
 
     acr_math = 0            # _lib.MATH code of the fp32 products (set_math)
 
-    fused = os.environ.get("ACR_MLP_FUSED", "1") != "0"
-    mlp_on_lib = os.environ.get("ACR_MLP_LIB", "0") == "1"
-    fc2_hip_fwd = os.environ.get("ACR_FC2_HIP", "1") != "0"     # A/B: fc2 forward on the hand-written GEMM (fused residual)
+    fused = True
+    mlp_on_lib = False
+    fc2_hip_fwd = True     # A/B: fc2 forward on the hand-written GEMM (fused residual)
 
 
 class Attention(nn.Module):

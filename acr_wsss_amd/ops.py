@@ -12,7 +12,7 @@ from . import _lib as L
 HEAD_DIM = 64
 # fp32 attention with a backward keeps its logits resident in HBM (csrc/attn_f32_sres.hip); ACR_ATTN_F32_SCORES=0 selects the
 # recompute generation (csrc/attn_f32_dma.hip) for A/B runs
-ATTN_F32_SCORES = os.environ.get("ACR_ATTN_F32_SCORES", "1") != "0"
+ATTN_F32_SCORES = True
 
 
 def pad4(n):
@@ -235,7 +235,7 @@ def attention_core(qkv, heads, stack=None, layer=0, owner=None, math=0):
     return AttnCoreFn.apply(qkv, heads, stack, layer, owner, math)
 
 
-ATTN_O_IMAGE = os.environ.get("ACR_ATTN_O_IMAGE", "1") != "0"      # A/B: the attention output's image from the forward's epilogue
+ATTN_O_IMAGE = True      # A/B: the attention output's image from the forward's epilogue
 
 
 def attention_core_oimg(qkv, heads, stack=None, layer=0, owner=None, math=0):
@@ -331,7 +331,7 @@ def wgrad_bf16(dy2, x2):
     return dw
 
 
-FUSED_BIAS_GRAD = os.environ.get("ACR_WGRAD_FUSED_BIAS", "1") != "0"      # A/B switch
+FUSED_BIAS_GRAD = True      # A/B switch
 
 
 def wgrad_bias_bf16(dy2, x2):
@@ -419,7 +419,7 @@ def weight_t(weight, owner=None, make=True):
     return weight.t().contiguous() if make else None
 
 
-F32_WT = os.environ.get("ACR_F32_WT", "1") != "0"      # A/B switch: fp32 input gradients on the cached W^T (NT) vs W as stored (NN)
+F32_WT = True      # A/B switch: fp32 input gradients on the cached W^T (NT) vs W as stored (NN)
 
 
 def _dx_f32(dy2, weight, owner, out, aux=None, act=0, math=0):
@@ -566,7 +566,7 @@ def gemm_f32_raw(mode, a, b, c, bias=None, aux=None, act=0, c2=None, colsum=None
     return c
 
 
-X3_IMAGES = os.environ.get("ACR_X3_IMAGES", "1") != "0"      # A/B: split-product Linears keep operand images across forward / backward
+X3_IMAGES = True      # A/B: split-product Linears keep operand images across forward / backward
 
 
 def x3_image(x2, colsum=None):
@@ -701,7 +701,7 @@ def gemm_x3(mode, a_img, b_img, c, K, bias=None, aux=None, act=0, c2=None, colsu
     return c
 
 
-X3_IMAGE_EPILOGUES = os.environ.get("ACR_X3_IMAGE_EPILOGUES", "1") != "0"      # A/B: the MLP's 4x-wide tensors leave their GEMMs as images
+X3_IMAGE_EPILOGUES = True      # A/B: the MLP's 4x-wide tensors leave their GEMMs as images
 
 
 def x3_image_empty(rows, cols, device):
@@ -720,7 +720,7 @@ def linear_f32_usable(x, weight):
             and weight.is_contiguous() and K % 4 == 0 and N % 4 == 0 and K >= 32 and N >= 32 and x.numel() // K >= 1)
 
 
-F32_HIP_LINEAR = os.environ.get("ACR_F32_HIP_LINEAR", "1") != "0"      # A/B switch: fp32 Linears on acr_gemm_f32 vs hipBLASLt
+F32_HIP_LINEAR = True      # A/B switch: fp32 Linears on acr_gemm_f32 vs hipBLASLt
 
 
 class LinearF32Fn(Function):
@@ -966,7 +966,7 @@ def subsample2(x):
     return x[:, :, ::2, ::2].contiguous()
 
 
-F32_HIP_CONV1X1 = os.environ.get("ACR_F32_HIP_CONV1X1", "1") != "0"      # A/B switch: fp32 1x1 convolutions on acr_conv1x1_f32 vs MIOpen
+F32_HIP_CONV1X1 = True      # A/B switch: fp32 1x1 convolutions on acr_conv1x1_f32 vs MIOpen
 
 
 def conv1x1_fusable(x, weight, stride):
@@ -980,7 +980,7 @@ def conv1x1_fusable(x, weight, stride):
             and (H * W) % 8 == 0)
 
 
-CONV1X1_WIMG = os.environ.get("ACR_CONV1X1_WIMG", "1") != "0"      # A/B: split-product 1x1 convolutions with the weight as an image
+CONV1X1_WIMG = True      # A/B: split-product 1x1 convolutions with the weight as an image
 
 
 def _conv1x1_f32_launch(math, w2, w_transposed, x, addend, y, N, co, ci, hw, img=None):
@@ -1068,7 +1068,7 @@ def conv3x3_fusable(x, weight, stride, math):
             and (x.shape[2] * x.shape[3]) % 16 == 0)
 
 
-CONV3X3_WIMG = os.environ.get("ACR_CONV3X3_WIMG", "1") != "0"      # A/B: 3x3 convolutions with the packed weight as a split-product image
+CONV3X3_WIMG = True      # A/B: 3x3 convolutions with the packed weight as a split-product image
 
 
 def _conv3x3_launch(wp, x, y, N, co, ci, H, W, img=None):
@@ -1127,7 +1127,7 @@ def conv3x3(x, weight, imgs=None):
 
 
 # ---- stride-2 SAME convolutions (7x7 stem convolution, the two stride-2 3x3s) on the tap-table kernels -------------------------
-CONV_S2_HIP = os.environ.get("ACR_CONV_S2_HIP", "1") != "0"      # A/B: strided convolutions under f32_split on csrc/conv3x3.hip vs MIOpen
+CONV_S2_HIP = True      # A/B: strided convolutions under f32_split on csrc/conv3x3.hip vs MIOpen
 
 
 class _S2Plan:
@@ -1379,7 +1379,7 @@ def layer_norm(x, ln, use_hip=True):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
 
 
-SKIP_FUSION = os.environ.get("ACR_SKIP_FUSION", "1") != "0"      # A/B switch for the fused skip-gradient adds
+SKIP_FUSION = True      # A/B switch for the fused skip-gradient adds
 
 
 def layer_norm_skip(x, ln, use_hip=True):
@@ -1391,7 +1391,7 @@ def layer_norm_skip(x, ln, use_hip=True):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps), x
 
 
-TOKENS_HIP = os.environ.get("ACR_TOKENS_HIP", "1") != "0"      # A/B: the hybrid ViT's token assembly as one kernel each way
+TOKENS_HIP = True      # A/B: the hybrid ViT's token assembly as one kernel each way
 
 
 class TokensFn(Function):
@@ -1429,7 +1429,7 @@ def tokens(y, bias, prefix, pos):
     return TokensFn.apply(y, bias, prefix, pos)
 
 
-LN_IMAGE = os.environ.get("ACR_LN_IMAGE", "1") != "0"      # A/B: the blocks' LayerNorms write their consumer's operand image directly
+LN_IMAGE = True      # A/B: the blocks' LayerNorms write their consumer's operand image directly
 
 
 def ln_image_usable(x, ln, lin, math, use_hip=True):
@@ -1448,7 +1448,7 @@ def layer_norm_image(x, ln):
 
 
 GN_ACT = {"none": 0, "relu": 1, "add_relu": 2}
-F32_HIP_NORMS = os.environ.get("ACR_F32_HIP_NORMS", "1") != "0"      # A/B switch: fp32 GroupNorm on the HIP kernels vs torch
+F32_HIP_NORMS = True      # A/B switch: fp32 GroupNorm on the HIP kernels vs torch
 
 
 def groupnorm_fusable(x, resid=None):
@@ -1525,7 +1525,7 @@ def _wstd_desc(p0s, p1s, p2s, device, p3s=None):
     return host.to(device, non_blocking=True), ch
 
 
-WSTD_TRANSPOSED = os.environ.get("ACR_WSTD_TRANSPOSED", "1") != "0"      # A/B: transposed 1x1 weights from the weight-std launch
+WSTD_TRANSPOSED = True      # A/B: transposed 1x1 weights from the weight-std launch
 
 
 class WeightStdAllFn(Function):

@@ -63,7 +63,7 @@ class PolyOptimizer(torch.optim.SGD):
 
     # ---- all-fp32 CUDA model: momentum + update of every parameter in ONE launch (acr_sgd_step_f32), bit-identical to the
     # stock multi-tensor path (13 launches, 0.95 ms per step at this model's 86 M parameters) ----
-    fused = os.environ.get("ACR_F32_FUSED_SGD", "1") != "0"
+    fused = True
 
     def _fused_ok(self):
         if not self.fused or len(self.param_groups) != 1 or _set_versions is None:
@@ -127,7 +127,7 @@ class PolyOptimizer(torch.optim.SGD):
         _set_versions(ps, [p._version + 1 for p in ps])
 
 
-TABLE_CHECK = os.environ.get("ACR_SGD_TABLE_CHECK", "1") != "0"      # A/B (timing only): per-step refresh of the pointer table
+TABLE_CHECK = True      # A/B (timing only): per-step refresh of the pointer table
 
 
 class MasterWeights:
