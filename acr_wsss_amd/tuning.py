@@ -1,5 +1,5 @@
 """Library-GEMM selection for the three MLP GEMMs when they run on hipBLASLt (fc1 forward, fc1 / fc2 input gradients:
-the ACR_MLP_LIB=1 A/B configuration; by default they run on this library's eight-wave kernel).
+the `Mlp.mlp_on_lib = True` A/B configuration; by default they run on this library's eight-wave kernel).
 
 hipBLASLt's default heuristic picks 130-150 us kernels for these shapes at the bench geometry; its own exhaustive search
 (PyTorch TunableOp, run once on an MI355X: ``PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 python bench.py``)
@@ -15,7 +15,7 @@ TUNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop
 def enable_tuned_gemms(path=TUNED_FILE):
     """Returns True when the tuned selections were loaded."""
     # Off by default since the block GEMMs moved to this library's kernels (nothing in the step that TunableOp covers is
-    # hot any more); ACR_TUNED_GEMMS=1 brings the lookup back for the ACR_MLP_LIB=1 / ACR_MLP_FUSED=0 A/B configurations.
+    # hot any more); ACR_TUNED_GEMMS=1 brings the lookup back for the `Mlp.mlp_on_lib` / `Mlp.fused = False` A/B configurations.
     if os.environ.get("ACR_TUNED_GEMMS", "0") != "1" or not torch.cuda.is_available() or not os.path.exists(path):
         return False
     try:
