@@ -702,6 +702,48 @@ def _sighted(vit, key):
     return n >= vit.graph_sightings
 
 
+class _PosEmbedResizeFn(torch.autograd.Function):
+    """F.interpolate(grid, (gs_h, gs_w), mode="bilinear") of the position-embedding grid (vision_transformer.py:490-504) with a
+    DETERMINISTIC backward.  The stock backward scatters with float atomics: when several output pixels read one input pixel
+    (any up-scaling -- 24^2 -> 28^2 at the BASELINE geometry) the gradient of `pos_embed` came out in a different summation
+    order from run to run: the one tensor of a 448^2 step that did not repeat bit for bit (scripts/lab/step_repeat.py, round
+    6).  Here every INPUT pixel gathers its (at most `m`) contributing output pixels through a table built once per geometry
+    from the operator itself (the images of the unit vectors under the very same F.interpolate) and sums them in ascending
+    output order.  Forward values are the stock op's, bit for bit."""
+    _tables = {}
+
+    @staticmethod
+    def tables(gs_old_h, gs_old_w, gs_h, gs_w, device, dtype):
+        key = (gs_old_h, gs_old_w, gs_h, gs_w, str(device), dtype)
+        t = _PosEmbedResizeFn._tables.get(key)
+        if t is None:
+            n_in = gs_old_h * gs_old_w
+            with torch.no_grad():
+                eye = torch.eye(n_in, device=device, dtype=torch.float32).reshape(n_in, 1, gs_old_h, gs_old_w)
+                R = F.interpolate(eye, size=(gs_h, gs_w), mode="bilinear").reshape(n_in, gs_h * gs_w)       # R[input pixel, output pixel]
+                nz = R != 0
+                m = max(1, int(nz.sum(1).max()))
+                # stable: the non-zero columns of every row first, in ascending output order
+                idx = torch.sort(nz.to(torch.int8), dim=1, descending=True, stable=True).indices[:, :m].contiguous()
+                w = R.gather(1, idx).to(dtype)                                                           # zero weight where a row has fewer than m
+            t = _PosEmbedResizeFn._tables[key] = (idx, w)
+        return t
+
+    @staticmethod
+    def forward(ctx, grid, gs_h, gs_w):
+        ctx.geom = (grid.shape[2], grid.shape[3], gs_h, gs_w)
+        return F.interpolate(grid, size=(gs_h, gs_w), mode="bilinear")
+
+    @staticmethod
+    def backward(ctx, g):
+        oh, ow, gs_h, gs_w = ctx.geom
+        idx, w = _PosEmbedResizeFn.tables(oh, ow, gs_h, gs_w, g.device, g.dtype)
+        b, c = g.shape[0], g.shape[1]
+        gf = g.reshape(b * c, gs_h * gs_w)
+        gi = (gf[:, idx] * w).sum(-1)                        # (b c, input pixels, m) -> fixed-order sum over m
+        return gi.reshape(b, c, oh, ow), None, None
+
+
 class VisionTransformer(nn.Module):
     def __init__(self, embed_dim=768, depth=12, num_heads=12, hybrid=True, patch=16, img_size=384,
                  num_classes=1000, distilled=False, in_chans=3):
@@ -750,7 +792,7 @@ class VisionTransformer(nn.Module):
         if gs_old == gs_h and gs_old == gs_w:
             return posemb
         grid = grid.reshape(1, gs_old, gs_old, -1).permute(0, 3, 1, 2)
-        grid = F.interpolate(grid, size=(gs_h, gs_w), mode="bilinear")
+        grid = _PosEmbedResizeFn.apply(grid, gs_h, gs_w)
         grid = grid.permute(0, 2, 3, 1).reshape(1, gs_h * gs_w, -1)
         return torch.cat([tok, grid], dim=1)
 

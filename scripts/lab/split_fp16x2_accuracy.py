@@ -33,9 +33,9 @@ DEV = torch.device("cuda:0")
 
 def pow2_scale(x, dim):
     """Exact power of two per slice along `dim` that puts the slice's largest magnitude in [2^14, 2^15)."""
-    m = x.abs().amax(dim=dim, keepdim=True).clamp_min(2.0 ** -120)
-    e = torch.floor(torch.log2(m))
-    return torch.exp2(14.0 - e)
+    m = x.abs().amax(dim=dim, keepdim=True)
+    e = torch.floor(torch.log2(m.clamp_min(2.0 ** -100))).clamp(-100.0, 100.0)
+    return torch.where(m > 0, torch.exp2(14.0 - e), torch.ones_like(m))         # an all-zero slice keeps scale 1
 
 
 def split16(x, s):

@@ -102,6 +102,10 @@ def _hybrid_worker(rank, world, port, out):
     from acr_wsss_amd.train import PolyOptimizer, train_step
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    # at this small geometry a few stem convolutions still fall to MIOpen (maps narrower than the HIP kernels' tiles), whose
+    # default solvers sum with atomics, forward included: held to the deterministic ones as in tests/conftest.py -- measured
+    # without it (scripts/lab/step_repeat.py): the SAME step repeated moves the stem's gradients by up to 2 % of their maximum
+    torch.backends.cudnn.deterministic = True
     model = _build_hybrid()
     broadcast_parameters(model, 0)
     # exactly what bench.py --gpus N builds: the declared-late stem parameters in the last bucket, static graph
@@ -152,7 +156,11 @@ def test_two_rank_hybrid_late_buckets_static_graph_matches_single_process():
     for it in range(4):
         diff = (out[0][it] - ref).abs()
         print("hybrid DP step %d vs single process: max %.3e mean %.3e of max %.3e" % (it, diff.max(), diff.mean(), ref.abs().max()))
-        assert diff.max() <= 2e-3 * ref.abs().max() and diff.mean() <= 1e-5 * ref.abs().max(), (it, diff.max(), diff.mean())
+        # (mean: measured 1.6e-7 of max.  The maximum sits in the stem's ill-conditioned gradients -- a 2-sample shard groups a few
+        # fp32 sums differently from the 4-sample batch, sign() gradients and 16 bottlenecks of GroupNorm over 4 x 4 maps amplify
+        # the last bits: 1.8e-3 of max measured, the same at every step)
+        assert diff.max() <= 5e-3 * ref.abs().max() and diff.mean() <= 1e-5 * ref.abs().max(), (it, diff.max(), diff.mean())
+        assert torch.equal(out[0][it], out[0][0])          # lr 0 + deterministic kernels: every step repeats the first bit for bit
 
 
 def _rccl_worker(rank, world, port, out):
