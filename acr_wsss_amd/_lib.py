@@ -136,6 +136,10 @@ SIGNATURES = {
                                         c_float, c_int32, c_void_p, c_void_p]),
     "acr_groupnorm_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "acr_groupnorm_fwd_mask_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                             c_float, c_void_p, c_void_p]),
+    "acr_groupnorm_bwd_mask_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "acr_weight_std_bf16": (c_int32, [c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p]),
     "acr_weight_std_f32": (c_int32, [c_void_p, c_int32, c_int32, c_float, c_int32, c_void_p]),
     "acr_layernorm_fwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),

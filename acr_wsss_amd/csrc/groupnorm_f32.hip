@@ -62,11 +62,24 @@ __device__ __forceinline__ float gnf_wave_sum(float v) {
     }
 #define GNF_LD1(p) (p)
 
+// The ReLU mask of relu(gn(x) + resid) as ONE BYTE per 16-byte vector (bit e = element e was positive), written by the forward and read
+// by the backward INSTEAD of the residual (round 6): the backward needs the residual only to re-derive that mask -- 1/16 of its bytes.
+// Same expression, same bits: the mask is the one the forward applied.
+__device__ __forceinline__ uint8_t gnf_relu_bits(const f32x4& pre) {
+    return (uint8_t)((pre[0] > 0.f ? 1 : 0) | (pre[1] > 0.f ? 2 : 0) | (pre[2] > 0.f ? 4 : 0) | (pre[3] > 0.f ? 8 : 0));
+}
+__device__ __forceinline__ f32x4 gnf_apply_bits(const f32x4& gy, uint32_t bits) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = ((bits >> e) & 1u) ? gy[e] : 0.f;
+    return o;
+}
+
 template <int NT, int ACT>
 __global__ __launch_bounds__(NT) void gnf_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y, float* __restrict__ stats, int C, int HW, int cg, float eps,
-                                                     GnfUnits un) {
+                                                     GnfUnits un, uint8_t* __restrict__ mk) {
     constexpr int NW = NT / 64;
     __shared__ float sh[2 * NW];
     const int g = blockIdx.x % GNF_GROUPS, n = blockIdx.x / GNF_GROUPS;
@@ -104,11 +117,13 @@ __global__ __launch_bounds__(NT) void gnf_fwd_kernel(const float* __restrict__ x
         const f32x4* xv = reinterpret_cast<const f32x4*>(x + base + (int64_t)cl * HW);
         const f32x4* rv = reinterpret_cast<const f32x4*>(res + (ACT == GNF_ADD_RELU ? base + (int64_t)cl * HW : 0));
         f32x4* yv = reinterpret_cast<f32x4*>(y + base + (int64_t)cl * HW);
+        uint8_t* mv = (ACT == GNF_ADD_RELU && mk) ? mk + ((base + (int64_t)cl * HW) >> 2) : nullptr;
         auto fin = [&](int v, const f32x4& a, const f32x4& r) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = fmaf(a[e], ga, be);
             if (ACT == GNF_ADD_RELU) o += r;
+            if (ACT == GNF_ADD_RELU && mv) mv[v] = gnf_relu_bits(o);
             if (ACT != GNF_NONE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ beta, const float* __restrict__ stats,
                                                      float* __restrict__ dx, float* __restrict__ dres,
                                                      float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int C, int HW, int cg,
-                                                     GnfUnits un) {
+                                                     GnfUnits un, const uint8_t* __restrict__ mk) {
     constexpr int NW = NT / 64;
     __shared__ float shu[2 * GNF_MAXU];                     // per unit: sum(dy'), sum(dy' * xhat)
     __shared__ float shc[2];
@@ -151,8 +166,10 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
     // the forward's exact expression decides the ReLU mask, so it is the one forward applied
+    const bool bymask = ACT == GNF_ADD_RELU && mk != nullptr;      // uniform: the forward's mask bytes instead of the residual
     auto masked = [&](const f32x4& gy, const f32x4& a, const f32x4& r, float ga, float be) {
         f32x4 o = gy;
+        if (bymask) return gnf_apply_bits(gy, __float_as_uint(r[0]));
         if (ACT != GNF_NONE) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -171,7 +188,10 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
         const float gam = gamma[c], ga = gam * rstd, be = beta[c] - mean * ga;
         const f32x4* xv = reinterpret_cast<const f32x4*>(x + base + (int64_t)cl * HW);
         const f32x4* gv = reinterpret_cast<const f32x4*>(dy + base + (int64_t)cl * HW);
-        const f32x4* rv = reinterpret_cast<const f32x4*>(res + (ACT == GNF_ADD_RELU ? base + (int64_t)cl * HW : 0));
+        const f32x4* rv = reinterpret_cast<const f32x4*>(res + ((ACT == GNF_ADD_RELU && !bymask) ? base + (int64_t)cl * HW : 0));
+        const uint8_t* mv = bymask ? mk + ((base + (int64_t)cl * HW) >> 2) : nullptr;
+        // r of a vector: the residual, or (bymask) the vector's mask byte carried in r[0]'s bits
+        auto ldr = [&](int vv) { f32x4 r = {0.f, 0.f, 0.f, 0.f}; if (bymask) r[0] = __uint_as_float((uint32_t)mv[vv]); else r = rv[vv]; return r; };
         float db = 0.f, dg = 0.f;
         auto acc = [&](const f32x4& a, const f32x4& gy0, const f32x4& r) {
             const f32x4 gy = masked(gy0, a, r, ga, be);
@@ -182,13 +202,13 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
         for (; v + 64 < v1; v += 128) {                     // two vectors of each of the (up to) three streams in flight
             const f32x4 a0 = xv[v], a1 = xv[v + 64], y0 = gv[v], y1 = gv[v + 64];
             f32x4 r0 = z4, r1 = z4;
-            if (ACT == GNF_ADD_RELU) { r0 = rv[v]; r1 = rv[v + 64]; }
+            if (ACT == GNF_ADD_RELU) { r0 = ldr(v); r1 = ldr(v + 64); }
             acc(a0, y0, r0); acc(a1, y1, r1);
         }
         for (; v < v1; v += 64) {
             const f32x4 a0 = xv[v], y0 = gv[v];
             f32x4 r0 = z4;
-            if (ACT == GNF_ADD_RELU) r0 = rv[v];
+            if (ACT == GNF_ADD_RELU) r0 = ldr(v);
             acc(a0, y0, r0);
         }
         db = gnf_wave_sum(db);
@@ -220,7 +240,9 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
         const float gam = gamma[c], ga = gam * rstd, be = beta[c] - mean * ga;
         const f32x4* xv = reinterpret_cast<const f32x4*>(x + base + (int64_t)cl * HW);
         const f32x4* gv = reinterpret_cast<const f32x4*>(dy + base + (int64_t)cl * HW);
-        const f32x4* rv = reinterpret_cast<const f32x4*>(res + (ACT == GNF_ADD_RELU ? base + (int64_t)cl * HW : 0));
+        const f32x4* rv = reinterpret_cast<const f32x4*>(res + ((ACT == GNF_ADD_RELU && !bymask) ? base + (int64_t)cl * HW : 0));
+        const uint8_t* mv = bymask ? mk + ((base + (int64_t)cl * HW) >> 2) : nullptr;
+        auto ldr = [&](int vv) { f32x4 r = {0.f, 0.f, 0.f, 0.f}; if (bymask) r[0] = __uint_as_float((uint32_t)mv[vv]); else r = GNF_LD2(rv[vv]); return r; };
         f32x4* ov = reinterpret_cast<f32x4*>(dx + base + (int64_t)cl * HW);
         f32x4* dv = reinterpret_cast<f32x4*>(dres + (ACT == GNF_ADD_RELU ? base + (int64_t)cl * HW : 0));
         auto fin = [&](int vv, const f32x4& a, const f32x4& gy0, const f32x4& r) {
@@ -235,13 +257,13 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
         for (; v + 64 < v1; v += 128) {
             const f32x4 a0 = GNF_LD2(xv[v]), a1 = GNF_LD2(xv[v + 64]), y0 = GNF_LD2(gv[v]), y1 = GNF_LD2(gv[v + 64]);
             f32x4 r0 = z4, r1 = z4;
-            if (ACT == GNF_ADD_RELU) { r0 = GNF_LD2(rv[v]); r1 = GNF_LD2(rv[v + 64]); }
+            if (ACT == GNF_ADD_RELU) { r0 = ldr(v); r1 = ldr(v + 64); }
             fin(v, a0, y0, r0); fin(v + 64, a1, y1, r1);
         }
         for (; v < v1; v += 64) {
             const f32x4 a0 = GNF_LD2(xv[v]), y0 = GNF_LD2(gv[v]);
             f32x4 r0 = z4;
-            if (ACT == GNF_ADD_RELU) r0 = GNF_LD2(rv[v]);
+            if (ACT == GNF_ADD_RELU) r0 = ldr(v);
             fin(v, a0, y0, r0);
         }
     }
@@ -279,11 +301,20 @@ struct GnfWalk {
 };
 #define GNF_AT(T, p, boff) (*reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<float*>(p)) + (boff)))
 
-template <int NT, int ACT>
+// the byte offset of slot (cl, vector v) of the walk inside the (sample, group); a lane past its segment re-reads a valid vector
+// and ignores it.  Recomputed in every loop from the walk (scalar unit + two VALU operations) instead of being kept in a register
+// per slot: with RV = 25 slots the offsets alone were 25 of the 128 registers a 1024-thread workgroup's waves may hold.
+__device__ __forceinline__ uint32_t gnf_off(const GnfWalk& wk, int lane, const GnfUnits& un, int vpc, int HW, bool& ok) {
+    const int v = wk.vector(lane, un, vpc);
+    ok = v >= 0;
+    return (uint32_t)(wk.cl * HW + 4 * max(v, 0)) * 4u;
+}
+
+template <int NT, int ACT, int RV>
 __global__ __launch_bounds__(NT) void gnf_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ y, float* __restrict__ stats, int C, int HW, int cg, float eps,
-                                                         GnfUnits un, int upw, int ch) {
+                                                         GnfUnits un, int upw, int ch, uint8_t* __restrict__ mk) {
     constexpr int NW = NT / 64;
     __shared__ float sh[2 * NW];
     const int g = blockIdx.x % GNF_GROUPS, n = blockIdx.x / GNF_GROUPS;
@@ -296,22 +327,20 @@ __global__ __launch_bounds__(NT) void gnf_fwd_reg_kernel(const float* __restrict
     const float* rb = res + (ACT == GNF_ADD_RELU ? base : 0);
     float* yb = y + base;
     const float x0 = xb[0];
-    f32x4 xr[GNF_RV];
-    uint32_t off[GNF_RV];
+    f32x4 xr[RV];
     uint32_t okm = 0;
     GnfWalk wk(wave, NW, un);
 #pragma unroll
-    for (int i = 0; i < GNF_RV; ++i, wk.next(un, ch)) {
+    for (int i = 0; i < RV; ++i, wk.next(un, ch)) {
         if (!wk.valid(wave, NW, un, upw)) break;
-        const int cl = wk.cl;
-        const int v = wk.vector(lane, un, vpc);
-        okm |= (v >= 0 ? 1u : 0u) << i;
-        off[i] = (uint32_t)(cl * HW + 4 * max(v, 0)) * 4u;   // a lane past its segment re-reads a valid vector and ignores it
-        xr[i] = GNF_LD2(GNF_AT(const f32x4, xb, off[i]));
+        bool ok;
+        const uint32_t off = gnf_off(wk, lane, un, vpc, HW, ok);
+        okm |= (ok ? 1u : 0u) << i;
+        xr[i] = GNF_LD2(GNF_AT(const f32x4, xb, off));
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < GNF_RV; ++i) {
+    for (int i = 0; i < RV; ++i) {
         if ((okm >> i) & 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = xr[i][e] - x0; s1 += d; s2 = fmaf(d, d, s2); }
@@ -329,36 +358,39 @@ __global__ __launch_bounds__(NT) void gnf_fwd_reg_kernel(const float* __restrict
     const float rstd = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + eps);
     wk = GnfWalk(wave, NW, un);
 #pragma unroll
-    for (int i = 0; i < GNF_RV; ++i, wk.next(un, ch)) {
+    for (int i = 0; i < RV; ++i, wk.next(un, ch)) {
         if (!wk.valid(wave, NW, un, upw)) break;
         const int cl = wk.cl;
         const int c = g * cg + cl;
         const float ga = gamma[c] * rstd;
         const float be = beta[c] - mean * ga;
+        bool ok;
+        const uint32_t off = gnf_off(wk, lane, un, vpc, HW, ok);
         if ((okm >> i) & 1) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = fmaf(xr[i][e], ga, be);
-            if (ACT == GNF_ADD_RELU) o += GNF_LD2(GNF_AT(const f32x4, rb, off[i]));
+            if (ACT == GNF_ADD_RELU) o += GNF_LD2(GNF_AT(const f32x4, rb, off));
+            if (ACT == GNF_ADD_RELU && mk) mk[(base >> 2) + (off >> 4)] = gnf_relu_bits(o);
             if (ACT != GNF_NONE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
             }
-            GNF_ST(GNF_AT(f32x4, yb, off[i]), o);
+            GNF_ST(GNF_AT(f32x4, yb, off), o);
         }
     }
     if (tid == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
 }
 
-template <int NT, int ACT>
+template <int NT, int ACT, int RV>
 __global__ __launch_bounds__(NT) void gnf_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ res, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ stats,
                                                          float* __restrict__ dx, float* __restrict__ dres,
                                                          float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int C, int HW,
-                                                         int cg, GnfUnits un, int upw, int ch) {
+                                                         int cg, GnfUnits un, int upw, int ch, const uint8_t* __restrict__ mk) {
     constexpr int NW = NT / 64;
-    __shared__ float shp[NW * GNF_RV * 2];                  // [wave][slot]: sum(dy'), sum(dy' * xhat)
+    __shared__ float shp[NW * RV * 2];                  // [wave][slot]: sum(dy'), sum(dy' * xhat)
     __shared__ float shc[2];
     const int g = blockIdx.x % GNF_GROUPS, n = blockIdx.x / GNF_GROUPS;
     const int64_t base = ((int64_t)n * C + (int64_t)g * cg) * HW;
@@ -372,32 +404,37 @@ __global__ __launch_bounds__(NT) void gnf_bwd_reg_kernel(const float* __restrict
     const float* rb = res + (ACT == GNF_ADD_RELU ? base : 0);
     float* ob = dx + base;
     float* db_ = dres + (ACT == GNF_ADD_RELU ? base : 0);
-    f32x4 xr[GNF_RV], gr[GNF_RV];
-    uint32_t off[GNF_RV];
+    f32x4 xr[RV], gr[RV];
     uint32_t okm = 0;
     GnfWalk wk(wave, NW, un);
 #pragma unroll
-    for (int i = 0; i < GNF_RV; ++i, wk.next(un, ch)) {
+    for (int i = 0; i < RV; ++i, wk.next(un, ch)) {
         if (!wk.valid(wave, NW, un, upw)) break;
-        const int cl = wk.cl;
-        const int v = wk.vector(lane, un, vpc);
-        okm |= (v >= 0 ? 1u : 0u) << i;
-        off[i] = (uint32_t)(cl * HW + 4 * max(v, 0)) * 4u;
-        xr[i] = GNF_LD2(GNF_AT(const f32x4, xb, off[i]));
-        gr[i] = GNF_LD2(GNF_AT(const f32x4, gb, off[i]));
+        bool ok;
+        const uint32_t off = gnf_off(wk, lane, un, vpc, HW, ok);
+        okm |= (ok ? 1u : 0u) << i;
+        xr[i] = GNF_LD2(GNF_AT(const f32x4, xb, off));
+        gr[i] = GNF_LD2(GNF_AT(const f32x4, gb, off));
     }
     // the forward's exact expression decides the ReLU mask; the masked gradient replaces dy in the registers
     wk = GnfWalk(wave, NW, un);
 #pragma unroll
-    for (int i = 0; i < GNF_RV; ++i, wk.next(un, ch)) {
+    for (int i = 0; i < RV; ++i, wk.next(un, ch)) {
         if (!wk.valid(wave, NW, un, upw)) break;
         const int cl = wk.cl;
         const int c = g * cg + cl;
         const float gam = gamma[c], ga = gam * rstd, be = beta[c] - mean * ga;
         float db = 0.f, dg = 0.f;
-        if (ACT != GNF_NONE) {
+        if (ACT == GNF_ADD_RELU && mk != nullptr) {          // the forward's mask bytes (uniform branch): no residual read
+            bool ok;
+            const uint32_t off = gnf_off(wk, lane, un, vpc, HW, ok);
+            gr[i] = gnf_apply_bits(gr[i], mk[(base >> 2) + (off >> 4)]);
+        } else if (ACT != GNF_NONE) {
             f32x4 r = {0.f, 0.f, 0.f, 0.f};
-            if (ACT == GNF_ADD_RELU) r = GNF_LD2(GNF_AT(const f32x4, rb, off[i]));
+            if (ACT == GNF_ADD_RELU) {
+                bool ok;
+                r = GNF_LD2(GNF_AT(const f32x4, rb, gnf_off(wk, lane, un, vpc, HW, ok)));
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float pre = fmaf(xr[i][e], ga, be);
@@ -411,7 +448,7 @@ __global__ __launch_bounds__(NT) void gnf_bwd_reg_kernel(const float* __restrict
         }
         db = gnf_wave_sum(db);
         dg = gnf_wave_sum(dg);
-        if (lane == 0) { shp[(wave * GNF_RV + i) * 2] = db; shp[(wave * GNF_RV + i) * 2 + 1] = dg; }
+        if (lane == 0) { shp[(wave * RV + i) * 2] = db; shp[(wave * RV + i) * 2 + 1] = dg; }
     }
     __syncthreads();
     if (tid == 0) {                                         // channel sums in (segment, chunk) order, group sums in channel order
@@ -420,7 +457,7 @@ __global__ __launch_bounds__(NT) void gnf_bwd_reg_kernel(const float* __restrict
             float db = 0.f, dg = 0.f;
             for (int sg = 0; sg < un.S; ++sg) {
                 const int u = cl * un.S + sg, w = u % NW, k = u / NW;
-                for (int j = 0; j < ch; ++j) { db += shp[(w * GNF_RV + k * ch + j) * 2]; dg += shp[(w * GNF_RV + k * ch + j) * 2 + 1]; }
+                for (int j = 0; j < ch; ++j) { db += shp[(w * RV + k * ch + j) * 2]; dg += shp[(w * RV + k * ch + j) * 2 + 1]; }
             }
             const int c = g * cg + cl;
             dgamma_part[(int64_t)n * C + c] = dg;
@@ -436,16 +473,18 @@ __global__ __launch_bounds__(NT) void gnf_bwd_reg_kernel(const float* __restrict
     const float c1 = shc[0], c2 = shc[1];
     wk = GnfWalk(wave, NW, un);
 #pragma unroll
-    for (int i = 0; i < GNF_RV; ++i, wk.next(un, ch)) {
+    for (int i = 0; i < RV; ++i, wk.next(un, ch)) {
         if (!wk.valid(wave, NW, un, upw)) break;
         const int cl = wk.cl;
         const float gam = gamma[g * cg + cl];
+        bool ok;
+        const uint32_t off = gnf_off(wk, lane, un, vpc, HW, ok);
         if ((okm >> i) & 1) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rstd * (fmaf(gr[i][e], gam, -c1) - (xr[i][e] - mean) * rstd * c2);
-            GNF_ST(GNF_AT(f32x4, ob, off[i]), o);
-            if (ACT == GNF_ADD_RELU) GNF_ST(GNF_AT(f32x4, db_, off[i]), gr[i]);
+            GNF_ST(GNF_AT(f32x4, ob, off), o);
+            if (ACT == GNF_ADD_RELU) GNF_ST(GNF_AT(f32x4, db_, off), gr[i]);
         }
     }
 }
@@ -565,9 +604,15 @@ static int gnf_check(const char* who, int N, int C, int HW, int act) {
     return ACR_OK;
 }
 
-// register-resident plan: threads per workgroup, units, units per wave, chunks per unit; ok = every lane holds <= GNF_RV vectors
-struct GnfRegPlan { bool ok; int nt; GnfUnits un; int upw, ch; };
-static GnfRegPlan gnf_reg_plan(int cg, int HW) {
+// register-resident plan: threads per workgroup, units, units per wave, chunks per unit; slots = vectors every lane holds.
+// Round 6: the kernels are templated on the slot count.  A 1024-thread workgroup's waves may hold 128 registers each (four waves
+// per SIMD), i.e. up to 25 vectors of ONE operand: the forward keeps ALL of the step's groups resident (the 401 KB groups of the
+// 112^2 maps and of the stem norm: 25 slots -- one read + one write instead of two reads + one write), the backward, which holds
+// x and dy, groups of up to 13 slots (128 channels at 112^2, 512 at 56^2: 2 (3) reads instead of 4 (6)).
+#define GNF_RV_FWD_MAX 25
+#define GNF_RV_BWD_MAX 13
+struct GnfRegPlan { bool ok; int nt; GnfUnits un; int upw, ch, slots; };
+static GnfRegPlan gnf_reg_plan(int cg, int HW, int max_slots) {
     GnfRegPlan p;
     const int nvec = cg * (HW >> 2);
     p.nt = nvec > 2048 ? 1024 : 256;
@@ -575,36 +620,43 @@ static GnfRegPlan gnf_reg_plan(int cg, int HW) {
     p.un = gnf_units(cg, HW, nw);
     p.ch = (p.un.segv + 63) / 64;
     p.upw = (p.un.units + nw - 1) / nw;
-    p.ok = p.upw * p.ch <= GNF_RV && p.un.units <= GNF_MAXU;
+    p.slots = p.upw * p.ch;
+    p.ok = p.slots <= max_slots && p.un.units <= GNF_MAXU && (p.slots <= GNF_RV || p.nt == 1024);
     return p;
 }
-#define GNF_DISPATCH_REG(KERNEL, P, ...)                                                                          \
-    if ((P).nt == 1024) {                                                                                         \
-        if (act == 0) hipLaunchKernelGGL((KERNEL<1024, 0>), grid, dim3(1024), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);        \
-        else if (act == 1) hipLaunchKernelGGL((KERNEL<1024, 1>), grid, dim3(1024), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);   \
-        else hipLaunchKernelGGL((KERNEL<1024, 2>), grid, dim3(1024), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);                 \
-    } else {                                                                                                      \
-        if (act == 0) hipLaunchKernelGGL((KERNEL<256, 0>), grid, dim3(256), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);          \
-        else if (act == 1) hipLaunchKernelGGL((KERNEL<256, 1>), grid, dim3(256), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);     \
-        else hipLaunchKernelGGL((KERNEL<256, 2>), grid, dim3(256), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch);                   \
+#define GNF_LAUNCH_REG(KERNEL, NT_, RV_, P, ...)                                                                                     \
+    {                                                                                                                                \
+        if (act == 0) hipLaunchKernelGGL((KERNEL<NT_, 0, RV_>), grid, dim3(NT_), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch, relu_mask);       \
+        else if (act == 1) hipLaunchKernelGGL((KERNEL<NT_, 1, RV_>), grid, dim3(NT_), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch, relu_mask);  \
+        else hipLaunchKernelGGL((KERNEL<NT_, 2, RV_>), grid, dim3(NT_), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch, relu_mask);                \
     }
+#define GNF_DISPATCH_REG_FWD(KERNEL, P, ...)                                                       \
+    if ((P).nt == 256) GNF_LAUNCH_REG(KERNEL, 256, GNF_RV, P, __VA_ARGS__)                         \
+    else if ((P).slots <= GNF_RV) GNF_LAUNCH_REG(KERNEL, 1024, GNF_RV, P, __VA_ARGS__)             \
+    else if ((P).slots <= GNF_RV_BWD_MAX) GNF_LAUNCH_REG(KERNEL, 1024, GNF_RV_BWD_MAX, P, __VA_ARGS__) \
+    else GNF_LAUNCH_REG(KERNEL, 1024, GNF_RV_FWD_MAX, P, __VA_ARGS__)
+#define GNF_DISPATCH_REG_BWD(KERNEL, P, ...)                                                       \
+    if ((P).nt == 256) GNF_LAUNCH_REG(KERNEL, 256, GNF_RV, P, __VA_ARGS__)                         \
+    else if ((P).slots <= GNF_RV) GNF_LAUNCH_REG(KERNEL, 1024, GNF_RV, P, __VA_ARGS__)             \
+    else GNF_LAUNCH_REG(KERNEL, 1024, GNF_RV_BWD_MAX, P, __VA_ARGS__)
 
 #define GNF_DISPATCH(KERNEL, ...)                                                                                \
     if (big) {                                                                                                    \
         const GnfUnits un = gnf_units(cg, HW, 16);                                                                \
-        if (act == 0) hipLaunchKernelGGL((KERNEL<1024, 0>), grid, dim3(1024), 0, st, __VA_ARGS__, un);           \
-        else if (act == 1) hipLaunchKernelGGL((KERNEL<1024, 1>), grid, dim3(1024), 0, st, __VA_ARGS__, un);      \
-        else hipLaunchKernelGGL((KERNEL<1024, 2>), grid, dim3(1024), 0, st, __VA_ARGS__, un);                    \
+        if (act == 0) hipLaunchKernelGGL((KERNEL<1024, 0>), grid, dim3(1024), 0, st, __VA_ARGS__, un, relu_mask);           \
+        else if (act == 1) hipLaunchKernelGGL((KERNEL<1024, 1>), grid, dim3(1024), 0, st, __VA_ARGS__, un, relu_mask);      \
+        else hipLaunchKernelGGL((KERNEL<1024, 2>), grid, dim3(1024), 0, st, __VA_ARGS__, un, relu_mask);                    \
     } else {                                                                                                      \
         const GnfUnits un = gnf_units(cg, HW, 4);                                                                 \
-        if (act == 0) hipLaunchKernelGGL((KERNEL<256, 0>), grid, dim3(256), 0, st, __VA_ARGS__, un);             \
-        else if (act == 1) hipLaunchKernelGGL((KERNEL<256, 1>), grid, dim3(256), 0, st, __VA_ARGS__, un);        \
-        else hipLaunchKernelGGL((KERNEL<256, 2>), grid, dim3(256), 0, st, __VA_ARGS__, un);                      \
+        if (act == 0) hipLaunchKernelGGL((KERNEL<256, 0>), grid, dim3(256), 0, st, __VA_ARGS__, un, relu_mask);             \
+        else if (act == 1) hipLaunchKernelGGL((KERNEL<256, 1>), grid, dim3(256), 0, st, __VA_ARGS__, un, relu_mask);        \
+        else hipLaunchKernelGGL((KERNEL<256, 2>), grid, dim3(256), 0, st, __VA_ARGS__, un, relu_mask);                      \
     }
 
-extern "C" int acr_groupnorm_fwd_f32(const float* x, const float* resid, const float* gamma, const float* beta, float* y, float* stats,
-                                     int32_t N, int32_t C, int32_t HW, float eps, int32_t act, float* ws, void* stream) {
+static int gnf_fwd_impl(const float* x, const float* resid, const float* gamma, const float* beta, float* y, float* stats,
+                        int32_t N, int32_t C, int32_t HW, float eps, int32_t act, float* ws, uint8_t* relu_mask, void* stream) {
     ACR_CHECK_ARG(x && gamma && beta && y && stats && (act != GNF_ADD_RELU || resid), "acr_groupnorm_fwd_f32: null pointer");
+    ACR_CHECK_ARG(!relu_mask || (act == GNF_ADD_RELU && !ws), "acr_groupnorm_fwd_mask_f32: the mask exists for act = 2 (residual + ReLU) without the small-launch workspace");
     int rc = gnf_check("acr_groupnorm_fwd_f32", N, C, HW, act);
     if (rc) return rc;
     ACR_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)resid & 15) == 0, "acr_groupnorm_fwd_f32: 16-byte alignment");
@@ -622,19 +674,31 @@ extern "C" int acr_groupnorm_fwd_f32(const float* x, const float* resid, const f
         else hipLaunchKernelGGL((gnf_apply_kernel<2>), pgrid, dim3(256), 0, st, x, resid, gamma, beta, (const float*)ws, y, stats, C, HW, cg, P, vper, eps);
         return acr_check_launch("acr_groupnorm_fwd_f32(parts)");
     }
-    const GnfRegPlan rp = gnf_reg_plan(cg, HW);
+    const GnfRegPlan rp = gnf_reg_plan(cg, HW, GNF_RV_FWD_MAX);
     if (rp.ok) {                                            // the group fits the workgroup's registers: one read
-        GNF_DISPATCH_REG(gnf_fwd_reg_kernel, rp, x, resid, gamma, beta, y, stats, C, HW, cg, eps)
+        GNF_DISPATCH_REG_FWD(gnf_fwd_reg_kernel, rp, x, resid, gamma, beta, y, stats, C, HW, cg, eps)
         return acr_check_launch("acr_groupnorm_fwd_f32(reg)");
     }
     GNF_DISPATCH(gnf_fwd_kernel, x, resid, gamma, beta, y, stats, C, HW, cg, eps)
     return acr_check_launch("acr_groupnorm_fwd_f32");
 }
 
-extern "C" int acr_groupnorm_bwd_f32(const float* dy, const float* x, const float* resid, const float* gamma, const float* beta,
-                                     const float* stats, float* dx, float* dresid, float* dgamma_part, float* dbeta_part,
-                                     float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t act, void* stream) {
-    ACR_CHECK_ARG(dy && x && gamma && beta && stats && dx && dgamma_part && dbeta_part && (act != GNF_ADD_RELU || (resid && dresid)),
+extern "C" int acr_groupnorm_fwd_f32(const float* x, const float* resid, const float* gamma, const float* beta, float* y, float* stats,
+                                     int32_t N, int32_t C, int32_t HW, float eps, int32_t act, float* ws, void* stream) {
+    return gnf_fwd_impl(x, resid, gamma, beta, y, stats, N, C, HW, eps, act, ws, nullptr, stream);
+}
+// act = 2 (relu(gn(x) + resid)) that also writes the ReLU mask, one byte per 16-byte vector of y (N*C*HW/4 bytes): the backward
+// (acr_groupnorm_bwd_mask_f32) reads it instead of the residual.
+extern "C" int acr_groupnorm_fwd_mask_f32(const float* x, const float* resid, const float* gamma, const float* beta, float* y, float* stats,
+                                          int32_t N, int32_t C, int32_t HW, float eps, uint8_t* relu_mask, void* stream) {
+    ACR_CHECK_ARG(relu_mask, "acr_groupnorm_fwd_mask_f32: null mask");
+    return gnf_fwd_impl(x, resid, gamma, beta, y, stats, N, C, HW, eps, GNF_ADD_RELU, nullptr, relu_mask, stream);
+}
+
+static int gnf_bwd_impl(const float* dy, const float* x, const float* resid, const float* gamma, const float* beta,
+                        const float* stats, float* dx, float* dresid, float* dgamma_part, float* dbeta_part,
+                        float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t act, const uint8_t* relu_mask, void* stream) {
+    ACR_CHECK_ARG(dy && x && gamma && beta && stats && dx && dgamma_part && dbeta_part && (act != GNF_ADD_RELU || ((resid || relu_mask) && dresid)),
                   "acr_groupnorm_bwd_f32: null pointer");
     int rc = gnf_check("acr_groupnorm_bwd_f32", N, C, HW, act);
     if (rc) return rc;
@@ -644,9 +708,9 @@ extern "C" int acr_groupnorm_bwd_f32(const float* dy, const float* x, const floa
     const bool big = (int64_t)HW >= 4096;                    // per-channel loops: 1024 threads only when a channel feeds them
     const dim3 grid(N * GNF_GROUPS);
     hipStream_t st = (hipStream_t)stream;
-    const GnfRegPlan rp = gnf_reg_plan(cg, HW);
+    const GnfRegPlan rp = gnf_reg_plan(cg, HW, GNF_RV_BWD_MAX);
     if (rp.ok) {
-        GNF_DISPATCH_REG(gnf_bwd_reg_kernel, rp, dy, x, resid, gamma, beta, stats, dx, dresid, dgamma_part, dbeta_part, C, HW, cg)
+        GNF_DISPATCH_REG_BWD(gnf_bwd_reg_kernel, rp, dy, x, resid, gamma, beta, stats, dx, dresid, dgamma_part, dbeta_part, C, HW, cg)
     } else {
         GNF_DISPATCH(gnf_bwd_kernel, dy, x, resid, gamma, beta, stats, dx, dresid, dgamma_part, dbeta_part, C, HW, cg)
     }
@@ -654,4 +718,17 @@ extern "C" int acr_groupnorm_bwd_f32(const float* dy, const float* x, const floa
         hipLaunchKernelGGL(gnf_param_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, (const float*)dgamma_part,
                            (const float*)dbeta_part, N, C, dgamma, dbeta);
     return acr_check_launch("acr_groupnorm_bwd_f32");
+}
+extern "C" int acr_groupnorm_bwd_f32(const float* dy, const float* x, const float* resid, const float* gamma, const float* beta,
+                                     const float* stats, float* dx, float* dresid, float* dgamma_part, float* dbeta_part,
+                                     float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t act, void* stream) {
+    return gnf_bwd_impl(dy, x, resid, gamma, beta, stats, dx, dresid, dgamma_part, dbeta_part, dgamma, dbeta, N, C, HW, act, nullptr, stream);
+}
+// backward of act = 2 from the forward's mask bytes: the residual is not read (6 -> 5 resp. 3 -> 2 operand reads + 1/16)
+extern "C" int acr_groupnorm_bwd_mask_f32(const float* dy, const float* x, const uint8_t* relu_mask, const float* gamma, const float* beta,
+                                          const float* stats, float* dx, float* dresid, float* dgamma_part, float* dbeta_part,
+                                          float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, void* stream) {
+    ACR_CHECK_ARG(relu_mask, "acr_groupnorm_bwd_mask_f32: null mask");
+    return gnf_bwd_impl(dy, x, nullptr, gamma, beta, stats, dx, dresid, dgamma_part, dbeta_part, dgamma, dbeta, N, C, HW, GNF_ADD_RELU, relu_mask,
+                        stream);
 }

@@ -1464,6 +1464,9 @@ def groupnorm_fusable(x, resid=None):
     return resid is None or (resid.shape == x.shape and resid.dtype == x.dtype and resid.is_contiguous())
 
 
+GN_RELU_MASK = True      # A/B: fp32 relu(gn(x) + resid) leaves a one-byte-per-vector ReLU mask for its backward (no residual read there)
+
+
 class GroupNormActFn(Function):
     """y = act(GroupNorm32(x) [+ resid]) on acr_groupnorm_{fwd,bwd}_bf16 (bf16 NCHW)."""
 
@@ -1473,7 +1476,14 @@ class GroupNormActFn(Function):
         lib = L.load()
         y = torch.empty_like(x)
         stats = torch.empty(N * 32 * 2, dtype=torch.float32, device=x.device)
-        if x.dtype == torch.float32:
+        mask = None
+        if x.dtype == torch.float32 and act == 2 and GN_RELU_MASK and any(ctx.needs_input_grad):
+            # relu(gn(x) + resid) with a backward to come: the forward leaves its ReLU mask, one byte per 16-byte vector, and the
+            # backward reads that instead of the residual (1/16 of its bytes: all it needed the residual for)
+            mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=x.device)
+            L.check(lib.acr_groupnorm_fwd_mask_f32(L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), N, C, H * W, eps,
+                                                   L.ptr(mask), L.stream_ptr()), "acr_groupnorm_fwd_mask_f32")
+        elif x.dtype == torch.float32:
             # gradient-free passes (CAM generation) of a few samples: the (sample, group) pairs are cut into parts (two launches)
             nws = lib.acr_groupnorm_fwd_ws_floats(N, C, H * W) if not any(ctx.needs_input_grad) else 0
             ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
@@ -1482,8 +1492,9 @@ class GroupNormActFn(Function):
         else:
             L.check(lib.acr_groupnorm_fwd_bf16(L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(stats), N, C, H * W, eps, act,
                                                L.stream_ptr()), "acr_groupnorm_fwd_bf16")
-        ctx.save_for_backward(x, weight, bias, stats, resid if act == 2 else None)
+        ctx.save_for_backward(x, weight, bias, stats, mask if mask is not None else (resid if act == 2 else None))
         ctx.act = act
+        ctx.by_mask = mask is not None
         return y
 
     @staticmethod
@@ -1497,6 +1508,11 @@ class GroupNormActFn(Function):
         dres = torch.empty_like(x) if ctx.act == 2 else None
         part = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
         dgb = torch.empty((2, C), dtype=x.dtype, device=x.device)             # summed over samples inside the call
+        if ctx.by_mask:
+            L.check(lib.acr_groupnorm_bwd_mask_f32(L.ptr(dy), L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(stats), L.ptr(dx), L.ptr(dres),
+                                                   L.ptr(part[0]), L.ptr(part[1]), L.ptr(dgb[0]), L.ptr(dgb[1]), N, C, H * W, L.stream_ptr()),
+                    "acr_groupnorm_bwd_mask_f32")
+            return dx, dgb[0], dgb[1], dres, None, None
         bwd = lib.acr_groupnorm_bwd_f32 if x.dtype == torch.float32 else lib.acr_groupnorm_bwd_bf16
         L.check(bwd(L.ptr(dy), L.ptr(x), L.ptr(resid), L.ptr(weight), L.ptr(bias), L.ptr(stats), L.ptr(dx), L.ptr(dres), L.ptr(part[0]),
                     L.ptr(part[1]), L.ptr(dgb[0]), L.ptr(dgb[1]), N, C, H * W, ctx.act, L.stream_ptr()), "acr_groupnorm_bwd")

@@ -428,8 +428,12 @@ int acr_groupnorm_bwd_bf16(const void* dy, const void* x, const void* resid, con
                            const float* stats, void* dx, void* dresid, float* dgamma_part, float* dbeta_part,
                            void* dgamma, void* dbeta, int32_t N, int32_t C, int32_t HW, int32_t act, void* stream);
 
-/* The same at the reference precision (fp32 NCHW tensors, fp32 gamma / beta / gradients): a group is streamed twice instead
- * of being held in registers; HW a multiple of 4; deterministic (fixed-order block reductions, no atomics).
+/* The same at the reference precision (fp32 NCHW tensors, fp32 gamma / beta / gradients): a group of up to 100 352 floats (every
+ * group of the 448^2 step; 50 176 in the backward, which holds x and dy) is read ONCE into the registers of a 1024-thread workgroup
+ * (round 6), larger ones are streamed twice; HW a multiple of 4; deterministic (fixed-order block reductions, no atomics).
+ * _mask_ variants (act 2 only): the forward also writes the ReLU mask of relu(gn(x) + resid), ONE BYTE per 16-byte vector of y
+ * (relu_mask: N*C*HW/4 bytes, bit e = element e of the vector was positive), and the backward reads those bytes INSTEAD of the
+ * residual -- it needs the residual for nothing else (same expression in both directions: the mask is the one the forward applied).
  * ws (forward; nullable): acr_groupnorm_fwd_ws_floats(N, C, HW) floats -- non-zero only for launches of a few samples (CAM
  * generation on one image), whose (sample, group) pairs are then cut into parts over two launches. */
 size_t acr_groupnorm_fwd_ws_floats(int32_t N, int32_t C, int32_t HW);
@@ -438,6 +442,11 @@ int acr_groupnorm_fwd_f32(const float* x, const float* resid, const float* gamma
 int acr_groupnorm_bwd_f32(const float* dy, const float* x, const float* resid, const float* gamma, const float* beta,
                           const float* stats, float* dx, float* dresid, float* dgamma_part, float* dbeta_part, float* dgamma,
                           float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t act, void* stream);
+int acr_groupnorm_fwd_mask_f32(const float* x, const float* resid, const float* gamma, const float* beta, float* y, float* stats,
+                               int32_t N, int32_t C, int32_t HW, float eps, uint8_t* relu_mask, void* stream);
+int acr_groupnorm_bwd_mask_f32(const float* dy, const float* x, const uint8_t* relu_mask, const float* gamma, const float* beta,
+                               const float* stats, float* dx, float* dresid, float* dgamma_part, float* dbeta_part, float* dgamma,
+                               float* dbeta, int32_t N, int32_t C, int32_t HW, void* stream);
 
 /* Weight standardisation of all StdConv2dSame weights of the stem in one launch (models/layers/std_conv.py:56-59).
  * desc_dev: device array of n_conv records {uint64 p0,p1,p2,p3; int32 cout, n, ch_start, pad} sorted by ch_start

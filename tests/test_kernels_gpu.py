@@ -944,12 +944,43 @@ def test_weight_std_all_f32():
         assert (w.grad.double() - wd.grad).abs().max() <= 5e-5 * wd.grad.abs().max()
 
 
-@pytest.mark.parametrize("N,C,H,W", [(2, 64, 8, 8), (3, 256, 16, 24), (2, 1024, 28, 28), (1, 64, 224, 224), (2, 256, 112, 112),
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 8, 8), (2, 1024, 28, 28), (2, 512, 56, 56), (2, 128, 112, 112), (2, 256, 112, 112), (1, 256, 128, 128),
                                      (2, 96, 6, 6)])
+def test_groupnorm_f32_relu_mask_equals_the_residual_path(N, C, H, W, monkeypatch):
+    """Round 6: relu(gn(x) + resid) leaves its ReLU mask as one byte per 16-byte vector (acr_groupnorm_fwd_mask_f32) and the backward
+    reads that instead of the residual (acr_groupnorm_bwd_mask_f32).  Same expression decides the mask in both directions, so y, dx,
+    d(resid), d(gamma), d(beta) must be BIT-identical to the path that re-derives the mask from the residual -- on every kernel
+    family: register-resident groups of 8 / 13 slots, the 25-slot forward with the streamed backward (256 x 112^2), and groups too
+    large for either (256 x 128^2: both directions streamed)."""
+    from acr_wsss_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(C + H)
+    x0 = (torch.randn(N, C, H, W, generator=g) * 1.7 + 0.3).to(dev)
+    r0 = torch.randn(N, C, H, W, generator=g).to(dev)
+    w0 = (1 + 0.2 * torch.randn(C, generator=g)).to(dev)
+    b0 = (0.3 * torch.randn(C, generator=g)).to(dev)
+    dy = torch.randn(N, C, H, W, generator=g).to(dev)
+    outs = []
+    for use_mask in (True, False):
+        monkeypatch.setattr(ops, "GN_RELU_MASK", use_mask)
+        x, r, w, b = (t.clone().requires_grad_(True) for t in (x0, r0, w0, b0))
+        y = ops.groupnorm_act(x, w, b, "add_relu", r)
+        assert (len(y.grad_fn.saved_tensors) == 5) and (y.grad_fn.saved_tensors[4].dtype == (torch.uint8 if use_mask else torch.float32))
+        (y * dy).sum().backward()
+        outs.append((y.detach(), x.grad, r.grad, w.grad, b.grad))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    assert float((outs[0][0] > 0).float().mean()) > 0.2 and float((outs[0][0] == 0).float().mean()) > 0.2       # the mask does something
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 8, 8), (3, 256, 16, 24), (2, 1024, 28, 28), (1, 64, 224, 224), (2, 256, 112, 112),
+                                     (2, 512, 56, 56), (2, 128, 112, 112), (1, 256, 128, 128), (2, 96, 6, 6)])
 @pytest.mark.parametrize("act", ["none", "relu", "add_relu"])
 def test_groupnorm_f32(N, C, H, W, act):
-    """fp32 streaming GroupNorm(32) [+ residual] [+ ReLU] forward/backward (reference precision) vs fp64; includes the
-    largest groups of the 448^2 stem (8 x 112^2 and 2 x 224^2 floats = 401 KB) and tiny groups (3 x 36)."""
+    """fp32 GroupNorm(32) [+ residual] [+ ReLU] forward/backward (reference precision) vs fp64; includes the largest groups of the
+    448^2 stem (8 x 112^2 and 2 x 224^2 floats = 401 KB: 25 register slots per lane forward, streamed backward), the 13-slot
+    groups that are register-resident in both directions (512 x 56^2, 128 x 112^2), a group too large for either (256 x 128^2,
+    the COCO 512^2 geometry: streamed) and tiny groups (3 x 36)."""
     from acr_wsss_amd import ops
     import torch.nn.functional as F
     dev = _dev()
