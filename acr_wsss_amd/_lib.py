@@ -179,7 +179,7 @@ SIGNATURES = {
 # set_option() by tests and lab scripts only; round 6 removed the environment variables that used to feed them at load time
 # (every A/B they served is recorded and settled) -- the library itself never reads the environment.
 OPTIONS = {"gemm_variant": 0, "gemm_nowide": 1, "gemm_regstage": 2, "wgrad_variant": 3, "wgrad_waves": 4, "dq_variant": 5,
-           "gemm_f32_regstage": 6, "attn_delta_1head": 7, "gemm_f32_notail": 9, "attn_f32_nosplittail": 10, "gemm_x3_inkernel": 11}
+           "gemm_f32_regstage": 6, "attn_delta_1head": 7, "gemm_f32_notail": 9, "attn_f32_nosplittail": 10, "gemm_x3_inkernel": 11, "gn_plan": 12}
 
 _lib = None
 

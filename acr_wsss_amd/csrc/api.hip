@@ -27,7 +27,7 @@ extern "C" int acr_version(void) { return ACR_ABI_VERSION; }
 extern "C" const char* acr_last_error(void) { return g_err; }
 
 // ---- explicit option table (the library's only process-wide state; see include/acr_hip.h) ------------------
-static std::atomic<int32_t> g_opt[ACR_OPT_COUNT_] = {{2}, {0}, {0}, {2}, {8}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+static std::atomic<int32_t> g_opt[ACR_OPT_COUNT_] = {{2}, {0}, {0}, {2}, {8}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {3}};
 
 int32_t acr_opt(int option) { return g_opt[option].load(std::memory_order_relaxed); }
 

@@ -311,7 +311,7 @@ __device__ __forceinline__ uint32_t gnf_off(const GnfWalk& wk, int lane, const G
 }
 
 template <int NT, int ACT, int RV>
-__global__ __launch_bounds__(NT) void gnf_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ res,
+__global__ __launch_bounds__(NT, 4) void gnf_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ y, float* __restrict__ stats, int C, int HW, int cg, float eps,
                                                          GnfUnits un, int upw, int ch, uint8_t* __restrict__ mk) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(NT) void gnf_fwd_reg_kernel(const float* __restrict
 }
 
 template <int NT, int ACT, int RV>
-__global__ __launch_bounds__(NT) void gnf_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(NT, 4) void gnf_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ res, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ stats,
                                                          float* __restrict__ dx, float* __restrict__ dres,
@@ -612,16 +612,37 @@ static int gnf_check(const char* who, int N, int C, int HW, int act) {
 #define GNF_RV_FWD_MAX 25
 #define GNF_RV_BWD_MAX 13
 struct GnfRegPlan { bool ok; int nt; GnfUnits un; int upw, ch, slots; };
-static GnfRegPlan gnf_reg_plan(int cg, int HW, int max_slots) {
+static GnfRegPlan gnf_reg_plan_nt(int cg, int HW, int nt) {
     GnfRegPlan p;
-    const int nvec = cg * (HW >> 2);
-    p.nt = nvec > 2048 ? 1024 : 256;
+    p.nt = nt;
     const int nw = p.nt / 64;
     p.un = gnf_units(cg, HW, nw);
     p.ch = (p.un.segv + 63) / 64;
     p.upw = (p.un.units + nw - 1) / nw;
     p.slots = p.upw * p.ch;
-    p.ok = p.slots <= max_slots && p.un.units <= GNF_MAXU && (p.slots <= GNF_RV || p.nt == 1024);
+    p.ok = p.un.units <= GNF_MAXU;
+    return p;
+}
+// Workgroup size of the register-resident kernels (ACR_OPT_GN_PLAN).  The register footprint of a group on a CU is the same
+// whatever the workgroup size; what changes is how many INDEPENDENT workgroups share the CU -- a lone 1024-thread workgroup
+// cannot overlap its load phase with another one's store phase.
+static GnfRegPlan gnf_reg_plan(int cg, int HW, int max_slots, bool backward) {
+    const int nvec = cg * (HW >> 2);
+    int pref = acr_opt(ACR_OPT_GN_PLAN);
+    if (pref == 3) pref = backward ? 2 : 0;
+    static const int order[3] = {256, 512, 1024};
+    GnfRegPlan p;
+    if (pref == 0) {
+        p = gnf_reg_plan_nt(cg, HW, nvec > 2048 ? 1024 : 256);
+        p.ok = p.ok && p.slots <= max_slots && (p.slots <= GNF_RV || p.nt == 1024);
+        return p;
+    }
+    for (int i = 0; i < 3; ++i) {
+        p = gnf_reg_plan_nt(cg, HW, order[i]);
+        const int cap = (pref == 1 && order[i] == 256) ? GNF_RV : max_slots;      // 1: small workgroups only for small groups
+        if (p.ok && p.slots <= cap) return p;
+    }
+    p.ok = false;
     return p;
 }
 #define GNF_LAUNCH_REG(KERNEL, NT_, RV_, P, ...)                                                                                     \
@@ -630,15 +651,17 @@ static GnfRegPlan gnf_reg_plan(int cg, int HW, int max_slots) {
         else if (act == 1) hipLaunchKernelGGL((KERNEL<NT_, 1, RV_>), grid, dim3(NT_), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch, relu_mask);  \
         else hipLaunchKernelGGL((KERNEL<NT_, 2, RV_>), grid, dim3(NT_), 0, st, __VA_ARGS__, (P).un, (P).upw, (P).ch, relu_mask);                \
     }
+#define GNF_LAUNCH_REG_NT(KERNEL, RV_, P, ...)                                                     \
+    if ((P).nt == 256) GNF_LAUNCH_REG(KERNEL, 256, RV_, P, __VA_ARGS__)                            \
+    else if ((P).nt == 512) GNF_LAUNCH_REG(KERNEL, 512, RV_, P, __VA_ARGS__)                       \
+    else GNF_LAUNCH_REG(KERNEL, 1024, RV_, P, __VA_ARGS__)
 #define GNF_DISPATCH_REG_FWD(KERNEL, P, ...)                                                       \
-    if ((P).nt == 256) GNF_LAUNCH_REG(KERNEL, 256, GNF_RV, P, __VA_ARGS__)                         \
-    else if ((P).slots <= GNF_RV) GNF_LAUNCH_REG(KERNEL, 1024, GNF_RV, P, __VA_ARGS__)             \
-    else if ((P).slots <= GNF_RV_BWD_MAX) GNF_LAUNCH_REG(KERNEL, 1024, GNF_RV_BWD_MAX, P, __VA_ARGS__) \
-    else GNF_LAUNCH_REG(KERNEL, 1024, GNF_RV_FWD_MAX, P, __VA_ARGS__)
+    if ((P).slots <= GNF_RV) { GNF_LAUNCH_REG_NT(KERNEL, GNF_RV, P, __VA_ARGS__) }                 \
+    else if ((P).slots <= GNF_RV_BWD_MAX) { GNF_LAUNCH_REG_NT(KERNEL, GNF_RV_BWD_MAX, P, __VA_ARGS__) } \
+    else { GNF_LAUNCH_REG_NT(KERNEL, GNF_RV_FWD_MAX, P, __VA_ARGS__) }
 #define GNF_DISPATCH_REG_BWD(KERNEL, P, ...)                                                       \
-    if ((P).nt == 256) GNF_LAUNCH_REG(KERNEL, 256, GNF_RV, P, __VA_ARGS__)                         \
-    else if ((P).slots <= GNF_RV) GNF_LAUNCH_REG(KERNEL, 1024, GNF_RV, P, __VA_ARGS__)             \
-    else GNF_LAUNCH_REG(KERNEL, 1024, GNF_RV_BWD_MAX, P, __VA_ARGS__)
+    if ((P).slots <= GNF_RV) { GNF_LAUNCH_REG_NT(KERNEL, GNF_RV, P, __VA_ARGS__) }                 \
+    else { GNF_LAUNCH_REG_NT(KERNEL, GNF_RV_BWD_MAX, P, __VA_ARGS__) }
 
 #define GNF_DISPATCH(KERNEL, ...)                                                                                \
     if (big) {                                                                                                    \
@@ -674,7 +697,7 @@ static int gnf_fwd_impl(const float* x, const float* resid, const float* gamma, 
         else hipLaunchKernelGGL((gnf_apply_kernel<2>), pgrid, dim3(256), 0, st, x, resid, gamma, beta, (const float*)ws, y, stats, C, HW, cg, P, vper, eps);
         return acr_check_launch("acr_groupnorm_fwd_f32(parts)");
     }
-    const GnfRegPlan rp = gnf_reg_plan(cg, HW, GNF_RV_FWD_MAX);
+    const GnfRegPlan rp = gnf_reg_plan(cg, HW, GNF_RV_FWD_MAX, false);
     if (rp.ok) {                                            // the group fits the workgroup's registers: one read
         GNF_DISPATCH_REG_FWD(gnf_fwd_reg_kernel, rp, x, resid, gamma, beta, y, stats, C, HW, cg, eps)
         return acr_check_launch("acr_groupnorm_fwd_f32(reg)");
@@ -708,7 +731,7 @@ static int gnf_bwd_impl(const float* dy, const float* x, const float* resid, con
     const bool big = (int64_t)HW >= 4096;                    // per-channel loops: 1024 threads only when a channel feeds them
     const dim3 grid(N * GNF_GROUPS);
     hipStream_t st = (hipStream_t)stream;
-    const GnfRegPlan rp = gnf_reg_plan(cg, HW, GNF_RV_BWD_MAX);
+    const GnfRegPlan rp = gnf_reg_plan(cg, HW, GNF_RV_BWD_MAX, true);
     if (rp.ok) {
         GNF_DISPATCH_REG_BWD(gnf_bwd_reg_kernel, rp, dy, x, resid, gamma, beta, stats, dx, dresid, dgamma_part, dbeta_part, C, HW, cg)
     } else {

@@ -90,6 +90,7 @@ typedef enum acr_option {
     ACR_OPT_GEMM_F32_NOTAIL = 9, /* 1: acr_gemm_f32 NT / NN never K-splits the tiles beyond the last whole half-round (A/B) */
     ACR_OPT_ATTN_F32_NOSPLITTAIL = 10, /* 1: resident-score attention keeps the leftover 32-row block as an ordinary (1 live wave) workgroup (A/B) */
     ACR_OPT_GEMM_X3_INKERNEL = 11, /* 1: split-product acr_gemm_f32 splits operand tiles inside the GEMM kernel instead of once per product into bf16 planes (A/B) */
+    ACR_OPT_GN_PLAN = 12,        /* fp32 GroupNorm, register-resident kernels: workgroup size preference -- 0 = 1024 threads for groups of more than 2048 vectors, 1 = 512 threads where the slots allow, 2 = the smallest of 256 / 512 / 1024 threads whose lanes can hold the group, 3 (default) = 0 in the forward and 2 in the backward: measured fastest, profiles/r06_gn_plans.txt (A/B) */
     ACR_OPT_COUNT_
 } acr_option;
 int     acr_set_option(int32_t option, int32_t value);
