@@ -157,6 +157,7 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
                                                      GnfUnits un, const uint8_t* __restrict__ mk) {
     constexpr int NW = NT / 64;
     __shared__ float shu[2 * GNF_MAXU];                     // per unit: sum(dy'), sum(dy' * xhat)
+    __shared__ float shq[3 * (GNF_MAXU / 2)];               // per channel: sum(dy'), sum(dy' * xhat), gamma
     __shared__ float shc[2];
     const int g = blockIdx.x % GNF_GROUPS, n = blockIdx.x / GNF_GROUPS;
     const int64_t base = ((int64_t)n * C + (int64_t)g * cg) * HW;
@@ -216,17 +217,24 @@ __global__ __launch_bounds__(NT) void gnf_bwd_kernel(const float* __restrict__ d
         if (lane == 0) { shu[2 * u] = db; shu[2 * u + 1] = dg; }
     }
     __syncthreads();
-    if (tid == 0) {                                         // channel sums in segment order, group sums in channel order
+    // channel sums in segment order -- one THREAD per channel (round 6: thread 0 used to walk all cg <= 32 channels alone, a chain
+    // of dependent LDS reads, scalar gamma loads and global stores that the other 1023 threads waited for) -- then the group
+    // sums in channel order by one thread: the same additions in the same order as before
+    if (tid < cg) {
+        const int cl = tid;
+        float db = 0.f, dg = 0.f;
+        for (int sg = 0; sg < un.S; ++sg) { db += shu[2 * (cl * un.S + sg)]; dg += shu[2 * (cl * un.S + sg) + 1]; }
+        const int c = g * cg + cl;
+        dgamma_part[(int64_t)n * C + c] = dg;
+        dbeta_part[(int64_t)n * C + c] = db;
+        shq[3 * cl] = db; shq[3 * cl + 1] = dg; shq[3 * cl + 2] = gamma[c];
+    }
+    __syncthreads();
+    if (tid == 0) {
         float s1 = 0.f, s2 = 0.f;
         for (int cl = 0; cl < cg; ++cl) {
-            float db = 0.f, dg = 0.f;
-            for (int sg = 0; sg < un.S; ++sg) { db += shu[2 * (cl * un.S + sg)]; dg += shu[2 * (cl * un.S + sg) + 1]; }
-            const int c = g * cg + cl;
-            dgamma_part[(int64_t)n * C + c] = dg;
-            dbeta_part[(int64_t)n * C + c] = db;
-            const float gam = gamma[c];
-            s1 = fmaf(db, gam, s1);
-            s2 = fmaf(dg, gam, s2);
+            s1 = fmaf(shq[3 * cl], shq[3 * cl + 2], s1);
+            s2 = fmaf(shq[3 * cl + 1], shq[3 * cl + 2], s2);
         }
         shc[0] = s1 * inv_n;
         shc[1] = s2 * inv_n;
@@ -391,6 +399,7 @@ __global__ __launch_bounds__(NT, 4) void gnf_bwd_reg_kernel(const float* __restr
                                                          int cg, GnfUnits un, int upw, int ch, const uint8_t* __restrict__ mk) {
     constexpr int NW = NT / 64;
     __shared__ float shp[NW * RV * 2];                  // [wave][slot]: sum(dy'), sum(dy' * xhat)
+    __shared__ float shq[3 * (GNF_MAXU / 2)];           // per channel: sum(dy'), sum(dy' * xhat), gamma
     __shared__ float shc[2];
     const int g = blockIdx.x % GNF_GROUPS, n = blockIdx.x / GNF_GROUPS;
     const int64_t base = ((int64_t)n * C + (int64_t)g * cg) * HW;
@@ -451,20 +460,25 @@ __global__ __launch_bounds__(NT, 4) void gnf_bwd_reg_kernel(const float* __restr
         if (lane == 0) { shp[(wave * RV + i) * 2] = db; shp[(wave * RV + i) * 2 + 1] = dg; }
     }
     __syncthreads();
-    if (tid == 0) {                                         // channel sums in (segment, chunk) order, group sums in channel order
+    // channel sums in (segment, chunk) order, one thread per channel; group sums in channel order by one thread (see gnf_bwd_kernel)
+    if (tid < cg) {
+        const int cl = tid;
+        float db = 0.f, dg = 0.f;
+        for (int sg = 0; sg < un.S; ++sg) {
+            const int u = cl * un.S + sg, w = u % NW, k = u / NW;
+            for (int j = 0; j < ch; ++j) { db += shp[(w * RV + k * ch + j) * 2]; dg += shp[(w * RV + k * ch + j) * 2 + 1]; }
+        }
+        const int c = g * cg + cl;
+        dgamma_part[(int64_t)n * C + c] = dg;
+        dbeta_part[(int64_t)n * C + c] = db;
+        shq[3 * cl] = db; shq[3 * cl + 1] = dg; shq[3 * cl + 2] = gamma[c];
+    }
+    __syncthreads();
+    if (tid == 0) {
         float s1 = 0.f, s2 = 0.f;
         for (int cl = 0; cl < cg; ++cl) {
-            float db = 0.f, dg = 0.f;
-            for (int sg = 0; sg < un.S; ++sg) {
-                const int u = cl * un.S + sg, w = u % NW, k = u / NW;
-                for (int j = 0; j < ch; ++j) { db += shp[(w * RV + k * ch + j) * 2]; dg += shp[(w * RV + k * ch + j) * 2 + 1]; }
-            }
-            const int c = g * cg + cl;
-            dgamma_part[(int64_t)n * C + c] = dg;
-            dbeta_part[(int64_t)n * C + c] = db;
-            const float gam = gamma[c];
-            s1 = fmaf(db, gam, s1);
-            s2 = fmaf(dg, gam, s2);
+            s1 = fmaf(shq[3 * cl], shq[3 * cl + 2], s1);
+            s2 = fmaf(shq[3 * cl + 1], shq[3 * cl + 2], s2);
         }
         shc[0] = s1 * inv_n;
         shc[1] = s2 * inv_n;

@@ -50,8 +50,8 @@ PRECISION = {"f32": "fp32 end to end (reference precision, exact-fp32 MFMA)",
 # committed: the `in_step` blocks and `traffic` figures of the line are CONSTANTS read from this file, not measurements of the
 # run that prints the line (only `launch_ms` / `achieved` / `frac` / `value` are measured live) -- the line says so itself
 # (`roofline.profile_source`)
-IN_STEP = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_in_step_kernels.json" % r) for r in (5, 4, 3)) if os.path.exists(p)),
-               os.path.join(ROOT, "profiles", "r05_in_step_kernels.json"))
+IN_STEP = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_in_step_kernels.json" % r) for r in (6, 5, 4, 3)) if os.path.exists(p)),
+               os.path.join(ROOT, "profiles", "r06_in_step_kernels.json"))
 
 
 def parse():
@@ -120,7 +120,7 @@ def roofline_probe(args, dev, dtype, live=None):
     pass of the forward).  When `live` is given (average ms of the same launches measured with HIP events INSIDE the timed
     steps, ops.KernelTimer) `achieved` / `frac` / `launch_ms` are the in-step values and the isolated replay is kept as
     `isolated_launch_ms`.  `frac` is ALGORITHMIC work / time / dense matrix peak of the dtype.  Returns the record of the
-    kernel that is on top of this round's in-step rocprof profile (profiles/r02_in_step_kernels.json) with the others
+    kernel that is on top of this round's in-step rocprof profile (IN_STEP: the newest profiles/rNN_in_step_kernels.json) with the others
     under `kernels`."""
     from acr_wsss_amd import _lib as L, ops
     lib = L.load()
