@@ -18,7 +18,7 @@ case " ${2:-f32_split f32 bf16} " in *" f32_split "*)
   (echo "# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --dtype f32_split --steps 3 --warmup 2 --no-roofline   [$tag tree, scripts/profile_round.sh]"; python3 "$ROOT/scripts/lab/mfma_busy_from_pmc.py" "$ROOT/gpurun_out/${tag}_busy") > "$ROOT/profiles/${tag}_clock_mfma_busy_f32_split.txt" 2>&1
   echo "busy pass done"
   rocprofv3 --kernel-trace --output-format csv -d "$ROOT/gpurun_out/${tag}_infer" -o p -- python3 "$ROOT/scripts/lab/infer_list_busy.py" 5 > "$ROOT/gpurun_out/${tag}_infer.log" 2>&1
-  (echo "# CAM generation, f32_split, scales {0.5,1,1.5,2}, acr_wsss_amd.infer_cam.infer_cam_list with its defaults (batches of 8, pass graphs on): rocprofv3 --kernel-trace"; echo "# -- python3 scripts/lab/infer_list_busy.py 5; the last 3 batches = 24 images, figures PER IMAGE   [$tag tree, scripts/profile_round.sh]"; grep "img/s" "$ROOT/gpurun_out/${tag}_infer.log" | sed 's/^/# under the tracer: /'; python3 "$ROOT/scripts/lab/infer_trace_summary.py" "$(ls "$ROOT"/gpurun_out/${tag}_infer/*/*kernel_trace.csv "$ROOT"/gpurun_out/${tag}_infer/*kernel_trace.csv 2>/dev/null | head -1)" 3 40 4 8) > "$ROOT/profiles/${tag}_infer_trace_summary_f32_split.txt" 2>&1
+  (echo "# CAM generation, f32_split, scales {0.5,1,1.5,2}, acr_wsss_amd.infer_cam.infer_cam_list with its defaults (batches of 8, pass graphs on): rocprofv3 --kernel-trace"; echo "# -- python3 scripts/lab/infer_list_busy.py 5; the last 3 batches = 24 images, figures PER IMAGE   [$tag tree, scripts/profile_round.sh]"; echo "# (the four scales of a batch run on streams of their own: kernel durations overlap, so GPU busy = the SUM of durations exceeds the span)"; grep "img/s" "$ROOT/gpurun_out/${tag}_infer.log" | sed 's/^/# under the tracer: /'; python3 "$ROOT/scripts/lab/infer_trace_summary.py" "$(ls "$ROOT"/gpurun_out/${tag}_infer/*/*kernel_trace.csv "$ROOT"/gpurun_out/${tag}_infer/*kernel_trace.csv 2>/dev/null | head -1)" 3 40 4 8) > "$ROOT/profiles/${tag}_infer_trace_summary_f32_split.txt" 2>&1
   echo "infer trace done"
   rm -rf "$ROOT/gpurun_out/${tag}_busy" "$ROOT/gpurun_out/${tag}_infer"
 ;; esac
