@@ -497,3 +497,21 @@ def test_state_dict_layout_equals_the_references(backbone, layout):
     sd = ACR(num_classes=20, backbone_name=backbone, use_pretrain=False).state_dict()
     assert sorted(sd) == sorted(ref)
     assert all(list(sd[k].shape) == ref[k] for k in ref)
+
+
+def test_environment_switches_stay_few_and_documented():
+    """the host reads a dozen ACR_* environment variables, not 46 -- every settled kernel-variant / host-path A/B is a
+    module attribute or an entry of the library's option table -- and each one that remains is in DESIGN.md's table.  The library
+    itself reads none (no getenv in csrc/)."""
+    import glob
+    import re
+    found = set()
+    for f in glob.glob(os.path.join(ROOT, "acr_wsss_amd", "**", "*.py"), recursive=True) + [os.path.join(ROOT, "bench.py")]:
+        found |= set(re.findall(r"environ[^\n]{0,12}[\"'](ACR_[A-Z0-9_]+)[\"']", open(f).read()))
+    assert 0 < len(found) <= 15, sorted(found)
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    missing = [v for v in found if v not in design]
+    assert not missing, missing
+    for f in glob.glob(os.path.join(ROOT, "acr_wsss_amd", "csrc", "*")):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(f).read(), f
